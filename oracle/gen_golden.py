@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""ORACLE tooling (build container only): generate tests/golden/*.npz by running the REAL reference on CPU.
+
+Usage (from the repo root, in the container that has /root/reference):
+    python oracle/gen_golden.py [--only forward|metrics|bilateral]
+
+The reference's Python never travels to the GPU box; only the vectors written here (inputs are re-generated from
+seeds, outputs are stored) are committed, together with this script.  Imports of the reference:
+  networks/vision_transformer.py, networks/maskformer/{maskformer,transformer_decoder}.py, metrics/*.py,
+  bilateral_solver.py — nothing else (no remote DINO fetch: MaskFormer's encoder factory is re-bound to the local
+  ``deit_small`` constructor).
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(REPO, "salient-object-detection_amd"))
+sys.path.insert(0, REPO)
+GOLD = os.path.join(REPO, "tests", "golden")
+
+from selfmask_amd.state_layout import state_shapes, synthetic_state_dict, synthetic_images  # noqa: E402
+
+N_THREADS = 8
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    if "natsort" not in sys.modules:  # utils/misc.py:7 imports it at module top; unused on this path
+        m = types.ModuleType("natsort")
+        m.natsorted = sorted
+        sys.modules["natsort"] = m
+    import networks.vision_transformer as vits
+    import networks.maskformer.maskformer as mf
+    mf.get_model = lambda arch, patch_size=None, training_method=None, **kw: vits.deit_small(
+        patch_size=patch_size, num_classes=0)
+    return vits, mf
+
+
+def build_reference_model(mf, patch, sd, dtype=torch.float32):
+    model = mf.MaskFormer(n_queries=20, arch="vit_small", patch_size=patch, n_decoder_layers=6,
+                          return_intermediate=True, scale_factor=2, use_binary_classifier=True).eval()
+    ref_sd = model.state_dict()
+    ours = state_shapes(20, patch, 6, True)
+    assert list(ref_sd.keys()) == list(ours.keys()), "state_dict key order differs from the reference"
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == ours[k], (k, tuple(v.shape), ours[k])
+    model.load_state_dict(sd, strict=True)
+    return model.to(dtype)
+
+
+@torch.no_grad()
+def run_reference(model, x):
+    """Whole forward through the reference's own sub-methods so the pre-sigmoid logits are observable."""
+    out = model(x)
+    enc = model.encoder
+    feats = model.forward_encoder(x)  # b x depth x 384 x hw
+    last = feats[:, -1]
+    queries = model.forward_transformer_decoder(last)
+    _h, _w = enc.make_input_divisible(x).shape[-2:]
+    grid = (_h // enc.patch_size, _w // enc.patch_size)
+    up = model.forward_pixel_decoder(last, input_size=grid)
+    logits = torch.einsum("bdqn,bnhw->bdqhw", queries, up)
+    assert torch.equal(torch.sigmoid(logits), out["mask_pred"])
+    tok0 = enc.prepare_tokens(x)
+    blk0 = enc.blocks[0](tok0)
+    return dict(logits=logits, mask_pred=out["mask_pred"], objectness=out["objectness"], features=out["features"],
+                queries=queries, patch_tokens=last.permute(0, 2, 1).contiguous(), tokens0=tok0, block0=blk0,
+                grid=np.array(grid))
+
+
+FORWARD_CASES = [
+    # name, patch, (B,H,W), weight seed, style, input seed, all_layers
+    ("p16_224_soft", 16, (2, 224, 224), 0, "soft", 1234, True),
+    ("p16_224_calib", 16, (2, 224, 224), 4, "calib", 1240, False),
+    ("p16_224_peaky", 16, (2, 224, 224), 1, "peaky", 1235, False),
+    ("p8_224_soft", 8, (1, 224, 224), 2, "soft", 1236, False),
+    ("p16_384_peaky", 16, (1, 384, 384), 3, "peaky", 1237, False),
+    ("p16_250x333_peaky", 16, (1, 250, 333), 1, "peaky", 1238, False),
+    ("p8_200x168_calib", 8, (1, 200, 168), 5, "calib", 1239, False),
+]
+
+
+def gen_forward():
+    vits, mf = _import_reference()
+    torch.set_num_threads(N_THREADS)
+    for name, patch, (B, Hh, Ww), wseed, style, xseed, all_layers in FORWARD_CASES:
+        sd = synthetic_state_dict(wseed, style, patch_size=patch)
+        x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+        m32 = build_reference_model(mf, patch, sd)
+        r32 = run_reference(m32, x)
+        m64 = build_reference_model(mf, patch, sd, torch.float64)
+        r64 = run_reference(m64, x.double())
+        err = (r32["logits"].double() - r64["logits"]).abs().max().item()
+        save = dict(
+            meta=np.array([patch, B, Hh, Ww, wseed, xseed, N_THREADS]),
+            style=np.array(style),
+            grid=r32["grid"],
+            logits_last=r32["logits"][:, -1].numpy(),
+            logits_last_f64=r64["logits"][:, -1].numpy(),
+            objectness=r32["objectness"].numpy(),
+            objectness_f64=r64["objectness"].numpy(),
+            features=r32["features"].numpy(),
+            queries=r32["queries"].numpy(),
+            logit_absmax=np.array(r32["logits"].abs().max().item()),
+            f32_vs_f64_maxabs=np.array(err),
+        )
+        if all_layers:  # the primary case also pins intermediates (image 0 only, to keep the fixture small)
+            save["logits_all"] = r32["logits"].numpy()
+            save["queries_f64"] = r64["queries"].numpy()
+            save["patch_tokens_b0"] = r32["patch_tokens"][0].numpy()
+            save["tokens0_b0"] = r32["tokens0"][0].numpy()
+            save["block0_b0"] = r32["block0"][0].numpy()
+            save["mask_pred_last"] = r32["mask_pred"][:, -1].numpy()
+        fp = os.path.join(GOLD, f"forward_{name}.npz")
+        np.savez_compressed(fp, **save)
+        print(f"{name}: grid={tuple(r32['grid'])} max|logit|={save['logit_absmax']:.2f} "
+              f"std={r32['logits'].std().item():.2f} f32-f64={err:.2e} "
+              f"sat(|l|>10)={(r32['logits'].abs() > 10).float().mean().item():.3f} "
+              f"-> {os.path.getsize(fp) / 1e6:.2f} MB")
+
+
+def _metric_cases():
+    """(pred, gt) pairs covering the branches of metrics/*.py (all-zero / all-one GT, empty prediction, ties)."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    cases = []
+
+    def blob(h, w, cy, cx, ry, rx):
+        yy, xx = np.mgrid[:h, :w]
+        return (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0)
+
+    for (h, w) in [(64, 80), (97, 61), (120, 120)]:
+        gt = blob(h, w, h * 0.45, w * 0.55, h * 0.25, w * 0.3)
+        soft = 1 / (1 + np.exp(-(gt * 6.0 - 3.0 + rng.standard_normal((h, w)) * 1.5)))
+        cases.append((soft.astype(np.float32), gt.astype(np.int64)))
+    h, w = 48, 56
+    gt = blob(h, w, 20, 30, 10, 14)
+    cases.append((rng.random((h, w)).astype(np.float32), np.zeros((h, w), np.int64)))  # GT all zero
+    cases.append((rng.random((h, w)).astype(np.float32), np.ones((h, w), np.int64)))  # GT all one
+    cases.append((np.zeros((h, w), np.float32), gt.astype(np.int64)))  # empty prediction
+    cases.append((np.ones((h, w), np.float32), gt.astype(np.int64)))  # full prediction
+    q = (np.round(rng.random((h, w)) * 255) / 255).astype(np.float32)  # values exactly on the k/255 thresholds
+    cases.append((q, gt.astype(np.int64)))
+    cases.append((gt.astype(np.float32), gt.astype(np.int64)))  # perfect
+    return cases
+
+
+def gen_metrics():
+    sys.path.insert(0, REF)
+    from metrics.iou import compute_iou
+    from metrics.mae import compute_mae
+    from metrics.pixel_acc import compute_pixel_accuracy
+    from metrics.f_measure import FMeasure
+    from metrics.s_measure import SMeasure
+    from metrics.average_meter import AverageMeter
+    save = {}
+    meters = {k: AverageMeter() for k in ("iou", "f_score", "f_max", "f_mean", "mae", "pixel_acc", "s_measure")}
+    for i, (pred, gt) in enumerate(_metric_cases()):
+        p, g = torch.from_numpy(pred), torch.from_numpy(gt)
+        f = FMeasure()(p, g)
+        sm = SMeasure()
+        sm.cuda = False  # metrics/s_measure.py:9 hard-codes .cuda(); the CPU branch is the same arithmetic
+        vals = dict(
+            iou=compute_iou(p, g).numpy(), f_score=f["f_measure"].numpy(), f_max=f["f_max"].numpy(),
+            f_mean=f["f_mean"].numpy(), mae=compute_mae(p, g).numpy(),
+            pixel_acc=compute_pixel_accuracy(p, g).numpy(),
+            s_measure=np.float64(sm(pred_mask=p, gt_mask=g.to(torch.float32))),
+        )
+        save[f"pred_{i}"] = pred
+        save[f"gt_{i}"] = gt.astype(np.uint8)
+        save[f"vals_{i}"] = np.array([np.float64(vals[k]) for k in meters], dtype=np.float64)
+        for k in meters:  # evaluator.pyc@L74-80: meter.update(val=<numpy 0-d>, n=1)
+            meters[k].update(val=vals[k], n=1)
+        print(i, {k: float(v) for k, v in vals.items()})
+    save["n_cases"] = np.array(len(_metric_cases()))
+    save["names"] = np.array(list(meters.keys()))
+    save["avg"] = np.array([np.float64(meters[k].avg) for k in meters], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, "metrics.npz"), **save)
+    print("avg", save["avg"])
+
+
+def _bilateral_cases():
+    rng = np.random.Generator(np.random.PCG64(99))
+    cases = []
+    for (h, w) in [(64, 64), (224, 224), (256, 384)]:
+        yy, xx = np.mgrid[:h, :w]
+        img = np.zeros((h, w, 3), np.float64)
+        img[..., 0] = 40 + 60 * np.sin(xx / 17.0) + 50 * (yy / h)
+        img[..., 1] = 90 + 50 * np.cos(yy / 13.0)
+        img[..., 2] = 120 + 40 * np.sin((xx + yy) / 23.0)
+        obj = (((yy - h * 0.5) / (h * 0.28)) ** 2 + ((xx - w * 0.45) / (w * 0.22)) ** 2) <= 1
+        img[obj] += np.array([90.0, -40.0, 60.0])
+        obj2 = (((yy - h * 0.2) / (h * 0.08)) ** 2 + ((xx - w * 0.85) / (w * 0.07)) ** 2) <= 1
+        img[obj2] += np.array([70.0, 50.0, -60.0])
+        img = np.clip(img + rng.standard_normal(img.shape) * 6, 0, 255).astype(np.uint8)
+        tgt = np.clip(0.15 + 0.7 * obj + 0.5 * obj2 + rng.standard_normal((h, w)) * 0.2, 0, 1)
+        hole = (((yy - h * 0.5) / (h * 0.06)) ** 2 + ((xx - w * 0.45) / (w * 0.05)) ** 2) <= 1
+        tgt[hole] = 0.05  # a hole for binary_fill_holes
+        cases.append((img, tgt.astype(np.float64)))
+    return cases
+
+
+def gen_bilateral():
+    sys.path.insert(0, REF)
+    from PIL import Image
+    import bilateral_solver as bs
+    _cg = bs.cg
+    # bilateral_solver.py:146-147 passes cg(..., tol=) which SciPy>=1.14 renamed to rtol (same meaning, atol=0)
+    bs.cg = lambda A, b, x0=None, M=None, maxiter=None, tol=1e-5: _cg(A, b, x0=x0, M=M, maxiter=maxiter, rtol=tol,
+                                                                       atol=0.0)
+    save = {}
+    for i, (img, tgt) in enumerate(_bilateral_cases()):
+        soft, binary = bs.bilateral_solver_output(Image.fromarray(img), tgt)
+        grid = bs.BilateralGrid(img, sigma_spatial=16, sigma_luma=16, sigma_chroma=8)
+        save[f"img_{i}"] = img
+        save[f"target_{i}"] = tgt
+        save[f"soft_{i}"] = soft
+        save[f"binary_{i}"] = binary
+        save[f"nvert_{i}"] = np.array(grid.nvertices)
+        save[f"blur_nnz_{i}"] = np.array([b.nnz for b in grid.blurs])
+        print(i, img.shape, "V=", grid.nvertices, "nnz=", [b.nnz for b in grid.blurs], "soft range",
+              soft.min(), soft.max(), "binary px", int(binary.sum()))
+    save["n_cases"] = np.array(len(_bilateral_cases()))
+    np.savez_compressed(os.path.join(GOLD, "bilateral.npz"), **save)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    if a.only in (None, "forward"):
+        gen_forward()
+    if a.only in (None, "metrics"):
+        gen_metrics()
+    if a.only in (None, "bilateral"):
+        gen_bilateral()

@@ -1,0 +1,184 @@
+"""ORACLE (test infrastructure, NOT product code): CPU restatement of the SelfMask inference forward pass.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file. The shipped HIP path
+(salient-object-detection_amd/) never does.
+
+Parity status: PINNED. tests/golden/forward_*.npz were produced by running the *real* reference modules
+(/root/reference/networks/...) on CPU in the build container (oracle/gen_golden.py, committed) and this restatement
+is checked against them in tests/test_oracle_golden.py.
+
+The restatement is functional (weights come as a ``state_dict`` mapping) and issues stock torch-CPU ops in the
+reference's order. Each function cites the reference lines it follows. Works in fp32 (the oracle) and fp64 (the
+"truth" used for error attribution) depending on the dtype of the inputs.
+"""
+from typing import Dict, Tuple
+import math
+
+import torch
+import torch.nn.functional as F
+
+D = 384
+H = 6
+DH = 64
+
+
+def _lin(x, sd, prefix):
+    return F.linear(x, sd[prefix + ".weight"], sd[prefix + ".bias"])
+
+
+def make_input_divisible(x: torch.Tensor, patch: int) -> torch.Tensor:
+    """networks/vision_transformer.py:260-267 — zero-pad right/bottom to a multiple of the patch size."""
+    h0, w0 = x.shape[-2:]
+    pad_w = (patch - w0 % patch) % patch
+    pad_h = (patch - h0 % patch) % patch
+    return F.pad(x, (0, pad_w, 0, pad_h), value=0)
+
+
+def interpolate_pos_encoding(pos_embed: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """networks/vision_transformer.py:377-401 — bicubic (align_corners=False) resize of the trained grid."""
+    n0 = pos_embed.shape[1] - 1
+    if size[0] * size[1] == n0:
+        return pos_embed
+    cls, grid = pos_embed[:, 0], pos_embed[:, 1:]
+    g0 = int(math.sqrt(n0))
+    grid = F.interpolate(grid.reshape(1, g0, g0, D).permute(0, 3, 1, 2), size=size, mode="bicubic",
+                         align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).reshape(1, -1, D)
+    return torch.cat((cls.unsqueeze(0), grid), dim=1)
+
+
+def prepare_tokens(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int):
+    """networks/vision_transformer.py:269-281 and PatchEmbed.forward :184-188."""
+    x = make_input_divisible(x, patch)
+    gh, gw = x.shape[-2] // patch, x.shape[-1] // patch
+    t = F.conv2d(x, sd["encoder.patch_embed.proj.weight"], sd["encoder.patch_embed.proj.bias"], stride=patch)
+    t = t.flatten(2).transpose(1, 2)
+    cls = sd["encoder.cls_token"].expand(x.shape[0], -1, -1)
+    t = torch.cat((cls, t), dim=1)
+    t = t + interpolate_pos_encoding(sd["encoder.pos_embed"], (gh, gw))
+    return t, (gh, gw)
+
+
+def encoder_attention(x: torch.Tensor, sd, p: str) -> torch.Tensor:
+    """Attention.forward, networks/vision_transformer.py:110-133."""
+    B, N, C = x.shape
+    qkv = _lin(x, sd, p + "attn.qkv").reshape(B, N, 3, H, DH).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * (DH ** -0.5)
+    attn = attn.softmax(dim=-1)
+    y = (attn @ v).transpose(1, 2).reshape(B, N, C)
+    return _lin(y, sd, p + "attn.proj")
+
+
+def encoder_block(x: torch.Tensor, sd, i: int) -> torch.Tensor:
+    """Block.forward, networks/vision_transformer.py:164-170 (pre-norm, eps 1e-6 from deit_small :522)."""
+    p = f"encoder.blocks.{i}."
+    y = encoder_attention(F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6), sd, p)
+    x = x + y
+    h = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+    h = _lin(F.gelu(_lin(h, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")  # Mlp.forward :88-94 (erf GELU)
+    return x + h
+
+
+def encoder_forward(x: torch.Tensor, sd, patch: int):
+    """VisionTransformer.forward :293-304, last layer only (maskformer.py:107-113,177 use ``[:, -1]``).
+
+    Returns the final-LN'd patch tokens (B, n, 384) (cls dropped) and the patch grid.
+    """
+    t, grid = prepare_tokens(x, sd, patch)
+    for i in range(12):
+        t = encoder_block(t, sd, i)
+    t = F.layer_norm(t, (D,), sd["encoder.norm.weight"], sd["encoder.norm.bias"], 1e-6)
+    return t[:, 1:, :], grid
+
+
+def _mha(q_in, k_in, v_in, sd, p: str, same_kv: bool) -> torch.Tensor:
+    """nn.MultiheadAttention forward (torch/nn/functional.py multi_head_attention_forward, need_weights path):
+    packed in-proj rows q:[0,384) k:[384,768) v:[768,1152); q scaled by 1/sqrt(64) before the product; per-head
+    softmax(q k^T) v; out_proj.  Layout (L, B, E) as used by transformer_decoder.py:271-289."""
+    w, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    L, B, E = q_in.shape
+    S = k_in.shape[0]
+    if same_kv:  # key is value (cross-attn): q separately, k/v with the packed [768,384] block
+        q = F.linear(q_in, w[:E], b[:E])
+        kv = F.linear(k_in, w[E:], b[E:])
+        k, v = kv[..., :E], kv[..., E:]
+    else:  # three separate projections (self-attn: q is k but v differs)
+        q = F.linear(q_in, w[:E], b[:E])
+        k = F.linear(k_in, w[E:2 * E], b[E:2 * E])
+        v = F.linear(v_in, w[2 * E:], b[2 * E:])
+    q = q.reshape(L, B * H, DH).transpose(0, 1)
+    k = k.reshape(S, B * H, DH).transpose(0, 1)
+    v = v.reshape(S, B * H, DH).transpose(0, 1)
+    q = q * math.sqrt(1.0 / DH)
+    a = torch.bmm(q, k.transpose(-2, -1)).softmax(dim=-1)
+    o = torch.bmm(a, v).transpose(0, 1).reshape(L * B, E)
+    o = F.linear(o, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+    return o.view(L, B, E)
+
+
+def decoder_layer(tgt, memory, qpos, sd, j: int) -> torch.Tensor:
+    """TransformerDecoderLayer.forward_post, networks/maskformer/transformer_decoder.py:260-297 (eps 1e-5)."""
+    p = f"decoder.layers.{j}."
+    qk = tgt + qpos
+    t2 = _mha(qk, qk, tgt, sd, p + "self_attn", same_kv=False)
+    tgt = F.layer_norm(tgt + t2, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+    t2 = _mha(tgt + qpos, memory, memory, sd, p + "multihead_attn", same_kv=True)
+    tgt = F.layer_norm(tgt + t2, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    t2 = _lin(F.relu(_lin(tgt, sd, p + "linear1")), sd, p + "linear2")
+    return F.layer_norm(tgt + t2, (D,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
+
+
+def decoder_forward(patch_tokens: torch.Tensor, sd, n_layers: int = 6) -> torch.Tensor:
+    """MaskFormer.forward_transformer_decoder (maskformer.py:118-142) + TransformerDecoder.forward
+    (transformer_decoder.py:112-150) with return_intermediate=True.  patch_tokens (B, n, 384) ->
+    queries (B, n_layers, nq, 384), every layer passed through the shared final ``decoder.norm``."""
+    B = patch_tokens.shape[0]
+    memory = patch_tokens.permute(1, 0, 2)  # (n, B, 384)
+    qpos = sd["query_embed"].unsqueeze(1).repeat(1, B, 1)
+    out = torch.zeros_like(qpos)
+    inter = []
+    for j in range(n_layers):
+        out = decoder_layer(out, memory, qpos, sd, j)
+        inter.append(F.layer_norm(out, (D,), sd["decoder.norm.weight"], sd["decoder.norm.bias"], 1e-5))
+    return torch.stack(inter).permute(2, 0, 1, 3)
+
+
+def pixel_decoder(patch_tokens: torch.Tensor, grid, scale_factor: int = 2) -> torch.Tensor:
+    """MaskFormer.forward_pixel_decoder (maskformer.py:144-162): (B,n,384)->(B,384,gh,gw)-> bilinear x2."""
+    B = patch_tokens.shape[0]
+    f = patch_tokens.permute(0, 2, 1).reshape(B, D, grid[0], grid[1])
+    return F.interpolate(f, scale_factor=scale_factor, mode="bilinear")
+
+
+def objectness_head(queries: torch.Tensor, sd) -> torch.Tensor:
+    """maskformer.py:227-239 + MLP.forward :265-268: sigmoid(W3 relu(W2 relu(W1 q))) -> (B, L, nq, 1)."""
+    x = F.relu(_lin(queries, sd, "ffn.layers.0"))
+    x = F.relu(_lin(x, sd, "ffn.layers.1"))
+    return torch.sigmoid(_lin(x, sd, "ffn.layers.2"))
+
+
+@torch.no_grad()
+def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int = 16, n_layers: int = 6,
+            scale_factor: int = 2) -> Dict[str, torch.Tensor]:
+    """MaskFormer.forward (maskformer.py:164-251), 5-D path (return_intermediate + use_binary_classifier).
+
+    Returns the reference's dict plus ``mask_logits`` (the pre-sigmoid einsum the 1e-4 gate is stated on).
+    """
+    tokens, grid = encoder_forward(x, sd, patch)
+    queries = decoder_forward(tokens, sd, n_layers)
+    features = queries[:, -1].mean(dim=1)  # maskformer.py:198-203
+    up = pixel_decoder(tokens, grid, scale_factor)
+    logits = torch.einsum("bdqn,bnhw->bdqhw", queries, up)  # maskformer.py:223
+    return {
+        "mask_logits": logits,
+        "mask_pred": torch.sigmoid(logits),
+        "objectness": objectness_head(queries, sd),
+        "features": features,
+        "patch_tokens": tokens,
+        "queries": queries,
+    }
+
+
+def cast_state(sd, dtype):
+    return {k: v.to(dtype) for k, v in sd.items()}
