@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the SelfMask inference hot path (ViT-S/16, 224^2, nq=20, batch 64 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
+
+A "step" is one MaskFormer.forward over one batch of synthetic images already resident in HBM (weights = synthetic
+checkpoint seed 0; there is no dataset or checkpoint offline).  Images shard across ranks with no data-path
+collective (weak scaling); the only exchange is the evaluator's end-of-run all-gather of per-image result rows
+(RCCL), issued once after the K steps inside the timed region.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline      - the dominant kernel (fp32-MFMA GEMM family) timed live with HIP events on the launch stream;
+  cpu_baseline  - the CPU oracle (torch-CPU restatement of the reference) on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(REPO, "salient-object-detection_amd"), REPO):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD, 256 CUs @ 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+
+
+def forward_flops_per_image(P, S, L=6, nq=20):
+    """SURVEY.md 8d formulae (algorithmic FLOPs of one MaskFormer.forward)."""
+    g = S // P
+    n, N = g * g, g * g + 1
+    enc = 2 * n * 3 * P * P * 384 + 12 * (2 * N * 384 * 1152 + 4 * N * N * 384 + 2 * N * 384 * 384 + 4 * N * 384 * 1536)
+    dec = L * (12 * nq * 384 * 384 + 4 * nq * nq * 384 + 4 * n * 384 * 384 + 4 * nq * n * 384 + 4 * nq * 384 * 1536)
+    head = L * 2 * nq * 384 * 4 * n + L * nq * (4 * 384 * 384 + 2 * 384)
+    return enc + dec + head
+
+
+def time_dominant_kernel(B, N, iters=5):
+    """Average launch duration of the dominant kernel, gemm_f32_kernel<128,128>: in one forward it is launched 24
+    times on the encoder (12 x qkv [M,384]x[384,1152] and 12 x fc1 [M,384]x[384,1536]); replay exactly that
+    launch mix between two HIP events on the stream the library launches on (torch's current stream)."""
+    from selfmask_amd import ops, _native as Nn
+    M = B * N
+    dev = "cuda"
+    a = torch.randn(M, 384, device=dev)
+    wq, bq = torch.randn(1152, 384, device=dev) * 0.02, torch.zeros(1152, device=dev)
+    w1, b1 = torch.randn(1536, 384, device=dev) * 0.02, torch.zeros(1536, device=dev)
+    cq = torch.empty(M, 1152, device=dev)
+    c1 = torch.empty(M, 1536, device=dev)
+    for _ in range(2):
+        ops.gemm(a, wq, bq, out=cq, tile=(128, 128))
+        ops.gemm(a, w1, b1, epilogue=Nn.EPI_GELU, out=c1, tile=(128, 128))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters * 12):
+        ops.gemm(a, wq, bq, out=cq, tile=(128, 128))
+        ops.gemm(a, w1, b1, epilogue=Nn.EPI_GELU, out=c1, tile=(128, 128))
+    e1.record()
+    torch.cuda.synchronize()
+    launches = iters * 24
+    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
+    flops_per_launch = (2.0 * M * 384 * 1152 + 2.0 * M * 384 * 1536) / 2.0
+    return avg_s, flops_per_launch
+
+
+def cpu_baseline(P, S, budget_s=15.0):
+    """The CPU oracle (torch-CPU restatement, fp32) on this host: bounded sample of the same workload."""
+    from oracle import selfmask_oracle as O  # measured as the BASELINE only, never on the product path
+    from selfmask_amd import synthetic_state_dict, synthetic_images
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = synthetic_state_dict(0, "soft", patch_size=P)
+    Bc = 16
+    x = torch.from_numpy(synthetic_images(1234, (Bc, 3, S, S)))
+    O.forward(x, sd, P)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        O.forward(x, sd, P)
+        n += Bc
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} images (batches of {Bc}, ViT-S/{P} {S}x{S}, fp32 torch-CPU oracle) in {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--patch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images
+    P, S, B = a.patch, a.size, a.batch
+    model = MaskFormer(n_queries=20, patch_size=P, n_decoder_layers=6, return_intermediate=True,
+                       use_binary_classifier=True)
+    model.load_state_dict(synthetic_state_dict(0, "soft", patch_size=P), strict=True)
+    model = model.to(dev)
+    # every rank owns a different shard of the (synthetic) image list: rank-strided seeds
+    x = torch.from_numpy(synthetic_images(1234 + rank, (B, 3, S, S))).to(dev)
+
+    def step():
+        out = model(x)
+        # evaluator's selection (evaluator.pyc@L219-221): highest-objectness query of the last decoder layer
+        return out["objectness"][:, -1, :, 0].argmax(dim=1)
+
+    for _ in range(a.warmup):
+        step()
+    rows = torch.zeros((a.steps * B, 15), device=dev)  # per-image result rows: global index + 14 metric slots
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        sel = step()
+        rows[k * B:(k + 1) * B, 0] = sel.float()
+    if world > 1:  # the path's one exchange: all-gather of the per-image rows
+        gathered = torch.empty((world * rows.shape[0], 15), device=dev)
+        dist.all_gather_into_tensor(gathered, rows)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        n = g = None
+        g = S // P
+        N = g * g + 1
+        value = world * a.steps * B / dt
+        flops_img = forward_flops_per_image(P, S)
+        avg_s, fl = time_dominant_kernel(B, N)
+        ach = fl / avg_s / 1e12
+        res = {
+            "metric": "images/sec (224^2, nq=20)", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
+                                   f"MaskFormer.forward + objectness arg-max (BASELINE.json configs[1])",
+                       "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20,
+                       "parallelism": f"images sharded x{world}, one all-gather of result rows"},
+            "model_tflops": round(value * flops_img / 1e12, 2),
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> (qkv + fc1 launches)",
+                         "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": fl},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(P, S)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

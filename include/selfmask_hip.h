@@ -1,0 +1,177 @@
+/*
+ * selfmask_hip.h — C ABI of libselfmask_hip.so: the MI355X (gfx950) implementation of the SelfMask
+ * saliency-inference hot path (DINO ViT-S encoder -> MaskFormer decoder -> N_q query masks).
+ *
+ * The reference (DaniyalMuneer786/Salient-Object-Detection) has no native/FFI layer: the path sits behind plain
+ * Python objects and every arithmetic step is a stock PyTorch ATen op.  Each entry point below therefore cites the
+ * reference *Python* call site whose ATen op(s) it replaces (file:line relative to the reference root).  The
+ * Python binding a maintainer adds is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (PyTorch allocations);
+ *   - fp32 everywhere (the reference computes in fp32); row-major, innermost dimension contiguous;
+ *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered and never synchronise;
+ *   - kernels never allocate; forward() uses a caller-sized workspace (sm_forward_workspace_bytes);
+ *   - return 0 on success, a negative SM_E* code otherwise; sm_last_error() gives the message (thread-local);
+ *   - stateless and re-entrant: safe from several host threads on distinct streams.
+ */
+#ifndef SELFMASK_HIP_H
+#define SELFMASK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SM_OK 0
+#define SM_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define SM_ELAUNCH (-2)  /* hipLaunchKernel reported an error */
+#define SM_ENOSPACE (-3) /* workspace too small */
+
+#define SM_EMBED 384
+#define SM_HEADS 6
+#define SM_HEAD_DIM 64
+#define SM_MLP 1536
+#define SM_ENC_DEPTH 12
+#define SM_MAX_DEC_LAYERS 8
+
+int sm_version(void);
+const char* sm_last_error(void);
+
+/* ---- epilogues of sm_gemm_f32 ------------------------------------------------------------------------------ */
+#define SM_EPI_BIAS 0      /* C = A W^T + bias                                   (F.linear)                      */
+#define SM_EPI_GELU 1      /* C = gelu_erf(A W^T + bias)                         vision_transformer.py:88-91     */
+#define SM_EPI_RELU 2      /* C = relu(A W^T + bias)                             transformer_decoder.py:293      */
+#define SM_EPI_RESIDUAL 3  /* C = R + (A W^T + bias)                             vision_transformer.py:168-169   */
+#define SM_EPI_SIGMOID2 4  /* C = A W^T (+bias); C2 = sigmoid(C)                 maskformer.py:223               */
+#define SM_EPI_PATCH 5     /* patch-embed: row m -> token (m/n)*(n+1)+1+m%n, + pos_embed[1+m%n]   v_t.py:184-188,280 */
+
+typedef struct sm_gemm_args {
+    const float* A;      /* [batch][M][lda]   activations, K contiguous                                         */
+    const float* W;      /* [batch][N][ldw]   torch Linear weight layout (out_features x in_features)           */
+    const float* bias;   /* [N] or NULL                                                                          */
+    float* C;            /* [batch][M][ldc]                                                                      */
+    const float* R;      /* residual [batch][M][ldr] (SM_EPI_RESIDUAL; may alias C) or pos_embed (SM_EPI_PATCH)  */
+    float* C2;           /* second output (SM_EPI_SIGMOID2) or NULL                                              */
+    const float* A_add;  /* optional: A[m][:] += A_add[m % a_add_rows][:]  (decoder "tgt + query_pos")           */
+    int64_t strideA, strideW, strideC, strideR; /* batch strides in elements (0 = shared)                        */
+    int32_t M, N, K;     /* any M, N >= 1; K % 32 == 0                                                           */
+    int32_t lda, ldw, ldc, ldr;
+    int32_t batch;       /* >= 1                                                                                 */
+    int32_t epilogue;    /* SM_EPI_*                                                                             */
+    int32_t a_add_rows;  /* rows of A_add (0 = none); A_add row stride = lda2                                    */
+    int32_t lda2;
+    int32_t patch_n;     /* SM_EPI_PATCH: patches per image n                                                    */
+} sm_gemm_args;
+
+/* C = epilogue(A W^T): replaces every F.linear / conv-as-GEMM / bmm on the path
+ * (vision_transformer.py:113,131,89-93,186; transformer_decoder.py:271-293; maskformer.py:223,265-268). */
+int sm_gemm_f32(const sm_gemm_args* args, void* stream);
+/* same with the workgroup tile forced (bm x bn in {128x128, 128x64, 64x64}); used by the parity tests to cover
+ * every instantiation and by tuning runs */
+int sm_gemm_f32_tile(const sm_gemm_args* args, int bm, int bn, void* stream);
+
+/* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
+ * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */
+int sm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
+                     int32_t rows, int32_t cols, float eps, void* stream);
+
+/* Same, with a grouped row remap on either side: logical row r reads x row (r/gi)*si + oi + r%gi and writes y row
+ * (r/go)*so + oo + r%go (group size 0 = identity).  Used to drop the cls token while normalising
+ * (maskformer.py:107-108: [:, 1:, :]) and to scatter decoder layer l into the (B,L,nq,384) stack
+ * (transformer_decoder.py:138-147 + maskformer.py:141). */
+typedef struct sm_row_map { int32_t group, stride, offset; } sm_row_map;
+int sm_layernorm_rows_f32(const float* x, int64_t ldx, sm_row_map in_map, const float* gamma, const float* beta,
+                          float* y, int64_t ldy, sm_row_map out_map, int32_t rows, float eps, void* stream);
+
+/* softmax(scale * Q K^T) V per (batch, head), head_dim 64: the q@k^T -> softmax -> @v core of
+ * Attention.forward (vision_transformer.py:122-130) and of nn.MultiheadAttention (transformer_decoder.py:273,283).
+ * Element (b, row, head, d) of X lives at X + b*strideXb + row*strideXr + head*64 + d. */
+typedef struct sm_attn_args {
+    const float *Q, *K, *V;
+    float* O;
+    int64_t sQb, sQr, sKb, sKr, sVb, sVr, sOb, sOr;
+    int32_t batch, heads, n_q, n_k;
+    float scale;
+} sm_attn_args;
+int sm_attention_f32(const sm_attn_args* args, void* stream);
+
+/* im2col of non-overlapping PxP patches with zero padding to a multiple of P (make_input_divisible,
+ * vision_transformer.py:260-267; PatchEmbed conv :182-188): img (B,3,H,W) -> cols (B*gh*gw, 3*P*P), k=(c,i,j). */
+int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream);
+
+/* tokens[b,0,:] = cls + pos[0]   (vision_transformer.py:276-280) */
+int sm_cls_rows_f32(const float* cls, const float* pos, float* tokens, int32_t B, int32_t N, void* stream);
+
+/* bicubic (A=-0.75, align_corners=False) resize of the trained position grid, cls slot copied:
+ * interpolate_pos_encoding (vision_transformer.py:377-401).  pos_in (1+g0*g0,384) -> pos_out (1+gh*gw,384). */
+int sm_pos_embed_bicubic_f32(const float* pos_in, int32_t g0, float* pos_out, int32_t gh, int32_t gw, void* stream);
+
+/* bilinear x2 (align_corners=False) of the patch-token grid, channels-last in and out:
+ * forward_pixel_decoder (maskformer.py:158-161).  tok element (b,p,c) at tok + b*strideb + p*384 + c;
+ * up (B, 2gh*2gw, 384). */
+int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
+                             void* stream);
+
+/* objectness = sigmoid(h . w3 + b3) for each row of h (rows,384): last layer of MLP + sigmoid (maskformer.py:231-239) */
+int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows, void* stream);
+
+/* features[b,:] = mean_q queries[b, last_layer, q, :]   (maskformer.py:198-203) */
+int sm_query_mean_f32(const float* queries, float* features, int32_t B, int32_t L, int32_t nq, void* stream);
+
+/* ---- whole forward --------------------------------------------------------------------------------------------- */
+typedef struct sm_enc_layer {
+    const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w,
+        *fc2_b;
+} sm_enc_layer;
+
+typedef struct sm_dec_layer {
+    const float *sa_in_w, *sa_in_b, *sa_out_w, *sa_out_b; /* self_attn.{in_proj_weight,in_proj_bias,out_proj.*}  */
+    const float *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b; /* multihead_attn.*                                     */
+    const float *lin1_w, *lin1_b, *lin2_w, *lin2_b;
+    const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+} sm_dec_layer;
+
+/* Pointer table over the reference's 267-tensor state_dict; tensors stay owned by the caller. */
+typedef struct sm_weights {
+    const float* query_embed; /* (nq,384) */
+    const float* cls_token;   /* (384)    */
+    const float* pos_embed;   /* (1+g0*g0,384) */
+    const float* patch_w;     /* (384, 3*P*P) */
+    const float* patch_b;
+    sm_enc_layer enc[SM_ENC_DEPTH];
+    const float *enc_norm_w, *enc_norm_b;
+    sm_dec_layer dec[SM_MAX_DEC_LAYERS];
+    const float *dec_norm_w, *dec_norm_b;
+    const float *ffn0_w, *ffn0_b, *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b; /* objectness MLP 384->384->384->1 */
+    int32_t patch;         /* 8 or 16 */
+    int32_t pos_grid;      /* g0: trained grid side (224/patch) */
+    int32_t n_queries;
+    int32_t n_dec_layers;
+} sm_weights;
+
+typedef struct sm_forward_io {
+    const float* x;     /* (B,3,H,W) normalised image */
+    int32_t B, H, W;
+    float* mask_logits; /* (B,L,nq,2gh,2gw) pre-sigmoid einsum (maskformer.py:223) or NULL                       */
+    float* mask_pred;   /* (B,L,nq,2gh,2gw) sigmoid                                                              */
+    float* objectness;  /* (B,L,nq,1) sigmoid                                                                    */
+    float* features;    /* (B,384)                                                                               */
+    float* queries;     /* (B,L,nq,384) decoder outputs after decoder.norm, or NULL (debug/parity tap)           */
+    float* patch_tokens;/* (B,gh*gw,384) final-LN'd encoder tokens, or NULL (debug/parity tap; encoder_only)     */
+    int32_t encoder_only;
+} sm_forward_io;
+
+/* bytes of workspace MaskFormer.forward needs for this shape */
+size_t sm_forward_workspace_bytes(const sm_weights* w, int32_t B, int32_t H, int32_t W);
+
+/* MaskFormer.forward(x) (maskformer.py:164-251) with return_intermediate=True, use_binary_classifier=True. */
+int sm_maskformer_forward(const sm_weights* w, const sm_forward_io* io, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELFMASK_HIP_H */

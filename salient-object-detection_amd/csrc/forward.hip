@@ -1,0 +1,216 @@
+// MaskFormer.forward (maskformer.py:164-251; return_intermediate=True, use_binary_classifier=True) as one
+// stream-ordered sequence of the kernels of this library.  No allocation, no synchronisation: the caller owns the
+// workspace and the stream, so the whole forward can be captured into a hipGraph.
+#include "common.h"
+
+namespace sm {
+
+struct Shape {
+    int B, H, W, P, gh, gw, n, N, L, nq;
+    int64_t M, Mp, Md, Mo;  // tokens, patch tokens, decoder rows, objectness rows
+};
+
+static Shape make_shape(const sm_weights* w, int B, int H, int W) {
+    Shape s;
+    s.B = B; s.H = H; s.W = W; s.P = w->patch;
+    s.gh = (H + s.P - 1) / s.P; s.gw = (W + s.P - 1) / s.P;
+    s.n = s.gh * s.gw; s.N = s.n + 1; s.L = w->n_dec_layers; s.nq = w->n_queries;
+    s.M = (int64_t)B * s.N; s.Mp = (int64_t)B * s.n; s.Md = (int64_t)B * s.nq; s.Mo = s.Md * s.L;
+    return s;
+}
+
+// workspace carve-up (floats, every region 256-B aligned)
+struct Ws {
+    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *KV, *UP, *TGT, *T2, *QK, *Vd, *Qc, *AOd, *HIDd, *QD, *LOG, *O1, *O2;
+    size_t total;
+};
+
+static Ws carve(const Shape& s, float* base) {
+    Ws w;
+    size_t off = 0;
+    auto take = [&](size_t nfloat) {
+        float* p = base ? base + off : nullptr;
+        off += (nfloat + 63) & ~(size_t)63;
+        return p;
+    };
+    const size_t D = SM_EMBED;
+    w.pos = take((size_t)s.N * D);
+    w.X = take(s.M * D);
+    w.Xn = take(s.M * D);
+    w.QKV = take(s.M * 3 * D);
+    w.AO = take(s.M * D);
+    // HID doubles as the im2col buffer (consumed by the patch GEMM before fc1 first writes HID)
+    size_t hid = s.M * SM_MLP, cols = (size_t)s.Mp * 3 * s.P * s.P;
+    w.HID = take(hid > cols ? hid : cols);
+    w.TOK = take(s.Mp * D);
+    w.KV = take(s.Mp * 2 * D);
+    w.UP = take(s.Mp * 4 * D);
+    w.TGT = take(s.Md * D);
+    w.T2 = take(s.Md * D);
+    w.QK = take(s.Md * 2 * D);
+    w.Vd = take(s.Md * D);
+    w.Qc = take(s.Md * D);
+    w.AOd = take(s.Md * D);
+    w.HIDd = take(s.Md * SM_MLP);
+    w.QD = take(s.Mo * D);
+    w.LOG = take(s.Mo * 4 * s.n);
+    w.O1 = take(s.Mo * D);
+    w.O2 = take(s.Mo * D);
+    w.total = off * sizeof(float);
+    return w;
+}
+
+static int linear(const float* A, int lda, const float* W, const float* b, float* C, int ldc, int64_t M, int N, int K,
+                  int epi, const float* R, int ldr, hipStream_t st, const float* A_add = nullptr, int add_rows = 0) {
+    sm_gemm_args g = {};
+    g.A = A; g.W = W; g.bias = b; g.C = C; g.R = R;
+    g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldr = ldr;
+    g.batch = 1; g.epilogue = epi;
+    g.A_add = A_add; g.a_add_rows = add_rows; g.lda2 = SM_EMBED;
+    return sm_gemm_f32(&g, st);
+}
+
+#define TRY(x)                \
+    do {                      \
+        int _rc = (x);        \
+        if (_rc) return _rc;  \
+    } while (0)
+
+static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, hipStream_t st) {
+    const Shape s = make_shape(w, io->B, io->H, io->W);
+    const Ws ws = carve(s, wsbase);
+    const int D = SM_EMBED;
+    const sm_row_map id = {0, 0, 0};
+
+    // ---- tokens: patch embedding + cls + position (vision_transformer.py:269-281) ----------------------------
+    const float* pos = w->pos_embed;
+    if (s.n != w->pos_grid * w->pos_grid) {  // interpolate_pos_encoding compares token COUNTS (:386-388)
+        TRY(sm_pos_embed_bicubic_f32(w->pos_embed, w->pos_grid, ws.pos, s.gh, s.gw, st));
+        pos = ws.pos;
+    }
+    float* cols = ws.HID;
+    TRY(sm_im2col_patches_f32(io->x, cols, s.B, s.H, s.W, s.P, st));
+    TRY(sm_cls_rows_f32(w->cls_token, pos, ws.X, s.B, s.N, st));
+    {
+        sm_gemm_args g = {};
+        g.A = cols; g.W = w->patch_w; g.bias = w->patch_b; g.C = ws.X; g.R = pos;
+        g.M = (int)s.Mp; g.N = D; g.K = 3 * s.P * s.P; g.lda = g.K; g.ldw = g.K; g.ldc = D; g.ldr = D;
+        g.batch = 1; g.epilogue = SM_EPI_PATCH; g.patch_n = s.n;
+        TRY(sm_gemm_f32(&g, st));
+    }
+
+    // ---- 12 pre-norm blocks (vision_transformer.py:164-170) -----------------------------------------------------
+    for (int i = 0; i < SM_ENC_DEPTH; ++i) {
+        const sm_enc_layer& e = w->enc[i];
+        TRY(sm_layernorm_f32(ws.X, D, e.norm1_w, e.norm1_b, ws.Xn, D, (int)s.M, D, 1e-6f, st));
+        TRY(linear(ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, st));
+        sm_attn_args a = {};
+        a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
+        a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
+        a.sOb = (int64_t)s.N * D; a.sOr = D;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
+        TRY(sm_attention_f32(&a, st));
+        TRY(linear(ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D, st));
+        TRY(sm_layernorm_f32(ws.X, D, e.norm2_w, e.norm2_b, ws.Xn, D, (int)s.M, D, 1e-6f, st));
+        TRY(linear(ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, st));
+        TRY(linear(ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D, st));
+    }
+    // final norm on the last layer only (the other 11 per-layer norms of :299 are dead work when
+    // lateral_connection=False), dropping the cls row on the way (maskformer.py:107-108,177)
+    float* tok = io->patch_tokens ? io->patch_tokens : ws.TOK;
+    {
+        const sm_row_map drop_cls = {s.n, s.N, 1};
+        TRY(sm_layernorm_rows_f32(ws.X, D, drop_cls, w->enc_norm_w, w->enc_norm_b, tok, D, id, (int)s.Mp, 1e-6f, st));
+    }
+    if (io->encoder_only) return SM_OK;
+
+    // ---- 6 post-norm decoder layers (transformer_decoder.py:260-297, :112-150) ----------------------------------
+    float* QD = io->queries ? io->queries : ws.QD;
+    if (hipMemsetAsync(ws.TGT, 0, s.Md * D * sizeof(float), st) != hipSuccess) {
+        set_error("sm_maskformer_forward: hipMemsetAsync failed");
+        return SM_ELAUNCH;
+    }
+    const float* qpos = w->query_embed;
+    for (int l = 0; l < s.L; ++l) {
+        const sm_dec_layer& d = w->dec[l];
+        // self-attention: q = k = tgt + query_pos, v = tgt
+        TRY(linear(ws.TGT, D, d.sa_in_w, d.sa_in_b, ws.QK, 2 * D, s.Md, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st, qpos, s.nq));
+        TRY(linear(ws.TGT, D, d.sa_in_w + 2 * D * D, d.sa_in_b + 2 * D, ws.Vd, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st));
+        sm_attn_args a = {};
+        a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.Vd; a.O = ws.AOd;
+        a.sQb = a.sKb = (int64_t)s.nq * 2 * D; a.sQr = a.sKr = 2 * D;
+        a.sVb = (int64_t)s.nq * D; a.sVr = D; a.sOb = (int64_t)s.nq * D; a.sOr = D;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
+        TRY(sm_attention_f32(&a, st));
+        TRY(linear(ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
+        TRY(sm_layernorm_f32(ws.T2, D, d.norm1_w, d.norm1_b, ws.TGT, D, (int)s.Md, D, 1e-5f, st));
+        // cross-attention: q = tgt + query_pos, k = v = memory (pos = None)
+        TRY(linear(ws.TGT, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st, qpos, s.nq));
+        TRY(linear(tok, D, d.ca_in_w + D * D, d.ca_in_b + D, ws.KV, 2 * D, s.Mp, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st));
+        a = {};
+        a.Q = ws.Qc; a.K = ws.KV; a.V = ws.KV + D; a.O = ws.AOd;
+        a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * 2 * D; a.sKr = a.sVr = 2 * D;
+        a.sOb = (int64_t)s.nq * D; a.sOr = D;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
+        TRY(sm_attention_f32(&a, st));
+        TRY(linear(ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
+        TRY(sm_layernorm_f32(ws.T2, D, d.norm2_w, d.norm2_b, ws.TGT, D, (int)s.Md, D, 1e-5f, st));
+        // FFN
+        TRY(linear(ws.TGT, D, d.lin1_w, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, st));
+        TRY(linear(ws.HIDd, SM_MLP, d.lin2_w, d.lin2_b, ws.T2, D, s.Md, D, SM_MLP, SM_EPI_RESIDUAL, ws.TGT, D, st));
+        TRY(sm_layernorm_f32(ws.T2, D, d.norm3_w, d.norm3_b, ws.TGT, D, (int)s.Md, D, 1e-5f, st));
+        // shared final norm on every layer's output, scattered into (B, L, nq, 384)
+        const sm_row_map stack = {s.nq, s.L * s.nq, l * s.nq};
+        TRY(sm_layernorm_rows_f32(ws.TGT, D, id, w->dec_norm_w, w->dec_norm_b, QD, D, stack, (int)s.Md, 1e-5f, st));
+    }
+
+    // ---- heads --------------------------------------------------------------------------------------------------
+    TRY(sm_query_mean_f32(QD, io->features, s.B, s.L, s.nq, st));
+    TRY(sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
+    {
+        // mask_pred[b] = sigmoid(Q[b] (L*nq x 384) . up[b]^T (384 x 4n))   (maskformer.py:223)
+        sm_gemm_args g = {};
+        g.A = QD; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;
+        g.M = s.L * s.nq; g.N = 4 * s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = 4 * s.n;
+        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)4 * s.n * D; g.strideC = (int64_t)s.L * s.nq * 4 * s.n;
+        g.batch = s.B; g.epilogue = SM_EPI_SIGMOID2;
+        TRY(sm_gemm_f32(&g, st));
+    }
+    TRY(linear(QD, D, w->ffn0_w, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, st));
+    TRY(linear(ws.O1, D, w->ffn1_w, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, st));
+    TRY(sm_rowdot_sigmoid_f32(ws.O2, w->ffn2_w, w->ffn2_b, io->objectness, (int)s.Mo, st));
+    return SM_OK;
+}
+
+static int validate(const sm_weights* w, const sm_forward_io* io) {
+    SM_REQUIRE(w && io, "sm_maskformer_forward: null arguments");
+    SM_REQUIRE(w->patch == 8 || w->patch == 16, "sm_maskformer_forward: patch=%d (8 or 16)", w->patch);
+    SM_REQUIRE(w->n_dec_layers >= 1 && w->n_dec_layers <= SM_MAX_DEC_LAYERS, "sm_maskformer_forward: n_dec_layers=%d",
+               w->n_dec_layers);
+    SM_REQUIRE(w->n_queries >= 1 && w->pos_grid >= 1, "sm_maskformer_forward: bad n_queries/pos_grid");
+    SM_REQUIRE(io->x && io->B > 0 && io->H > 0 && io->W > 0, "sm_maskformer_forward: bad input shape");
+    if (!io->encoder_only)
+        SM_REQUIRE(io->mask_pred && io->objectness && io->features, "sm_maskformer_forward: null output");
+    else
+        SM_REQUIRE(io->patch_tokens, "sm_maskformer_forward: encoder_only needs patch_tokens");
+    return SM_OK;
+}
+
+}  // namespace sm
+
+extern "C" size_t sm_forward_workspace_bytes(const sm_weights* w, int32_t B, int32_t H, int32_t W) {
+    if (!w || B <= 0 || H <= 0 || W <= 0 || (w->patch != 8 && w->patch != 16)) return 0;
+    return sm::carve(sm::make_shape(w, B, H, W), nullptr).total;
+}
+
+extern "C" int sm_maskformer_forward(const sm_weights* w, const sm_forward_io* io, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    int rc = sm::validate(w, io);
+    if (rc) return rc;
+    const size_t need = sm_forward_workspace_bytes(w, io->B, io->H, io->W);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace % 256) != 0) {
+        sm::set_error("sm_maskformer_forward: workspace %zu B < %zu B needed (or not 256-B aligned)", workspace_bytes, need);
+        return SM_ENOSPACE;
+    }
+    return sm::forward(w, io, (float*)workspace, (hipStream_t)stream);
+}

@@ -1,0 +1,203 @@
+// HBM-bound helper kernels of the SelfMask path: im2col for the patch embedding, cls rows, bicubic position-grid
+// resize, bilinear x2 of the token grid, objectness row-dot + sigmoid, query mean, thread-local error text.
+#include "common.h"
+#include <math.h>
+#include <string.h>
+
+namespace sm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- im2col: cols[(b,gy,gx)][(c,i,j)] = img[b][c][gy*P+i][gx*P+j], zero beyond H/W ------------------------------
+// one thread per 4 consecutive j (16 B of one image row); consecutive threads walk k fastest so the cols rows are
+// written as full contiguous lines; image reads are P*4-byte runs.
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ cols, int B,
+                                                     int H, int W, int P, int gh, int gw, int64_t total4) {
+    const int K = 3 * P * P, K4 = K / 4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+        const int k4 = (int)(t % K4);
+        const int64_t m = t / K4;
+        const int gx = (int)(m % gw), gy = (int)((m / gw) % gh), b = (int)(m / ((int64_t)gw * gh));
+        const int k = k4 * 4, c = k / (P * P), i = (k / P) % P, j = k % P;
+        const int y = gy * P + i, x = gx * P + j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < H) {
+            const float* src = img + (((int64_t)b * 3 + c) * H + y) * W + x;
+            if (x + 3 < W && (((uintptr_t)src) & 15) == 0) {
+                v = *reinterpret_cast<const float4*>(src);
+            } else {
+                if (x < W) v.x = src[0];
+                if (x + 1 < W) v.y = src[1];
+                if (x + 2 < W) v.z = src[2];
+                if (x + 3 < W) v.w = src[3];
+            }
+        }
+        *reinterpret_cast<float4*>(cols + m * K + k) = v;
+    }
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* tokens, int B,
+                                int N) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < SM_EMBED; c += blockDim.x) tokens[(int64_t)b * N * SM_EMBED + c] = cls[c] + pos[c];
+}
+
+// ---- bicubic (Keys, A = -0.75, align_corners = False), separable: along x for the 4 tap rows, then along y -------
+__device__ __forceinline__ float cubic1(float x) { const float A = -0.75f; return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x) { const float A = -0.75f; return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+
+__global__ __launch_bounds__(128) void pos_bicubic_kernel(const float* __restrict__ pin, int g0, float* __restrict__ pout,
+                                                          int gh, int gw) {
+    const int p = blockIdx.x;  // output token (0 = cls)
+    if (p == 0) {
+        for (int c = threadIdx.x; c < SM_EMBED; c += blockDim.x) pout[c] = pin[c];
+        return;
+    }
+    const int oy = (p - 1) / gw, ox = (p - 1) % gw;
+    const float sy = (float)g0 / (float)gh, sx = (float)g0 / (float)gw;
+    const float ry = sy * (oy + 0.5f) - 0.5f, rx = sx * (ox + 0.5f) - 0.5f;
+    const float fy = floorf(ry), fx = floorf(rx);
+    const int iy = (int)fy, ix = (int)fx;
+    const float ty = ry - fy, tx = rx - fx;
+    const float wy[4] = {cubic2(ty + 1.f), cubic1(ty), cubic1(1.f - ty), cubic2(2.f - ty)};
+    const float wx[4] = {cubic2(tx + 1.f), cubic1(tx), cubic1(1.f - tx), cubic2(2.f - tx)};
+    const float* grid = pin + SM_EMBED;
+    for (int c = threadIdx.x; c < SM_EMBED; c += blockDim.x) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = min(max(iy - 1 + i, 0), g0 - 1);
+            float rowv = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = min(max(ix - 1 + j, 0), g0 - 1);
+                rowv += wx[j] * grid[((int64_t)yy * g0 + xx) * SM_EMBED + c];
+            }
+            acc += wy[i] * rowv;
+        }
+        pout[(int64_t)p * SM_EMBED + c] = acc;
+    }
+}
+
+// ---- bilinear x2, align_corners=False, channels-last: up[b][(oy,ox)][c] ------------------------------------------
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ tok, int64_t strideb,
+                                                         float* __restrict__ up, int gh, int gw, int64_t total4) {
+    const int oh = 2 * gh, ow = 2 * gw, C4 = SM_EMBED / 4;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % C4) * 4;
+        const int64_t px = t / C4;
+        const int ox = (int)(px % ow), oy = (int)((px / ow) % oh), b = (int)(px / ((int64_t)ow * oh));
+        float syf = 0.5f * (oy + 0.5f) - 0.5f, sxf = 0.5f * (ox + 0.5f) - 0.5f;
+        syf = syf < 0.f ? 0.f : syf;
+        sxf = sxf < 0.f ? 0.f : sxf;
+        const int y0 = (int)syf, x0 = (int)sxf;
+        const int y1 = y0 + (y0 < gh - 1 ? 1 : 0), x1 = x0 + (x0 < gw - 1 ? 1 : 0);
+        const float ly1 = syf - y0, ly0 = 1.f - ly1, lx1 = sxf - x0, lx0 = 1.f - lx1;
+        const float* base = tok + (int64_t)b * strideb + c;
+        const float4 p00 = *reinterpret_cast<const float4*>(base + ((int64_t)y0 * gw + x0) * SM_EMBED);
+        const float4 p01 = *reinterpret_cast<const float4*>(base + ((int64_t)y0 * gw + x1) * SM_EMBED);
+        const float4 p10 = *reinterpret_cast<const float4*>(base + ((int64_t)y1 * gw + x0) * SM_EMBED);
+        const float4 p11 = *reinterpret_cast<const float4*>(base + ((int64_t)y1 * gw + x1) * SM_EMBED);
+        float4 o;
+        o.x = ly0 * (lx0 * p00.x + lx1 * p01.x) + ly1 * (lx0 * p10.x + lx1 * p11.x);
+        o.y = ly0 * (lx0 * p00.y + lx1 * p01.y) + ly1 * (lx0 * p10.y + lx1 * p11.y);
+        o.z = ly0 * (lx0 * p00.z + lx1 * p01.z) + ly1 * (lx0 * p10.z + lx1 * p11.z);
+        o.w = ly0 * (lx0 * p00.w + lx1 * p01.w) + ly1 * (lx0 * p10.w + lx1 * p11.w);
+        *reinterpret_cast<float4*>(up + px * SM_EMBED + c) = o;
+    }
+}
+
+// ---- out[row] = sigmoid(h[row] . w + b): one wave per row ---------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __restrict__ hbuf, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* hr = hbuf + (int64_t)row * SM_EMBED;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float2 a = *reinterpret_cast<const float2*>(hr + i * 128 + lane * 2);
+        const float2 ww = *reinterpret_cast<const float2*>(w + i * 128 + lane * 2);
+        s += a.x * ww.x + a.y * ww.y;
+    }
+    s = wave_sum(s) + bias[0];
+    if (lane == 0) out[row] = 1.0f / (1.0f + expf(-s));
+}
+
+__global__ void query_mean_kernel(const float* __restrict__ q, float* __restrict__ f, int L, int nq) {
+    const int b = blockIdx.x;
+    const float* src = q + (((int64_t)b * L + (L - 1)) * nq) * SM_EMBED;
+    for (int c = threadIdx.x; c < SM_EMBED; c += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < nq; ++i) s += src[(int64_t)i * SM_EMBED + c];
+        f[(int64_t)b * SM_EMBED + c] = s / (float)nq;
+    }
+}
+
+static inline int grid_for(int64_t work, int per_block = 256) {
+    int64_t g = (work + per_block - 1) / per_block;
+    return (int)(g > 256 * 8 ? 256 * 8 : (g < 1 ? 1 : g));  // cap at ~8 blocks per CU, grid-stride the rest
+}
+
+}  // namespace sm
+
+extern "C" int sm_version(void) { return 100; }
+extern "C" const char* sm_last_error(void) { return sm::g_err; }
+
+extern "C" int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P,
+                                     void* stream) {
+    SM_REQUIRE(img && cols, "sm_im2col_patches_f32: null pointer");
+    SM_REQUIRE(B > 0 && H > 0 && W > 0 && (P == 8 || P == 16), "sm_im2col_patches_f32: bad shape B=%d H=%d W=%d P=%d", B,
+               H, W, P);
+    const int gh = (H + P - 1) / P, gw = (W + P - 1) / P;
+    const int64_t total4 = (int64_t)B * gh * gw * (3 * P * P / 4);
+    hipLaunchKernelGGL(sm::im2col_kernel, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, img, cols, B, H,
+                       W, P, gh, gw, total4);
+    return sm::check_launch("sm_im2col_patches_f32");
+}
+
+extern "C" int sm_cls_rows_f32(const float* cls, const float* pos, float* tokens, int32_t B, int32_t N, void* stream) {
+    SM_REQUIRE(cls && pos && tokens && B > 0 && N > 0, "sm_cls_rows_f32: bad arguments");
+    hipLaunchKernelGGL(sm::cls_rows_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, cls, pos, tokens, B, N);
+    return sm::check_launch("sm_cls_rows_f32");
+}
+
+extern "C" int sm_pos_embed_bicubic_f32(const float* pos_in, int32_t g0, float* pos_out, int32_t gh, int32_t gw,
+                                        void* stream) {
+    SM_REQUIRE(pos_in && pos_out && g0 > 0 && gh > 0 && gw > 0, "sm_pos_embed_bicubic_f32: bad arguments");
+    hipLaunchKernelGGL(sm::pos_bicubic_kernel, dim3(1 + gh * gw), dim3(128), 0, (hipStream_t)stream, pos_in, g0, pos_out,
+                       gh, gw);
+    return sm::check_launch("sm_pos_embed_bicubic_f32");
+}
+
+extern "C" int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
+                                        void* stream) {
+    SM_REQUIRE(tok && up && B > 0 && gh > 0 && gw > 0 && strideb % 4 == 0, "sm_upsample2x_tokens_f32: bad arguments");
+    const int64_t total4 = (int64_t)B * 4 * gh * gw * (SM_EMBED / 4);
+    hipLaunchKernelGGL(sm::upsample2x_kernel, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, tok, strideb,
+                       up, gh, gw, total4);
+    return sm::check_launch("sm_upsample2x_tokens_f32");
+}
+
+extern "C" int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows,
+                                     void* stream) {
+    SM_REQUIRE(h && w && b && out && rows > 0, "sm_rowdot_sigmoid_f32: bad arguments");
+    hipLaunchKernelGGL(sm::rowdot_sigmoid_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, h, w, b, out,
+                       rows);
+    return sm::check_launch("sm_rowdot_sigmoid_f32");
+}
+
+extern "C" int sm_query_mean_f32(const float* queries, float* features, int32_t B, int32_t L, int32_t nq, void* stream) {
+    SM_REQUIRE(queries && features && B > 0 && L > 0 && nq > 0, "sm_query_mean_f32: bad arguments");
+    hipLaunchKernelGGL(sm::query_mean_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, queries, features, L, nq);
+    return sm::check_launch("sm_query_mean_f32");
+}

@@ -1,0 +1,11 @@
+"""selfmask_amd - MI355X-native SelfMask saliency inference (ViT-S encoder -> MaskFormer decoder -> query masks).
+
+Host side mirrors the reference's Python surface; arithmetic runs in hand-written gfx950 kernels behind the C ABI of
+``include/selfmask_hip.h`` (``lib/libselfmask_hip.so``).
+"""
+from .maskformer import MaskFormer, load_checkpoint  # noqa: F401
+from .misc import get_model, set_seeds  # noqa: F401
+from .base_structure import BaseStructure  # noqa: F401
+from .state_layout import state_shapes, synthetic_state_dict, synthetic_images  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,116 @@
+"""ctypes binding of libselfmask_hip.so (C ABI declared in include/selfmask_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, ``load()`` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libselfmask_hip.so"))
+
+EMBED, HEADS, HEAD_DIM, MLP, ENC_DEPTH, MAX_DEC_LAYERS = 384, 6, 64, 1536, 12, 8
+EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID2, EPI_PATCH = range(6)
+
+fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("R", fp), ("C2", fp), ("A_add", fp),
+                ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
+                ("batch", C.c_int32), ("epilogue", C.c_int32), ("a_add_rows", C.c_int32), ("lda2", C.c_int32),
+                ("patch_n", C.c_int32)]
+
+
+class RowMap(C.Structure):
+    _fields_ = [("group", C.c_int32), ("stride", C.c_int32), ("offset", C.c_int32)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", fp), ("K", fp), ("V", fp), ("O", fp),
+                ("sQb", C.c_int64), ("sQr", C.c_int64), ("sKb", C.c_int64), ("sKr", C.c_int64),
+                ("sVb", C.c_int64), ("sVr", C.c_int64), ("sOb", C.c_int64), ("sOr", C.c_int64),
+                ("batch", C.c_int32), ("heads", C.c_int32), ("n_q", C.c_int32), ("n_k", C.c_int32),
+                ("scale", C.c_float)]
+
+
+ENC_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
+              "fc2_w", "fc2_b"]
+DEC_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
+              "lin1_w", "lin1_b", "lin2_w", "lin2_b", "norm1_w", "norm1_b", "norm2_w", "norm2_b", "norm3_w",
+              "norm3_b"]
+
+
+class EncLayer(C.Structure):
+    _fields_ = [(n, fp) for n in ENC_FIELDS]
+
+
+class DecLayer(C.Structure):
+    _fields_ = [(n, fp) for n in DEC_FIELDS]
+
+
+class Weights(C.Structure):
+    _fields_ = [("query_embed", fp), ("cls_token", fp), ("pos_embed", fp), ("patch_w", fp), ("patch_b", fp),
+                ("enc", EncLayer * ENC_DEPTH), ("enc_norm_w", fp), ("enc_norm_b", fp),
+                ("dec", DecLayer * MAX_DEC_LAYERS), ("dec_norm_w", fp), ("dec_norm_b", fp),
+                ("ffn0_w", fp), ("ffn0_b", fp), ("ffn1_w", fp), ("ffn1_b", fp), ("ffn2_w", fp), ("ffn2_b", fp),
+                ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
+                ("n_dec_layers", C.c_int32)]
+
+
+class ForwardIO(C.Structure):
+    _fields_ = [("x", fp), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("mask_logits", fp), ("mask_pred", fp), ("objectness", fp), ("features", fp), ("queries", fp),
+                ("patch_tokens", fp), ("encoder_only", C.c_int32)]
+
+
+# every symbol include/selfmask_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "sm_version": (C.c_int, []),
+    "sm_last_error": (C.c_char_p, []),
+    "sm_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), fp]),
+    "sm_gemm_f32_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, fp]),
+    "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),
+    "sm_layernorm_rows_f32": (C.c_int, [fp, C.c_int64, RowMap, fp, fp, fp, C.c_int64, RowMap, C.c_int32, C.c_float,
+                                        fp]),
+    "sm_attention_f32": (C.c_int, [C.POINTER(AttnArgs), fp]),
+    "sm_im2col_patches_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_cls_rows_f32": (C.c_int, [fp, fp, fp, C.c_int32, C.c_int32, fp]),
+    "sm_pos_embed_bicubic_f32": (C.c_int, [fp, C.c_int32, fp, C.c_int32, C.c_int32, fp]),
+    "sm_upsample2x_tokens_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
+    "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Weights), C.c_int32, C.c_int32, C.c_int32]),
+    "sm_maskformer_forward": (C.c_int, [C.POINTER(Weights), C.POINTER(ForwardIO), fp, C.c_size_t, fp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or fail loudly (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"selfmask_amd: {LIB_PATH} is missing - build it with `python salient-object-detection_amd/build.py` "
+            f"(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the product path.")
+    try:  # make sure PyTorch's HIP runtime (same soname, libamdhip64.so.7) is the one already mapped
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - the library itself only needs libamdhip64
+        pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not export what the header declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().sm_last_error()
+        raise RuntimeError(f"selfmask_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's ``networks.maskformer.maskformer.MaskFormer`` (maskformer.py:11-251).
+
+Same constructor arguments, same 267-tensor ``state_dict`` (so ``selfmask_nq20.pt`` loads unchanged), same
+``forward(x, encoder_only=False, skip_decoder=False) -> dict``; the arithmetic runs in libselfmask_hip.so.
+The sub-modules below are parameter containers only (they give the parameters the reference's names); their own
+``forward`` methods are never called on the product path.
+"""
+from math import ceil
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+class _Mlp(nn.Module):  # vision_transformer.py:78-94
+    def __init__(self, d, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(d, hidden)
+        self.fc2 = nn.Linear(hidden, d)
+
+
+class _Attention(nn.Module):  # vision_transformer.py:97-133
+    def __init__(self, d):
+        super().__init__()
+        self.qkv = nn.Linear(d, 3 * d, bias=True)
+        self.proj = nn.Linear(d, d)
+
+
+class _Block(nn.Module):  # vision_transformer.py:136-170
+    def __init__(self, d, hidden):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(d, eps=1e-6)
+        self.attn = _Attention(d)
+        self.norm2 = nn.LayerNorm(d, eps=1e-6)
+        self.mlp = _Mlp(d, hidden)
+
+
+class _PatchEmbed(nn.Module):  # vision_transformer.py:173-188
+    def __init__(self, patch, d):
+        super().__init__()
+        self.proj = nn.Conv2d(3, d, kernel_size=patch, stride=patch)
+
+
+class VisionTransformerParams(nn.Module):
+    """Parameter container with the attributes callers read off ``model.encoder``."""
+
+    def __init__(self, patch_size: int = 16, embed_dim: int = N.EMBED, depth: int = N.ENC_DEPTH,
+                 num_heads: int = N.HEADS, mlp_ratio: int = 4):
+        super().__init__()
+        self.patch_embed = _PatchEmbed(patch_size, embed_dim)
+        n0 = (224 // patch_size) ** 2  # PatchEmbed is always built for 224x224 (vision_transformer.py:213-218)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n0 + 1, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, embed_dim * mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.depth = depth
+        self.embed_dim = self.n_embs = embed_dim
+        self.mlp_ratio = mlp_ratio
+        self.n_heads = num_heads
+        self.patch_size = patch_size
+
+    def make_input_divisible(self, x: torch.Tensor) -> torch.Tensor:
+        """vision_transformer.py:260-267 (shape helper for callers; the HIP im2col pads implicitly)."""
+        h0, w0 = x.shape[-2:]
+        pad_w = (self.patch_size - w0 % self.patch_size) % self.patch_size
+        pad_h = (self.patch_size - h0 % self.patch_size) % self.patch_size
+        return nn.functional.pad(x, (0, pad_w, 0, pad_h), value=0)
+
+
+class _DecoderLayer(nn.Module):  # transformer_decoder.py:229-258
+    def __init__(self, d, heads, hidden):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d, heads, dropout=0.0)
+        self.multihead_attn = nn.MultiheadAttention(d, heads, dropout=0.0)
+        self.linear1 = nn.Linear(d, hidden)
+        self.linear2 = nn.Linear(hidden, d)
+        self.norm1 = nn.LayerNorm(d)
+        self.norm2 = nn.LayerNorm(d)
+        self.norm3 = nn.LayerNorm(d)
+
+
+class _Decoder(nn.Module):  # transformer_decoder.py:104-111
+    def __init__(self, d, heads, hidden, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_DecoderLayer(d, heads, hidden) for _ in range(n_layers)])
+        self.norm = nn.LayerNorm(d)
+        self.num_layers = n_layers
+
+
+class _MLPHead(nn.Module):  # maskformer.py:254-268
+    def __init__(self, d_in, d_hidden, d_out, num_layers):
+        super().__init__()
+        h = [d_hidden] * (num_layers - 1)
+        self.num_layers = num_layers
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([d_in] + h, h + [d_out]))
+
+
+class MaskFormer(nn.Module):
+    def __init__(
+            self,
+            n_queries: int = 100,
+            arch: str = "vit_small",
+            patch_size: int = 8,
+            training_method: str = "dino",
+            n_decoder_layers: int = 6,
+            normalize_before: bool = False,
+            return_intermediate: bool = False,
+            learnable_pixel_decoder: bool = False,
+            lateral_connection: bool = False,
+            scale_factor: int = 2,
+            abs_2d_pe_init: bool = False,
+            use_binary_classifier: bool = False
+    ):
+        super().__init__()
+        if arch != "vit_small":
+            raise NotImplementedError(f"arch={arch!r}: only the DINO ViT-S encoder is on the MI355X hot path "
+                                      f"(resnet50 backbones are out of scope, SURVEY.md section 2 #11)")
+        if patch_size not in (8, 16):
+            raise ValueError(f"patch_size={patch_size}: ViT-S/8 and ViT-S/16 are supported")
+        if normalize_before or learnable_pixel_decoder or lateral_connection or scale_factor != 2:
+            raise NotImplementedError("normalize_before / learnable_pixel_decoder / lateral_connection / "
+                                      "scale_factor != 2 are not used by the shipped config and not implemented")
+        if not 1 <= n_decoder_layers <= N.MAX_DEC_LAYERS:
+            raise ValueError(f"n_decoder_layers={n_decoder_layers} (1..{N.MAX_DEC_LAYERS})")
+        d = N.EMBED
+        # NB: unlike utils/misc.py:196,243 no remote DINO weights are fetched; the checkpoint overwrites them anyway.
+        self.encoder = VisionTransformerParams(patch_size=patch_size)
+        self.decoder = _Decoder(d, N.HEADS, d * self.encoder.mlp_ratio, n_decoder_layers)
+        self.query_embed = nn.Embedding(n_queries, d).weight  # registered as parameter "query_embed"
+        if use_binary_classifier:
+            self.ffn = _MLPHead(d, d, 1, num_layers=3)
+        else:
+            self.ffn = _MLPHead(d, d, d, num_layers=3)
+            self.linear_classifier = nn.Linear(d, 2)
+            self.norm = nn.LayerNorm(d)
+        self.arch = arch
+        self.use_binary_classifier = use_binary_classifier
+        self.lateral_connection = lateral_connection
+        self.learnable_pixel_decoder = learnable_pixel_decoder
+        self.scale_factor = scale_factor
+        self.return_intermediate = return_intermediate
+        self.n_queries = n_queries
+        self.n_decoder_layers = n_decoder_layers
+        self._table = None       # (Weights struct, key) cache
+        self._workspace = {}     # (device, B, H, W) -> uint8 tensor
+        self.eval()
+
+    # ---- weight pointer table -------------------------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .float() move storage: drop cached pointers
+        self._table = None
+        self._workspace = {}
+        return super()._apply(fn, *a, **kw)
+
+    def _weights(self) -> N.Weights:
+        key = (self.query_embed.data_ptr(), self.ffn.layers[2].bias.data_ptr(), self.encoder.pos_embed.data_ptr())
+        if self._table is not None and self._table[1] == key:
+            return self._table[0]
+        for n_, p in self.named_parameters():
+            if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError(f"parameter {n_} must be a contiguous float32 tensor on a HIP device "
+                                   f"(got {p.device}, {p.dtype}); the product path has no CPU fallback")
+        w = N.Weights()
+        e = self.encoder
+        w.query_embed = self.query_embed.data_ptr()
+        w.cls_token = e.cls_token.data_ptr()
+        w.pos_embed = e.pos_embed.data_ptr()
+        w.patch_w = e.patch_embed.proj.weight.data_ptr()
+        w.patch_b = e.patch_embed.proj.bias.data_ptr()
+        for i, blk in enumerate(e.blocks):
+            L = w.enc[i]
+            L.norm1_w, L.norm1_b = blk.norm1.weight.data_ptr(), blk.norm1.bias.data_ptr()
+            L.qkv_w, L.qkv_b = blk.attn.qkv.weight.data_ptr(), blk.attn.qkv.bias.data_ptr()
+            L.proj_w, L.proj_b = blk.attn.proj.weight.data_ptr(), blk.attn.proj.bias.data_ptr()
+            L.norm2_w, L.norm2_b = blk.norm2.weight.data_ptr(), blk.norm2.bias.data_ptr()
+            L.fc1_w, L.fc1_b = blk.mlp.fc1.weight.data_ptr(), blk.mlp.fc1.bias.data_ptr()
+            L.fc2_w, L.fc2_b = blk.mlp.fc2.weight.data_ptr(), blk.mlp.fc2.bias.data_ptr()
+        w.enc_norm_w, w.enc_norm_b = e.norm.weight.data_ptr(), e.norm.bias.data_ptr()
+        for j, lay in enumerate(self.decoder.layers):
+            L = w.dec[j]
+            L.sa_in_w, L.sa_in_b = lay.self_attn.in_proj_weight.data_ptr(), lay.self_attn.in_proj_bias.data_ptr()
+            L.sa_out_w, L.sa_out_b = lay.self_attn.out_proj.weight.data_ptr(), lay.self_attn.out_proj.bias.data_ptr()
+            L.ca_in_w, L.ca_in_b = lay.multihead_attn.in_proj_weight.data_ptr(), lay.multihead_attn.in_proj_bias.data_ptr()
+            L.ca_out_w = lay.multihead_attn.out_proj.weight.data_ptr()
+            L.ca_out_b = lay.multihead_attn.out_proj.bias.data_ptr()
+            L.lin1_w, L.lin1_b = lay.linear1.weight.data_ptr(), lay.linear1.bias.data_ptr()
+            L.lin2_w, L.lin2_b = lay.linear2.weight.data_ptr(), lay.linear2.bias.data_ptr()
+            L.norm1_w, L.norm1_b = lay.norm1.weight.data_ptr(), lay.norm1.bias.data_ptr()
+            L.norm2_w, L.norm2_b = lay.norm2.weight.data_ptr(), lay.norm2.bias.data_ptr()
+            L.norm3_w, L.norm3_b = lay.norm3.weight.data_ptr(), lay.norm3.bias.data_ptr()
+        w.dec_norm_w, w.dec_norm_b = self.decoder.norm.weight.data_ptr(), self.decoder.norm.bias.data_ptr()
+        f = self.ffn.layers
+        w.ffn0_w, w.ffn0_b = f[0].weight.data_ptr(), f[0].bias.data_ptr()
+        w.ffn1_w, w.ffn1_b = f[1].weight.data_ptr(), f[1].bias.data_ptr()
+        w.ffn2_w, w.ffn2_b = f[2].weight.data_ptr(), f[2].bias.data_ptr()
+        w.patch = e.patch_size
+        w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))
+        w.n_queries = self.n_queries
+        w.n_dec_layers = self.n_decoder_layers
+        self._table = (w, key)
+        return w
+
+    def _get_workspace(self, w: N.Weights, x: torch.Tensor) -> torch.Tensor:
+        B, _, H, W = x.shape
+        k = (x.device, B, H, W)
+        ws = self._workspace.get(k)
+        if ws is None:
+            nbytes = N.load().sm_forward_workspace_bytes(w, B, H, W)
+            if nbytes == 0:
+                raise RuntimeError("sm_forward_workspace_bytes returned 0 (bad shape)")
+            if len(self._workspace) > 4:  # keep a few shapes resident, not an unbounded set
+                self._workspace.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            self._workspace[k] = ws
+        return ws
+
+    # ---- forward ----------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, encoder_only: bool = False, skip_decoder: bool = False,
+                return_logits: bool = False) -> Dict[str, torch.Tensor]:
+        """x: (B,3,H,W) normalised image on a HIP device.  Output dict as maskformer.py:240-251:
+        5-D path -> {"objectness" (B,L,nq,1), "mask_pred" (B,L,nq,2gh,2gw) in [0,1], "features" (B,384)};
+        3-D path (return_intermediate=False, use_binary_classifier=False) -> {"mask_pred" logits (B,nq,2gh,2gw),
+        "features"}.  ``return_logits`` additionally returns the pre-sigmoid einsum as "mask_logits" and the decoder
+        queries / encoder patch tokens (parity taps)."""
+        if not x.is_cuda:
+            raise RuntimeError("MaskFormer (MI355X) needs its input on a HIP device; there is no CPU fallback")
+        if self.training:
+            raise RuntimeError("inference-only implementation: call model.eval()")
+        if self.return_intermediate and not self.use_binary_classifier:
+            raise NotImplementedError("return_intermediate=True with use_binary_classifier=False (ffn-projected "
+                                      "queries, maskformer.py:225) is not implemented")
+        if not self.return_intermediate and self.use_binary_classifier:
+            # the reference permutes a 3-D tensor with 4 indices at maskformer.py:229 and raises
+            raise RuntimeError("use_binary_classifier=True requires loss_every_decoder_layer/return_intermediate=True")
+        lib = N.load()
+        x = x.contiguous().float()
+        B, c, H, W = x.shape
+        assert c == 3, "expected an RGB image batch (B,3,H,W)"
+        p = self.encoder.patch_size
+        gh, gw = ceil(H / p), ceil(W / p)
+        L, nq, dev = self.n_decoder_layers, self.n_queries, x.device
+        w = self._weights()
+        ws = self._get_workspace(w, x)
+        io = N.ForwardIO()
+        io.x, io.B, io.H, io.W = x.data_ptr(), B, H, W
+        if encoder_only:
+            # the reference's encoder_only branch raises on a non-contiguous view (maskformer.py:188); return the
+            # evident intent: (B, gh, gw, 384) patch tokens
+            tokens = torch.empty((B, gh * gw, N.EMBED), device=dev, dtype=torch.float32)
+            io.patch_tokens, io.encoder_only = tokens.data_ptr(), 1
+            N.check(lib.sm_maskformer_forward(w, io, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                    "sm_maskformer_forward")
+            return {"patch_tokens": tokens.view(B, gh, gw, N.EMBED)}
+        mask_pred = torch.empty((B, L, nq, 2 * gh, 2 * gw), device=dev, dtype=torch.float32)
+        objectness = torch.empty((B, L, nq, 1), device=dev, dtype=torch.float32)
+        features = torch.empty((B, N.EMBED), device=dev, dtype=torch.float32)
+        io.mask_pred, io.objectness, io.features = mask_pred.data_ptr(), objectness.data_ptr(), features.data_ptr()
+        extras = {}
+        if return_logits or not self.return_intermediate:
+            logits = torch.empty_like(mask_pred)
+            io.mask_logits = logits.data_ptr()
+            extras["mask_logits"] = logits
+        if return_logits:
+            extras["queries"] = torch.empty((B, L, nq, N.EMBED), device=dev, dtype=torch.float32)
+            extras["patch_tokens"] = torch.empty((B, gh * gw, N.EMBED), device=dev, dtype=torch.float32)
+            io.queries, io.patch_tokens = extras["queries"].data_ptr(), extras["patch_tokens"].data_ptr()
+        N.check(lib.sm_maskformer_forward(w, io, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
+                "sm_maskformer_forward")
+        if not self.return_intermediate:  # 3-D path: last layer, un-sigmoided (maskformer.py:219-220)
+            out = {"mask_pred": extras["mask_logits"][:, -1], "features": features}
+        else:
+            out = {"objectness": objectness, "mask_pred": mask_pred, "features": features}
+        if return_logits:
+            out.update(extras)
+        return out
+
+
+def load_checkpoint(model: MaskFormer, path: str, map_location="cpu", strict: bool = True):
+    """Accept both checkpoint forms of the reference: a raw state_dict (evaluator.pyc@L357-359) or
+    ``{'model': state_dict, ...}`` (app.py:185-186, test_model.py:112-113)."""
+    ckpt = torch.load(path, map_location=map_location, weights_only=True)
+    sd = ckpt.get("model", ckpt) if isinstance(ckpt, dict) and "model" in ckpt else ckpt
+    return model.load_state_dict(sd, strict=strict)

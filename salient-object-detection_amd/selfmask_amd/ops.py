@@ -1,0 +1,131 @@
+"""Per-operator Python entry points over the C ABI (torch tensors in, torch tensors out, current HIP stream).
+
+PyTorch is plumbing here: device memory + streams.  Every function launches hand-written gfx950 kernels from
+libselfmask_hip.so and raises if handed a CPU tensor (there is no fallback path).
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _native as N
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise RuntimeError("selfmask_amd ops need float32 tensors on a HIP device (no CPU fallback)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = N.EPI_BIAS,
+         residual: Optional[torch.Tensor] = None, a_add: Optional[torch.Tensor] = None,
+         tile: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None,
+         out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = epilogue(A W^T + bias).  a: (M,K) or (batch,M,K); w: (N,K) or (batch,N,K) (torch Linear layout)."""
+    _dev(a, w, bias, residual, a_add)
+    lib = N.load()
+    a3 = a if a.dim() == 3 else a.unsqueeze(0)
+    w3 = w if w.dim() == 3 else w.unsqueeze(0)
+    assert a3.stride(-1) == 1 and w3.stride(-1) == 1
+    batch = max(a3.shape[0], w3.shape[0])
+    M, K = a3.shape[1], a3.shape[2]
+    Nn = w3.shape[1]
+    c = out if out is not None else torch.empty((batch, M, Nn), device=a.device, dtype=torch.float32)
+    c3 = c if c.dim() == 3 else c.unsqueeze(0)
+    g = N.GemmArgs()
+    g.A, g.W, g.bias, g.C = a3.data_ptr(), w3.data_ptr(), _ptr(bias), c3.data_ptr()
+    g.strideA = a3.stride(0) if a3.shape[0] > 1 else 0
+    g.strideW = w3.stride(0) if w3.shape[0] > 1 else 0
+    g.strideC = c3.stride(0)
+    g.M, g.N, g.K = M, Nn, K
+    g.lda, g.ldw, g.ldc = a3.stride(1), w3.stride(1), c3.stride(1)
+    g.batch, g.epilogue = batch, epilogue
+    if residual is not None:
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        g.R, g.ldr = r3.data_ptr(), r3.stride(1)
+        g.strideR = r3.stride(0) if r3.shape[0] > 1 else 0
+    if a_add is not None:
+        g.A_add, g.a_add_rows, g.lda2 = a_add.data_ptr(), a_add.shape[0], a_add.stride(0)
+    if epilogue == N.EPI_SIGMOID2:
+        c2 = out2 if out2 is not None else torch.empty_like(c)
+        g.C2 = c2.data_ptr()
+    if tile is None:
+        N.check(lib.sm_gemm_f32(g, _stream()), "sm_gemm_f32")
+    else:
+        N.check(lib.sm_gemm_f32_tile(g, tile[0], tile[1], _stream()), "sm_gemm_f32_tile")
+    res = c if a.dim() == 3 or w.dim() == 3 or out is not None else c[0]
+    if epilogue == N.EPI_SIGMOID2:
+        return res, (c2 if c2.dim() == res.dim() else c2[0])
+    return res
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    _dev(x, gamma, beta)
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.stride(1) == 1
+    y = torch.empty((x2.shape[0], x2.shape[1]), device=x.device, dtype=torch.float32)
+    N.check(N.load().sm_layernorm_f32(x2.data_ptr(), x2.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                      y.stride(0), x2.shape[0], x2.shape[1], eps, _stream()), "sm_layernorm_f32")
+    return y.view(x.shape)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 0.125) -> torch.Tensor:
+    """q (B,Nq,H,64), k/v (B,Nk,H,64) views (last two dims contiguous) -> (B,Nq,H*64)."""
+    _dev(q, k, v)
+    B, nq, H, dh = q.shape
+    nk = k.shape[1]
+    assert dh == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
+    o = torch.empty((B, nq, H * dh), device=q.device, dtype=torch.float32)
+    a = N.AttnArgs()
+    a.Q, a.K, a.V, a.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    a.sQb, a.sQr, a.sKb, a.sKr, a.sVb, a.sVr = q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1)
+    a.sOb, a.sOr = o.stride(0), o.stride(1)
+    a.batch, a.heads, a.n_q, a.n_k, a.scale = B, H, nq, nk, scale
+    N.check(N.load().sm_attention_f32(a, _stream()), "sm_attention_f32")
+    return o
+
+
+def im2col_patches(img: torch.Tensor, patch: int) -> torch.Tensor:
+    _dev(img)
+    img = img.contiguous()
+    B, _, H, W = img.shape
+    gh, gw = -(-H // patch), -(-W // patch)
+    cols = torch.empty((B * gh * gw, 3 * patch * patch), device=img.device, dtype=torch.float32)
+    N.check(N.load().sm_im2col_patches_f32(img.data_ptr(), cols.data_ptr(), B, H, W, patch, _stream()), "sm_im2col")
+    return cols
+
+
+def pos_embed_bicubic(pos: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
+    _dev(pos)
+    pos = pos.reshape(-1, N.EMBED).contiguous()
+    g0 = int(round((pos.shape[0] - 1) ** 0.5))
+    out = torch.empty((1 + gh * gw, N.EMBED), device=pos.device, dtype=torch.float32)
+    N.check(N.load().sm_pos_embed_bicubic_f32(pos.data_ptr(), g0, out.data_ptr(), gh, gw, _stream()), "sm_pos_bicubic")
+    return out
+
+
+def upsample2x_tokens(tok: torch.Tensor, gh: int, gw: int) -> torch.Tensor:
+    """tok (B, gh*gw, 384) -> (B, 4*gh*gw, 384), channels-last bilinear x2."""
+    _dev(tok)
+    assert tok.stride(2) == 1 and tok.stride(1) == N.EMBED
+    B = tok.shape[0]
+    up = torch.empty((B, 4 * gh * gw, N.EMBED), device=tok.device, dtype=torch.float32)
+    N.check(N.load().sm_upsample2x_tokens_f32(tok.data_ptr(), tok.stride(0), up.data_ptr(), B, gh, gw, _stream()),
+            "sm_upsample2x")
+    return up
+
+
+def rowdot_sigmoid(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _dev(h, w, b)
+    h2 = h.reshape(-1, N.EMBED).contiguous()
+    out = torch.empty((h2.shape[0],), device=h.device, dtype=torch.float32)
+    N.check(N.load().sm_rowdot_sigmoid_f32(h2.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), h2.shape[0],
+                                           _stream()), "sm_rowdot_sigmoid")
+    return out

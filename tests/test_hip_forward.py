@@ -1,0 +1,121 @@
+"""Whole-forward parity of the HIP path (through the C ABI) against (a) the vectors the REAL reference produced
+(tests/golden, made by oracle/gen_golden.py) and (b) the CPU oracle run on this box in fp32 and fp64."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import selfmask_oracle as O  # noqa: E402  (checker only)
+from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images  # noqa: E402
+
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLD, "forward_*.npz")))
+
+# BASELINE.json north_star: "within 1e-4 max-abs on logits".  With unit decoder.norm gain the synthetic checkpoints
+# give |logit| up to 65 where the fp32 reference itself is 0.8-1.6e-4 from its own fp64 evaluation
+# (f32_vs_f64_maxabs in the fixtures), so the absolute gate is applied on the "calib" checkpoints (|logit| <= 16,
+# fp32 floor 2e-5) and scaled with the logit range elsewhere (1e-4 at |logit| = 16).
+ABS_TOL = 1e-4
+
+
+def _tol(scale):
+    return ABS_TOL * max(1.0, scale / 16.0)
+
+
+def _model(patch, wseed, style):
+    m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True,
+                   use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(wseed, style, patch_size=patch), strict=True)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("fp", CASES, ids=[os.path.basename(c)[8:-4] for c in CASES])
+def test_forward_matches_reference_vectors(fp):
+    g = np.load(fp)
+    patch, B, Hh, Ww, wseed, xseed, _ = [int(v) for v in g["meta"]]
+    m = _model(patch, wseed, str(g["style"]))
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww))).to(DEV)
+    out = m(x, return_logits=True)
+    scale = float(g["logit_absmax"])
+    tol = _tol(scale)
+    logits = out["mask_logits"][:, -1].cpu().numpy()
+    d32 = np.abs(logits - g["logits_last"]).max()
+    d64 = np.abs(logits - g["logits_last_f64"]).max()
+    ref64 = float(g["f32_vs_f64_maxabs"])
+    print(f"\n{os.path.basename(fp)}: |logit|max={scale:.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e} tol={tol:.1e}")
+    assert d32 <= tol
+    assert d64 <= max(2.0 * ref64, 0.5 * tol)  # as close to the fp64 truth as the fp32 reference is (x2 slack)
+    assert out["mask_pred"].shape == (B, 6, 20, 2 * int(g["grid"][0]), 2 * int(g["grid"][1]))
+    assert np.abs(out["objectness"].cpu().numpy() - g["objectness"]).max() <= 2e-5
+    assert np.abs(out["features"].cpu().numpy() - g["features"]).max() <= 5e-5
+    assert np.abs(out["queries"].cpu().numpy() - g["queries"]).max() <= 5e-5
+    # selection parity: arg-max objectness query and the IoU of its thresholded mask vs the reference's
+    obj_ref = g["objectness"][:, -1, :, 0]
+    obj = out["objectness"][:, -1, :, 0].cpu().numpy()
+    assert (obj.argmax(1) == obj_ref.argmax(1)).all()
+    mp = out["mask_pred"][:, -1].cpu().numpy()
+    ref_bin = (1 / (1 + np.exp(-g["logits_last"].astype(np.float64)))) > 0.5
+    flips = ((mp > 0.5) != ref_bin).mean()
+    assert flips <= 2e-5, flips
+    if "logits_all" in g:
+        assert np.abs(out["mask_logits"].cpu().numpy() - g["logits_all"]).max() <= tol
+        assert np.abs(out["patch_tokens"][0].cpu().numpy() - g["patch_tokens_b0"]).max() <= 5e-5
+
+
+def test_forward_vs_oracle_batch8_and_fp64_truth():
+    """Larger seeded batch through the oracle on this box's CPU (fp32 + fp64), strict 1e-4 on a calib checkpoint."""
+    patch, B = 16, 8
+    sd = synthetic_state_dict(11, "calib", patch_size=patch)
+    x = torch.from_numpy(synthetic_images(4321, (B, 3, 224, 224)))
+    m = _model(patch, 11, "calib")
+    out = m(x.to(DEV), return_logits=True)
+    o32 = O.forward(x, sd, patch)
+    o64 = O.forward(x.double(), O.cast_state(sd, torch.float64), patch)
+    lg = out["mask_logits"].cpu()
+    d32 = (lg - o32["mask_logits"]).abs().max().item()
+    d64 = (lg.double() - o64["mask_logits"]).abs().max().item()
+    r64 = (o32["mask_logits"].double() - o64["mask_logits"]).abs().max().item()
+    print(f"\nB=8 calib: |logit|max={o32['mask_logits'].abs().max():.1f} hip-oracle32={d32:.2e} hip-truth64={d64:.2e} "
+          f"oracle32-truth64={r64:.2e}")
+    assert d32 <= ABS_TOL
+    assert d64 <= max(2 * r64, 0.5 * ABS_TOL)
+    assert (out["mask_pred"].cpu() - o32["mask_pred"]).abs().max().item() <= 0.25 * ABS_TOL + 1e-6
+    assert (out["objectness"].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
+    assert (out["features"].cpu() - o32["features"]).abs().max().item() <= 5e-5
+
+
+def test_forward_is_deterministic_and_batch_invariant():
+    m = _model(16, 0, "soft")
+    x = torch.from_numpy(synthetic_images(99, (4, 3, 224, 224))).to(DEV)
+    a = m(x, return_logits=True)
+    b = m(x, return_logits=True)
+    assert torch.equal(a["mask_logits"], b["mask_logits"]) and torch.equal(a["objectness"], b["objectness"])
+    # image i alone gives the same bits as image i inside the batch (no cross-image reduction anywhere)
+    c = m(x[2:3], return_logits=True)
+    assert torch.equal(c["mask_logits"][0], a["mask_logits"][2])
+
+
+def test_encoder_only_and_3d_path():
+    m = _model(16, 0, "soft")
+    x = torch.from_numpy(synthetic_images(5, (2, 3, 224, 224))).to(DEV)
+    full = m(x, return_logits=True)
+    enc = m(x, encoder_only=True)
+    assert enc["patch_tokens"].shape == (2, 14, 14, 384)
+    assert torch.equal(enc["patch_tokens"].reshape(2, 196, 384), full["patch_tokens"])
+    m3 = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=False,
+                    use_binary_classifier=False)
+    sd = synthetic_state_dict(0, "soft", patch_size=16, use_binary_classifier=False)
+    m3.load_state_dict(sd, strict=True)
+    o3 = m3.to(DEV)(x)
+    assert set(o3.keys()) == {"mask_pred", "features"} and o3["mask_pred"].shape == (2, 20, 28, 28)
+
+
+def test_cpu_input_is_refused():
+    m = _model(16, 0, "soft")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 224, 224))

@@ -1,0 +1,148 @@
+"""Per-kernel parity: each C-ABI entry point against the stock torch-CPU op it replaces (fp64 as truth)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from selfmask_amd import _native as N  # noqa: E402
+from selfmask_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+def _maxerr(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64), None])
+@pytest.mark.parametrize("M,Nn,K", [(197 * 3, 1152, 384), (300, 384, 1536), (120, 784, 384), (33, 64, 32)])
+def test_gemm_bias_all_tiles(tile, M, Nn, K):
+    a, w, b = _rand(M, K, seed=1), _rand(Nn, K, seed=2, scale=0.05), _rand(Nn, seed=3)
+    c = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), tile=tile)
+    ref = a.double() @ w.double().T + b.double()
+    # exact-fp32 products, fp32 accumulation: error ~ sqrt(K) * eps * |row|.|col|
+    tol = 4e-7 * math.sqrt(K) * (a.abs().max() * w.abs().max() * math.sqrt(K)).item() + 1e-6
+    assert _maxerr(c, ref) <= tol
+    # and as close to fp64 as torch's own fp32 GEMM is (x3 slack)
+    assert _maxerr(c, ref) <= 3 * _maxerr(a @ w.T + b, ref) + 1e-6
+
+
+@pytest.mark.parametrize("epi", ["gelu", "relu", "residual", "sigmoid2"])
+def test_gemm_epilogues(epi):
+    M, Nn, K = 257, 192, 384
+    a, w, b, r = _rand(M, K, seed=4), _rand(Nn, K, seed=5, scale=0.05), _rand(Nn, seed=6), _rand(M, Nn, seed=7)
+    lin = a.double() @ w.double().T + b.double()
+    if epi == "gelu":
+        c = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=N.EPI_GELU)
+        ref = F.gelu(lin)
+    elif epi == "relu":
+        c = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=N.EPI_RELU)
+        ref = F.relu(lin)
+    elif epi == "residual":
+        rd = r.to(DEV)
+        c = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=N.EPI_RESIDUAL, residual=rd, out=rd)  # in place
+        ref = r.double() + lin
+    else:
+        c, c2 = ops.gemm(a.to(DEV), w.to(DEV), None, epilogue=N.EPI_SIGMOID2)
+        ref = a.double() @ w.double().T
+        assert _maxerr(c2, torch.sigmoid(ref)) <= 2e-6
+    assert _maxerr(c, ref) <= 2e-5
+
+
+def test_gemm_batched_and_a_add():
+    B, M, Nn, K = 3, 120, 784, 384
+    a, w = _rand(B, M, K, seed=8), _rand(B, Nn, K, seed=9, scale=0.1)
+    c = ops.gemm(a.to(DEV), w.to(DEV))
+    assert _maxerr(c, torch.einsum("bmk,bnk->bmn", a.double(), w.double())) <= 3e-5
+    # decoder "tgt + query_pos": A rows get A_add[m % 20]
+    t, qp, w2, b2 = _rand(60, K, seed=10), _rand(20, K, seed=11), _rand(768, K, seed=12, scale=0.05), _rand(768, seed=13)
+    c = ops.gemm(t.to(DEV), w2.to(DEV), b2.to(DEV), a_add=qp.to(DEV))
+    ref = (t + qp.repeat(3, 1)).double() @ w2.double().T + b2.double()
+    assert _maxerr(c, ref) <= 3e-5
+
+
+def test_gemm_rejects_bad_shapes():
+    a, w = _rand(8, 40).to(DEV), _rand(64, 40).to(DEV)
+    with pytest.raises(RuntimeError, match="multiple of 32"):
+        ops.gemm(a, w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(_rand(8, 32), _rand(64, 32))
+
+
+@pytest.mark.parametrize("rows,eps", [(1, 1e-6), (197 * 2, 1e-6), (1283, 1e-5)])
+def test_layernorm(rows, eps):
+    x, g, b = _rand(rows, 384, seed=20, scale=3.0) + 0.7, 1 + 0.1 * _rand(384, seed=21), 0.1 * _rand(384, seed=22)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), eps)
+    ref = F.layer_norm(x.double(), (384,), g.double(), b.double(), eps)
+    assert _maxerr(y, ref) <= 2e-6
+    assert _maxerr(y, ref) <= 3 * _maxerr(F.layer_norm(x, (384,), g, b, eps), ref) + 5e-7
+
+
+def _attn_ref(q, k, v, scale):
+    s = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * scale
+    p = s.softmax(-1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v.double()).reshape(q.shape[0], q.shape[1], -1)
+
+
+@pytest.mark.parametrize("B,nq,nk", [(2, 197, 197), (1, 785, 785), (1, 577, 577), (3, 20, 20), (3, 20, 196), (2, 20, 784),
+                                      (1, 1, 1), (1, 33, 225)])
+def test_attention_shapes(B, nq, nk):
+    qkv = _rand(B, max(nq, nk), 3, 6, 64, seed=30, scale=1.5).to(DEV)
+    q, k, v = qkv[:, :nq, 0], qkv[:, :nk, 1], qkv[:, :nk, 2]  # strided views like the packed qkv buffer
+    o = ops.attention(q, k, v, 0.125)
+    ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), 0.125)
+    assert _maxerr(o, ref) <= 5e-6
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running-max rescale between 224-key chunks: the global max sits in the LAST chunk (rule: a rare
+    data-dependent branch needs an input that takes it)."""
+    B, n = 1, 500
+    q, k, v = _rand(B, n, 6, 64, seed=31), _rand(B, n, 6, 64, seed=32), _rand(B, n, 6, 64, seed=33)
+    k[:, 470] = q[:, 5] * 4.0  # spike: key 470 (third chunk) dominates query 5
+    k[:, 3] = q[:, 100] * 3.0  # and a first-chunk spike for another row
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0.125)
+    assert _maxerr(o, _attn_ref(q, k, v, 0.125)) <= 5e-6
+
+
+@pytest.mark.parametrize("P,H,W", [(16, 224, 224), (8, 64, 72), (16, 250, 333), (8, 30, 21)])
+def test_im2col(P, H, W):
+    x = _rand(2, 3, H, W, seed=40)
+    cols = ops.im2col_patches(x.to(DEV), P)
+    xp = F.pad(x, (0, (P - W % P) % P, 0, (P - H % P) % P))
+    ref = F.unfold(xp, kernel_size=P, stride=P).transpose(1, 2).reshape(-1, 3 * P * P)
+    assert torch.equal(cols.cpu(), ref)
+
+
+@pytest.mark.parametrize("g0,gh,gw", [(14, 24, 24), (14, 16, 21), (28, 25, 21), (14, 7, 9)])
+def test_pos_embed_bicubic(g0, gh, gw):
+    pos = _rand(1 + g0 * g0, 384, seed=50, scale=0.05)
+    out = ops.pos_embed_bicubic(pos.to(DEV), gh, gw)
+    grid = F.interpolate(pos[1:].reshape(1, g0, g0, 384).permute(0, 3, 1, 2), size=(gh, gw), mode="bicubic",
+                         align_corners=False).permute(0, 2, 3, 1).reshape(-1, 384)
+    assert torch.equal(out[0].cpu(), pos[0])
+    assert _maxerr(out[1:], grid) <= 1e-6
+
+
+@pytest.mark.parametrize("gh,gw", [(14, 14), (16, 21), (1, 1), (3, 1)])
+def test_upsample2x(gh, gw):
+    tok = _rand(2, gh * gw, 384, seed=60)
+    up = ops.upsample2x_tokens(tok.to(DEV), gh, gw)
+    ref = F.interpolate(tok.permute(0, 2, 1).reshape(2, 384, gh, gw), scale_factor=2, mode="bilinear")
+    ref = ref.permute(0, 2, 3, 1).reshape(2, 4 * gh * gw, 384)
+    assert _maxerr(up, ref) <= 1e-6
+
+
+def test_rowdot_sigmoid():
+    h, w, b = _rand(241, 384, seed=70), _rand(384, seed=71, scale=0.1), _rand(1, seed=72)
+    out = ops.rowdot_sigmoid(h.to(DEV), w.to(DEV), b.to(DEV))
+    assert _maxerr(out, torch.sigmoid(h.double() @ w.double() + b.double())) <= 1e-6
