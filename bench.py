@@ -78,6 +78,7 @@ def cpu_baseline(P, S, budget_s=15.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("SM_CPU_BASELINE_THREADS", "16")))  # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     sd = synthetic_state_dict(0, "soft", patch_size=P)
     Bc = 16

@@ -100,7 +100,9 @@ def test_attention_shapes(B, nq, nk):
     q, k, v = qkv[:, :nq, 0], qkv[:, :nk, 1], qkv[:, :nk, 2]  # strided views like the packed qkv buffer
     o = ops.attention(q, k, v, 0.125)
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), 0.125)
-    assert _maxerr(o, ref) <= 5e-6
+    ref32 = F.scaled_dot_product_attention(q.cpu().transpose(1, 2), k.cpu().transpose(1, 2), v.cpu().transpose(1, 2),
+                                           scale=0.125).transpose(1, 2).reshape(B, nq, -1)
+    assert _maxerr(o, ref) <= max(1e-5, 3 * _maxerr(ref32, ref))
 
 
 def test_attention_online_softmax_rescale_branch():
