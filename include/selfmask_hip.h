@@ -55,13 +55,13 @@ typedef struct sm_gemm_args {
     float* C;            /* [batch][M][ldc]                                                                      */
     const float* R;      /* residual [batch][M][ldr] (SM_EPI_RESIDUAL; may alias C) or pos_embed (SM_EPI_PATCH)  */
     float* C2;           /* second output (SM_EPI_SIGMOID2) or NULL                                              */
-    const float* A_add;  /* optional: A[m][:] += A_add[m % a_add_rows][:]  (decoder "tgt + query_pos")           */
+    const float* A_add;  /* reserved, must be NULL (the "tgt + query_pos" add lives in sm_layernorm_rows_f32)     */
     int64_t strideA, strideW, strideC, strideR; /* batch strides in elements (0 = shared)                        */
     int32_t M, N, K;     /* any M, N >= 1; K % 32 == 0                                                           */
     int32_t lda, ldw, ldc, ldr;
     int32_t batch;       /* >= 1                                                                                 */
     int32_t epilogue;    /* SM_EPI_*                                                                             */
-    int32_t a_add_rows;  /* rows of A_add (0 = none); A_add row stride = lda2                                    */
+    int32_t a_add_rows;  /* reserved, must be 0                                                                  */
     int32_t lda2;
     int32_t patch_n;     /* SM_EPI_PATCH: patches per image n                                                    */
 } sm_gemm_args;
@@ -78,13 +78,26 @@ int sm_gemm_f32_tile(const sm_gemm_args* args, int bm, int bn, void* stream);
 int sm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,
                      int32_t rows, int32_t cols, float eps, void* stream);
 
-/* Same, with a grouped row remap on either side: logical row r reads x row (r/gi)*si + oi + r%gi and writes y row
- * (r/go)*so + oo + r%go (group size 0 = identity).  Used to drop the cls token while normalising
+/* General form.  Grouped row remap on either side: logical row r reads x row (r/gi)*si + oi + r%gi and writes y row
+ * (r/go)*so + oo + r%go (group size 0 = identity) - used to drop the cls token while normalising
  * (maskformer.py:107-108: [:, 1:, :]) and to scatter decoder layer l into the (B,L,nq,384) stack
- * (transformer_decoder.py:138-147 + maskformer.py:141). */
+ * (transformer_decoder.py:138-147 + maskformer.py:141).  Optional second output y2[r] = y[r] + add[r % add_rows]:
+ * the decoder's "tgt + query_pos" operand (transformer_decoder.py:271,283 with_pos_embed) produced by the LayerNorm
+ * that writes tgt, so the following projection GEMM reads it with plain LDS-DMA. */
 typedef struct sm_row_map { int32_t group, stride, offset; } sm_row_map;
-int sm_layernorm_rows_f32(const float* x, int64_t ldx, sm_row_map in_map, const float* gamma, const float* beta,
-                          float* y, int64_t ldy, sm_row_map out_map, int32_t rows, float eps, void* stream);
+typedef struct sm_ln_args {
+    const float* x;  int64_t ldx;  sm_row_map in_map;
+    const float *gamma, *beta;
+    float* y;        int64_t ldy;  sm_row_map out_map;
+    float* y2;       int64_t ldy2;          /* NULL = none; indexed by the logical row r */
+    const float* add; int32_t add_rows;      /* (add_rows,384), row stride 384 */
+    int32_t rows;
+    float eps;
+} sm_ln_args;
+int sm_layernorm_rows_f32(const sm_ln_args* args, void* stream);
+
+/* y[b*rows_per + i, :] = src[i, :] for b < B  (decoder init: tgt + query_pos with tgt = 0, maskformer.py:130-135) */
+int sm_broadcast_rows_f32(const float* src, float* dst, int32_t rows_per, int32_t B, void* stream);
 
 /* softmax(scale * Q K^T) V per (batch, head), head_dim 64: the q@k^T -> softmax -> @v core of
  * Attention.forward (vision_transformer.py:122-130) and of nn.MultiheadAttention (transformer_decoder.py:273,283).

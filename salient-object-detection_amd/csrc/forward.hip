@@ -21,7 +21,7 @@ static Shape make_shape(const sm_weights* w, int B, int H, int W) {
 
 // workspace carve-up (floats, every region 256-B aligned)
 struct Ws {
-    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *KV, *UP, *TGT, *T2, *QK, *Vd, *Qc, *AOd, *HIDd, *QD, *LOG, *O1, *O2;
+    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *KV, *UP, *TGT, *TGTQ, *T2, *QK, *Vd, *Qc, *AOd, *HIDd, *QD, *LOG, *O1, *O2;
     size_t total;
 };
 
@@ -46,6 +46,7 @@ static Ws carve(const Shape& s, float* base) {
     w.KV = take(s.Mp * 2 * D);
     w.UP = take(s.Mp * 4 * D);
     w.TGT = take(s.Md * D);
+    w.TGTQ = take(s.Md * D);
     w.T2 = take(s.Md * D);
     w.QK = take(s.Md * 2 * D);
     w.Vd = take(s.Md * D);
@@ -61,13 +62,22 @@ static Ws carve(const Shape& s, float* base) {
 }
 
 static int linear(const float* A, int lda, const float* W, const float* b, float* C, int ldc, int64_t M, int N, int K,
-                  int epi, const float* R, int ldr, hipStream_t st, const float* A_add = nullptr, int add_rows = 0) {
+                  int epi, const float* R, int ldr, hipStream_t st) {
     sm_gemm_args g = {};
     g.A = A; g.W = W; g.bias = b; g.C = C; g.R = R;
     g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldr = ldr;
     g.batch = 1; g.epilogue = epi;
-    g.A_add = A_add; g.a_add_rows = add_rows; g.lda2 = SM_EMBED;
     return sm_gemm_f32(&g, st);
+}
+
+static int ln(const float* x, const float* gw, const float* gb, float* y, int64_t rows, float eps, hipStream_t st,
+              sm_row_map in_map = {0, 0, 0}, sm_row_map out_map = {0, 0, 0}, float* y2 = nullptr,
+              const float* add = nullptr, int add_rows = 0) {
+    sm_ln_args a = {};
+    a.x = x; a.ldx = SM_EMBED; a.in_map = in_map; a.gamma = gw; a.beta = gb; a.y = y; a.ldy = SM_EMBED;
+    a.out_map = out_map; a.y2 = y2; a.ldy2 = SM_EMBED; a.add = add; a.add_rows = add_rows;
+    a.rows = (int)rows; a.eps = eps;
+    return sm_layernorm_rows_f32(&a, st);
 }
 
 #define TRY(x)                \
@@ -102,7 +112,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // ---- 12 pre-norm blocks (vision_transformer.py:164-170) -----------------------------------------------------
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
-        TRY(sm_layernorm_f32(ws.X, D, e.norm1_w, e.norm1_b, ws.Xn, D, (int)s.M, D, 1e-6f, st));
+        TRY(ln(ws.X, e.norm1_w, e.norm1_b, ws.Xn, s.M, 1e-6f, st));
         TRY(linear(ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, st));
         sm_attn_args a = {};
         a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
@@ -111,7 +121,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
         TRY(sm_attention_f32(&a, st));
         TRY(linear(ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D, st));
-        TRY(sm_layernorm_f32(ws.X, D, e.norm2_w, e.norm2_b, ws.Xn, D, (int)s.M, D, 1e-6f, st));
+        TRY(ln(ws.X, e.norm2_w, e.norm2_b, ws.Xn, s.M, 1e-6f, st));
         TRY(linear(ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, st));
         TRY(linear(ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D, st));
     }
@@ -120,7 +130,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     float* tok = io->patch_tokens ? io->patch_tokens : ws.TOK;
     {
         const sm_row_map drop_cls = {s.n, s.N, 1};
-        TRY(sm_layernorm_rows_f32(ws.X, D, drop_cls, w->enc_norm_w, w->enc_norm_b, tok, D, id, (int)s.Mp, 1e-6f, st));
+        TRY(ln(ws.X, w->enc_norm_w, w->enc_norm_b, tok, s.Mp, 1e-6f, st, drop_cls, id));
     }
     if (io->encoder_only) return SM_OK;
 
@@ -131,10 +141,11 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         return SM_ELAUNCH;
     }
     const float* qpos = w->query_embed;
+    TRY(sm_broadcast_rows_f32(qpos, ws.TGTQ, s.nq, s.B, st));  // tgt + query_pos with tgt = 0
     for (int l = 0; l < s.L; ++l) {
         const sm_dec_layer& d = w->dec[l];
         // self-attention: q = k = tgt + query_pos, v = tgt
-        TRY(linear(ws.TGT, D, d.sa_in_w, d.sa_in_b, ws.QK, 2 * D, s.Md, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st, qpos, s.nq));
+        TRY(linear(ws.TGTQ, D, d.sa_in_w, d.sa_in_b, ws.QK, 2 * D, s.Md, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st));
         TRY(linear(ws.TGT, D, d.sa_in_w + 2 * D * D, d.sa_in_b + 2 * D, ws.Vd, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st));
         sm_attn_args a = {};
         a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.Vd; a.O = ws.AOd;
@@ -143,9 +154,9 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
         TRY(sm_attention_f32(&a, st));
         TRY(linear(ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
-        TRY(sm_layernorm_f32(ws.T2, D, d.norm1_w, d.norm1_b, ws.TGT, D, (int)s.Md, D, 1e-5f, st));
+        TRY(ln(ws.T2, d.norm1_w, d.norm1_b, ws.TGT, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq));
         // cross-attention: q = tgt + query_pos, k = v = memory (pos = None)
-        TRY(linear(ws.TGT, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st, qpos, s.nq));
+        TRY(linear(ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st));
         TRY(linear(tok, D, d.ca_in_w + D * D, d.ca_in_b + D, ws.KV, 2 * D, s.Mp, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st));
         a = {};
         a.Q = ws.Qc; a.K = ws.KV; a.V = ws.KV + D; a.O = ws.AOd;
@@ -154,14 +165,14 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
         TRY(sm_attention_f32(&a, st));
         TRY(linear(ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
-        TRY(sm_layernorm_f32(ws.T2, D, d.norm2_w, d.norm2_b, ws.TGT, D, (int)s.Md, D, 1e-5f, st));
+        TRY(ln(ws.T2, d.norm2_w, d.norm2_b, ws.TGT, s.Md, 1e-5f, st));
         // FFN
         TRY(linear(ws.TGT, D, d.lin1_w, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, st));
         TRY(linear(ws.HIDd, SM_MLP, d.lin2_w, d.lin2_b, ws.T2, D, s.Md, D, SM_MLP, SM_EPI_RESIDUAL, ws.TGT, D, st));
-        TRY(sm_layernorm_f32(ws.T2, D, d.norm3_w, d.norm3_b, ws.TGT, D, (int)s.Md, D, 1e-5f, st));
+        TRY(ln(ws.T2, d.norm3_w, d.norm3_b, ws.TGT, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq));
         // shared final norm on every layer's output, scattered into (B, L, nq, 384)
         const sm_row_map stack = {s.nq, s.L * s.nq, l * s.nq};
-        TRY(sm_layernorm_rows_f32(ws.TGT, D, id, w->dec_norm_w, w->dec_norm_b, QD, D, stack, (int)s.Md, 1e-5f, st));
+        TRY(ln(ws.TGT, w->dec_norm_w, w->dec_norm_b, QD, s.Md, 1e-5f, st, id, stack));
     }
 
     // ---- heads --------------------------------------------------------------------------------------------------

@@ -4,91 +4,121 @@
 // chain (exact fp32, 64 FLOP/clk/SIMD), which is what the 1e-4 logit-parity gate needs (bf16 operands miss it
 // by four orders of magnitude).
 //
-// Tiling (wave64): a 256-thread workgroup = 4 waves as 2x2; each wave owns (BM/2)x(BN/2) outputs as TMxTN
-// 32x32 MFMA blocks.  A and W tiles (BK = 32 deep) go global -> registers -> LDS (double buffered, one barrier
-// per K-tile) with rows padded to 36 floats so the ds_read_b128 fragment reads are bank-conflict free.
-// k-permutation: within each 8-wide k group lane-half h owns k = 4h..4h+3, so one ds_read_b128 per operand
-// feeds 4 consecutive MFMA steps (A and W use the same permutation, so the products summed are unchanged).
+// Structure (wave64, 256 threads = 4 waves as 2x2, each wave (BM/2)x(BN/2) outputs as TMxTN 32x32 MFMA blocks):
+//   * A and W K-tiles (BK = 32 floats = one 128-B line per row) stream HBM/L2 -> LDS with LDS-DMA
+//     (global_load_lds_dwordx4: no staging VGPRs, no ds_write), NST buffers deep, retired with a COUNTED
+//     s_waitcnt vmcnt(N) + one raw s_barrier per K-tile (never vmcnt(0) in the loop when NST > 2);
+//   * the LDS image is linear (an LDS-DMA wave-instruction writes 64 lanes x 16 B contiguously), so bank
+//     conflicts are removed by XOR-swizzling the 16-B chunk index with (row>>1)&7 on the per-lane SOURCE
+//     address and again on the ds_read_b128 fragment reads (conflict-free for all four 16-lane groups);
+//   * k-permutation: within each 8-wide k group lane-half h owns k = 4h..4h+3, so one ds_read_b128 per operand
+//     feeds 4 consecutive MFMA steps (A and W use the same permutation: the set of products is unchanged);
+//   * two-level summation: the MFMA chain runs over 128 k, then is folded into a second accumulator with VALU
+//     adds (a single 1536-long chain measured 5x torch-CPU's error against fp64).
 #include "common.h"
+#include <type_traits>
 
 namespace sm {
 
 constexpr int BK = 32;
-constexpr int LDS_LD = 36;
 
-template <int BM, int BN, bool ADD>
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [lds_off, lds_off + 1 KiB).
+// Issued from inline asm on purpose: hipcc does not count asm VMEM ops, so it cannot insert its conservative
+// `s_waitcnt vmcnt(0)` in front of the next ds_read (it did with the builtin, serialising DMA and MFMA); the
+// retire points are the explicit counted waits below.  M0 (the LDS base) is compiler-reserved: save/restore it.
+__device__ __forceinline__ void dma16(const float* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_off)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_out(const sm_gemm_args& g, float* C, int64_t bz, int m, int n, float val) {
+    if constexpr (EPI == SM_EPI_GELU) {
+        val = 0.5f * val * (1.0f + erff(val * 0.70710678118654752440f));
+    } else if constexpr (EPI == SM_EPI_RELU) {
+        val = fmaxf(val, 0.f);
+    } else if constexpr (EPI == SM_EPI_RESIDUAL) {
+        val = (g.R + bz * g.strideR)[(int64_t)m * g.ldr + n] + val;
+    } else if constexpr (EPI == SM_EPI_SIGMOID2) {
+        (g.C2 + bz * g.strideC)[(int64_t)m * g.ldc + n] = 1.0f / (1.0f + expf(-val));
+    } else if constexpr (EPI == SM_EPI_PATCH) {
+        const int img = m / g.patch_n, p = m - img * g.patch_n;
+        val += g.R[(int64_t)(1 + p) * g.ldr + n];
+        C[((int64_t)img * (g.patch_n + 1) + 1 + p) * g.ldc + n] = val;
+        return;
+    }
+    C[(int64_t)m * g.ldc + n] = val;
+}
+
+template <int BM, int BN, int NST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int A_CH = BM * 8 / 256, W_CH = BN * 8 / 256;
+    constexpr int A_INST = BM / 32, W_INST = BN / 32;  // LDS-DMA wave-instructions per wave per K-tile (8 rows each)
+    constexpr int NI = A_INST + W_INST;
+    constexpr int STAGE = (BM + BN) * BK;              // floats per pipeline stage
+    constexpr int FLUSH_KT = 4;                        // fold the MFMA chain every 4 K-tiles (128 k)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;
-    float* Ws = smem + 2 * BM * LDS_LD;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int64_t bz = blockIdx.z;
-
     const float* __restrict__ A = g.A + bz * g.strideA;
     const float* __restrict__ W = g.W + bz * g.strideW;
-    const int M = g.M, K = g.K;
+    const int M = g.M, N = g.N;
+    const int nk = g.K / BK;
 
-    // per-thread staging coordinates (fixed over the K loop)
-    const float* a_src[A_CH];
-    const float* a2_src[A_CH];
-    const float* w_src[W_CH];
-    int a_dst[A_CH], w_dst[W_CH];
+    // ---- LDS-DMA source pointers: lane L of instruction I fills LDS row (8*(wave*INST+I) + L/8), chunk L%8 --------
+    const float* a_src[A_INST];
+    const float* w_src[W_INST];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 4;
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = (wave * A_INST + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        a_src[i] = A + (int64_t)gm * g.lda + kc;
-        a2_src[i] = ADD ? g.A_add + (int64_t)(gm % g.a_add_rows) * g.lda2 + kc : nullptr;
-        a_dst[i] = row * LDS_LD + kc;
+        a_src[i] = A + (int64_t)gm * g.lda + c * 4;
     }
 #pragma unroll
-    for (int i = 0; i < W_CH; ++i) {
-        const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 4;
+    for (int i = 0; i < W_INST; ++i) {
+        const int row = (wave * W_INST + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row;
-        gn = gn < g.N ? gn : g.N - 1;
-        w_src[i] = W + (int64_t)gn * g.ldw + kc;
-        w_dst[i] = row * LDS_LD + kc;
+        gn = gn < N ? gn : N - 1;
+        w_src[i] = W + (int64_t)gn * g.ldw + c * 4;
     }
+    const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem;  // LDS byte address of the dynamic region
+    auto issue = [&](int kt, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + (stage * STAGE + wave * A_INST * 8 * BK) * 4);
+        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + (stage * STAGE + BM * BK + wave * W_INST * 8 * BK) * 4);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) dma16(a_src[i] + kt * BK, sa + i * 8 * BK * 4);
+#pragma unroll
+        for (int i = 0; i < W_INST; ++i) dma16(w_src[i] + kt * BK, sw + i * 8 * BK * 4);
+    };
 
-    // Staging registers.  No branch surrounds the loads/stores (a conditional made hipcc keep these arrays in
-    // scratch): the last iteration re-loads the final K-tile and stores it to the idle buffer, which nobody reads.
-    float4 ra[A_CH], rb[A_CH], rw[W_CH];
-#define SM_LOAD_TILES(k0)                                                                           \
-    {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                            \
-            ra[i] = *reinterpret_cast<const float4*>(a_src[i] + (k0));                              \
-        _Pragma("unroll") for (int i = 0; i < W_CH; ++i)                                            \
-            rw[i] = *reinterpret_cast<const float4*>(w_src[i] + (k0));                              \
-        if constexpr (ADD) {                                                                        \
-            _Pragma("unroll") for (int i = 0; i < A_CH; ++i)                                        \
-                rb[i] = *reinterpret_cast<const float4*>(a2_src[i] + (k0));                         \
-        }                                                                                           \
-    }
-#define SM_STORE_TILES(buf)                                                                         \
-    {                                                                                               \
-        float* as_ = As + (buf) * BM * LDS_LD;                                                      \
-        float* ws_ = Ws + (buf) * BN * LDS_LD;                                                      \
-        _Pragma("unroll") for (int i = 0; i < A_CH; ++i) {                                          \
-            float4 t_ = ra[i];                                                                      \
-            if constexpr (ADD) { t_.x += rb[i].x; t_.y += rb[i].y; t_.z += rb[i].z; t_.w += rb[i].w; } \
-            *reinterpret_cast<float4*>(as_ + a_dst[i]) = t_;                                        \
-        }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < W_CH; ++i)                                            \
-            *reinterpret_cast<float4*>(ws_ + w_dst[i]) = rw[i];                                     \
-    }
+    // ---- fragment read offsets (floats): row r of a 32-row block, chunk (2kb+h) ^ ((r>>1)&7) -----------------------
+    const int swz = (r >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) koff[kb] = ((2 * kb + h) ^ swz) * 4;
+    const int a_row = (wm * (BM / 2) + r) * BK;
+    const int w_row = BM * BK + (wn * (BN / 2) + r) * BK;
 
-    // Two-level summation: the MFMA chain (a k-ordered fmaf chain) runs over FLUSH_KT K-tiles (128 k), then is
-    // folded into `tot` with VALU adds.  A single 1536-long chain (fc2) measured 5x the error of torch-CPU's
-    // blocked sgemm against fp64; with 128-long chains the kernel is at or below the CPU's error.  Cost: 16 v_add
-    // per 32x32 block per 128 k (~1.5 % of the MFMA time).
-    constexpr int FLUSH_KT = 4;
     f32x16 acc[TM][TN], tot[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -97,26 +127,28 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) { acc[i][j][v] = 0.f; tot[i][j][v] = 0.f; }
 
-    const int nk = K / BK;
-    SM_LOAD_TILES(0);
-    SM_STORE_TILES(0);
-    __syncthreads();
-
-    const int a_frag = (wm * (BM / 2) + r) * LDS_LD + 4 * h;
-    const int w_frag = (wn * (BN / 2) + r) * LDS_LD + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        SM_LOAD_TILES((kt + 1 < nk ? kt + 1 : kt) * BK);
-        const float* as = As + buf * BM * LDS_LD + a_frag;
-        const float* ws = Ws + buf * BN * LDS_LD + w_frag;
+        // tile kt has landed once this wave's DMAs for it are retired (all but the NST-2 younger tiles) and every
+        // wave has passed the barrier; the barrier also proves every wave is done reading tile kt-1, whose buffer
+        // the next issue overwrites.  Tail iterations re-issue the last tile so the counts stay uniform.
+        wait_vmcnt<(NST - 2) * NI>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int nt = kt + NST - 1;
+            issue(nt < nk ? nt : nk - 1, nt % NST);
+        }
+        const float* st = smem + (kt % NST) * STAGE;
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             float4 af[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(as + i * 32 * LDS_LD + kb * 8);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(st + a_row + i * 32 * BK + koff[kb]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const float4*>(ws + j * 32 * LDS_LD + kb * 8);
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const float4*>(st + w_row + j * 32 * BK + koff[kb]);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -130,7 +162,6 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
                 }
             }
         }
-        SM_STORE_TILES(buf ^ 1);
         if ((kt & (FLUSH_KT - 1)) == FLUSH_KT - 1) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -139,8 +170,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
 #pragma unroll
                     for (int v = 0; v < 16; ++v) { tot[i][j][v] += acc[i][j][v]; acc[i][j][v] = 0.f; }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of this tile has returned
     }
+    wait_vmcnt<0>();  // drain the (redundant) tail DMAs before the LDS is released
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -148,49 +180,47 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) tot[i][j][v] += acc[i][j][v];
 
-    // ---- epilogue -------------------------------------------------------------------------------------------
+    // ---- epilogue (one specialised loop per epilogue kind; the kind is kernel-uniform) ---------------------------
     float* C = g.C + bz * g.strideC;  // may alias R (in-place residual)
-    const int epi = g.epilogue;
+    auto run = [&](auto epi_tag) {
+        constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + r;
-        if (n >= g.N) continue;
-        const float bv = g.bias ? g.bias[n] : 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + r;
+            if (n >= N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + acc_row(v, h);
-                if (m >= M) continue;
-                float val = tot[i][j][v] + bv;
-                if (epi == SM_EPI_GELU) {
-                    val = 0.5f * val * (1.0f + erff(val * 0.70710678118654752440f));
-                } else if (epi == SM_EPI_RELU) {
-                    val = fmaxf(val, 0.f);
-                } else if (epi == SM_EPI_RESIDUAL) {
-                    val = (g.R + bz * g.strideR)[(int64_t)m * g.ldr + n] + val;
-                } else if (epi == SM_EPI_SIGMOID2) {
-                    (g.C2 + bz * g.strideC)[(int64_t)m * g.ldc + n] = 1.0f / (1.0f + expf(-val));
-                } else if (epi == SM_EPI_PATCH) {
-                    const int img = m / g.patch_n, p = m - img * g.patch_n;
-                    val += g.R[(int64_t)(1 + p) * g.ldr + n];
-                    C[((int64_t)img * (g.patch_n + 1) + 1 + p) * g.ldc + n] = val;
-                    continue;
+                for (int v = 0; v < 16; ++v) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + acc_row(v, h);
+                    if (m < M) store_out<EPI>(g, C, bz, m, n, tot[i][j][v] + bv);
                 }
-                C[(int64_t)m * g.ldc + n] = val;
             }
         }
+    };
+    switch (g.epilogue) {
+        case SM_EPI_GELU: run(std::integral_constant<int, SM_EPI_GELU>{}); break;
+        case SM_EPI_RELU: run(std::integral_constant<int, SM_EPI_RELU>{}); break;
+        case SM_EPI_RESIDUAL: run(std::integral_constant<int, SM_EPI_RESIDUAL>{}); break;
+        case SM_EPI_SIGMOID2: run(std::integral_constant<int, SM_EPI_SIGMOID2>{}); break;
+        case SM_EPI_PATCH: run(std::integral_constant<int, SM_EPI_PATCH>{}); break;
+        default: run(std::integral_constant<int, SM_EPI_BIAS>{}); break;
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 static int launch_gemm(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch);
-    const size_t lds = 2 * (BM + BN) * LDS_LD * sizeof(float);
-    if (g.a_add_rows > 0)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true>), grid, dim3(256), lds, st, g);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false>), grid, dim3(256), lds, st, g);
+    constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, NST>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, NST>), grid, dim3(256), lds, st, g);
     return check_launch("sm_gemm_f32");
 }
 
@@ -202,14 +232,13 @@ static int validate(const sm_gemm_args* g) {
     SM_REQUIRE(g->lda >= g->K && g->ldw >= g->K && g->ldc >= g->N, "sm_gemm_f32: leading dimension too small");
     SM_REQUIRE(g->lda % 4 == 0 && g->ldw % 4 == 0, "sm_gemm_f32: lda/ldw must be multiples of 4 (16-B loads)");
     SM_REQUIRE(((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->W % 16 == 0), "sm_gemm_f32: A/W must be 16-B aligned");
+    SM_REQUIRE(g->strideA % 4 == 0 && g->strideW % 4 == 0, "sm_gemm_f32: batch strides must be multiples of 4");
     SM_REQUIRE(g->epilogue >= 0 && g->epilogue <= SM_EPI_PATCH, "sm_gemm_f32: bad epilogue %d", g->epilogue);
     if (g->epilogue == SM_EPI_RESIDUAL) SM_REQUIRE(g->R && g->ldr >= g->N, "sm_gemm_f32: residual needs R/ldr");
     if (g->epilogue == SM_EPI_SIGMOID2) SM_REQUIRE(g->C2, "sm_gemm_f32: SIGMOID2 needs C2");
     if (g->epilogue == SM_EPI_PATCH)
         SM_REQUIRE(g->R && g->patch_n > 0 && g->ldr >= g->N && g->batch == 1, "sm_gemm_f32: PATCH needs R/patch_n");
-    if (g->a_add_rows > 0)
-        SM_REQUIRE(g->A_add && g->lda2 >= g->K && g->lda2 % 4 == 0 && ((uintptr_t)g->A_add % 16 == 0),
-                   "sm_gemm_f32: bad A_add");
+    SM_REQUIRE(g->a_add_rows == 0, "sm_gemm_f32: A_add is not supported (fold it into the producing LayerNorm)");
     return SM_OK;
 }
 
@@ -219,10 +248,11 @@ extern "C" int sm_gemm_f32_tile(const sm_gemm_args* g, int bm, int bn, void* str
     int rc = sm::validate(g);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (bm == 128 && bn == 128) return sm::launch_gemm<128, 128>(*g, st);
-    if (bm == 128 && bn == 64) return sm::launch_gemm<128, 64>(*g, st);
-    if (bm == 64 && bn == 64) return sm::launch_gemm<64, 64>(*g, st);
-    sm::set_error("sm_gemm_f32_tile: unsupported tile %dx%d for N=%d", bm, bn, g->N);
+    // pipeline depth per tile: every configuration keeps <= 72 KiB of LDS so two workgroups share a CU
+    if (bm == 128 && bn == 128) return sm::launch_gemm<128, 128, 2>(*g, st);
+    if (bm == 128 && bn == 64) return sm::launch_gemm<128, 64, 3>(*g, st);
+    if (bm == 64 && bn == 64) return sm::launch_gemm<64, 64, 4>(*g, st);
+    sm::set_error("sm_gemm_f32_tile: unsupported tile %dx%d", bm, bn);
     return SM_EINVAL;
 }
 

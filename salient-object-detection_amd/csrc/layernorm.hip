@@ -10,14 +10,11 @@ __device__ __forceinline__ int64_t map_row(int r, sm_row_map m) {
     return m.group > 0 ? (int64_t)(r / m.group) * m.stride + m.offset + r % m.group : r;
 }
 
-__global__ __launch_bounds__(256) void layernorm384_kernel(const float* __restrict__ x, int64_t ldx, sm_row_map in_map,
-                                                           const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* y, int64_t ldy,
-                                                           sm_row_map out_map, int rows, float eps) {
+__global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;  // whole wave exits together
-    const float* xr = x + map_row(row, in_map) * ldx;
+    if (row >= a.rows) return;  // whole wave exits together
+    const float* xr = a.x + map_row(row, a.in_map) * a.ldx;
     float2 v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2);
@@ -30,37 +27,61 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(const float* __restri
         v[i].y -= mean;
         q += v[i].x * v[i].x + v[i].y * v[i].y;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 384.0f) + eps);
-    float* yr = y + map_row(row, out_map) * ldy;
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 384.0f) + a.eps);
+    float* yr = a.y + map_row(row, a.out_map) * a.ldy;
+    float* y2r = a.y2 ? a.y2 + (int64_t)row * a.ldy2 : nullptr;
+    const float* ar = a.y2 ? a.add + (int64_t)(row % a.add_rows) * SM_EMBED : nullptr;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float2 gm = *reinterpret_cast<const float2*>(gamma + i * 128 + lane * 2);
-        const float2 bt = *reinterpret_cast<const float2*>(beta + i * 128 + lane * 2);
+        const float2 gm = *reinterpret_cast<const float2*>(a.gamma + i * 128 + lane * 2);
+        const float2 bt = *reinterpret_cast<const float2*>(a.beta + i * 128 + lane * 2);
         float2 o;
         o.x = v[i].x * rstd * gm.x + bt.x;
         o.y = v[i].y * rstd * gm.y + bt.y;
         *reinterpret_cast<float2*>(yr + i * 128 + lane * 2) = o;
+        if (y2r) {
+            const float2 ad = *reinterpret_cast<const float2*>(ar + i * 128 + lane * 2);
+            o.x += ad.x;
+            o.y += ad.y;
+            *reinterpret_cast<float2*>(y2r + i * 128 + lane * 2) = o;
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int rows_per, int64_t total4) {
+    const int64_t per4 = (int64_t)rows_per * (SM_EMBED / 4);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256)
+        reinterpret_cast<float4*>(dst)[t] = reinterpret_cast<const float4*>(src)[t % per4];
 }
 
 }  // namespace sm
 
-extern "C" int sm_layernorm_rows_f32(const float* x, int64_t ldx, sm_row_map in_map, const float* gamma,
-                                     const float* beta, float* y, int64_t ldy, sm_row_map out_map, int32_t rows,
-                                     float eps, void* stream) {
-    SM_REQUIRE(x && gamma && beta && y, "sm_layernorm_f32: null pointer");
-    SM_REQUIRE(rows >= 0 && ldx >= SM_EMBED && ldy >= SM_EMBED && ldx % 2 == 0 && ldy % 2 == 0,
+extern "C" int sm_layernorm_rows_f32(const sm_ln_args* a, void* stream) {
+    SM_REQUIRE(a && a->x && a->gamma && a->beta && a->y, "sm_layernorm_f32: null pointer");
+    SM_REQUIRE(a->rows >= 0 && a->ldx >= SM_EMBED && a->ldy >= SM_EMBED && a->ldx % 2 == 0 && a->ldy % 2 == 0,
                "sm_layernorm_f32: bad rows/strides");
-    SM_REQUIRE(in_map.group >= 0 && out_map.group >= 0, "sm_layernorm_f32: bad row map");
-    if (rows == 0) return SM_OK;
-    hipLaunchKernelGGL(sm::layernorm384_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, in_map,
-                       gamma, beta, y, ldy, out_map, rows, eps);
+    SM_REQUIRE(a->in_map.group >= 0 && a->out_map.group >= 0, "sm_layernorm_f32: bad row map");
+    if (a->y2) SM_REQUIRE(a->add && a->add_rows > 0 && a->ldy2 >= SM_EMBED && a->ldy2 % 2 == 0, "sm_layernorm_f32: bad y2/add");
+    if (a->rows == 0) return SM_OK;
+    hipLaunchKernelGGL(sm::layernorm384_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
     return sm::check_launch("sm_layernorm_f32");
 }
 
 extern "C" int sm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y,
                                 int64_t ldy, int32_t rows, int32_t cols, float eps, void* stream) {
     SM_REQUIRE(cols == SM_EMBED, "sm_layernorm_f32: cols=%d, only 384 is supported", cols);
-    const sm_row_map id = {0, 0, 0};
-    return sm_layernorm_rows_f32(x, ldx, id, gamma, beta, y, ldy, id, rows, eps, stream);
+    sm_ln_args a = {};
+    a.x = x; a.ldx = ldx; a.gamma = gamma; a.beta = beta; a.y = y; a.ldy = ldy; a.rows = rows; a.eps = eps;
+    return sm_layernorm_rows_f32(&a, stream);
+}
+
+extern "C" int sm_broadcast_rows_f32(const float* src, float* dst, int32_t rows_per, int32_t B, void* stream) {
+    SM_REQUIRE(src && dst && rows_per > 0 && B > 0, "sm_broadcast_rows_f32: bad arguments");
+    const int64_t total4 = (int64_t)B * rows_per * (SM_EMBED / 4);
+    int64_t grid = (total4 + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sm::broadcast_rows_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, dst, rows_per,
+                       total4);
+    return sm::check_launch("sm_broadcast_rows_f32");
 }

@@ -27,6 +27,12 @@ class RowMap(C.Structure):
     _fields_ = [("group", C.c_int32), ("stride", C.c_int32), ("offset", C.c_int32)]
 
 
+class LnArgs(C.Structure):
+    _fields_ = [("x", fp), ("ldx", C.c_int64), ("in_map", RowMap), ("gamma", fp), ("beta", fp),
+                ("y", fp), ("ldy", C.c_int64), ("out_map", RowMap), ("y2", fp), ("ldy2", C.c_int64),
+                ("add", fp), ("add_rows", C.c_int32), ("rows", C.c_int32), ("eps", C.c_float)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("Q", fp), ("K", fp), ("V", fp), ("O", fp),
                 ("sQb", C.c_int64), ("sQr", C.c_int64), ("sKb", C.c_int64), ("sKr", C.c_int64),
@@ -72,8 +78,8 @@ SYMBOLS = {
     "sm_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), fp]),
     "sm_gemm_f32_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, fp]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),
-    "sm_layernorm_rows_f32": (C.c_int, [fp, C.c_int64, RowMap, fp, fp, fp, C.c_int64, RowMap, C.c_int32, C.c_float,
-                                        fp]),
+    "sm_layernorm_rows_f32": (C.c_int, [C.POINTER(LnArgs), fp]),
+    "sm_broadcast_rows_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_attention_f32": (C.c_int, [C.POINTER(AttnArgs), fp]),
     "sm_im2col_patches_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_cls_rows_f32": (C.c_int, [fp, fp, fp, C.c_int32, C.c_int32, fp]),

@@ -25,11 +25,11 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = N.EPI_BIAS,
-         residual: Optional[torch.Tensor] = None, a_add: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None,
          tile: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None,
          out2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C = epilogue(A W^T + bias).  a: (M,K) or (batch,M,K); w: (N,K) or (batch,N,K) (torch Linear layout)."""
-    _dev(a, w, bias, residual, a_add)
+    _dev(a, w, bias, residual)
     lib = N.load()
     a3 = a if a.dim() == 3 else a.unsqueeze(0)
     w3 = w if w.dim() == 3 else w.unsqueeze(0)
@@ -51,8 +51,6 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
         g.R, g.ldr = r3.data_ptr(), r3.stride(1)
         g.strideR = r3.stride(0) if r3.shape[0] > 1 else 0
-    if a_add is not None:
-        g.A_add, g.a_add_rows, g.lda2 = a_add.data_ptr(), a_add.shape[0], a_add.stride(0)
     if epilogue == N.EPI_SIGMOID2:
         c2 = out2 if out2 is not None else torch.empty_like(c)
         g.C2 = c2.data_ptr()
@@ -66,14 +64,28 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return res
 
 
-def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
-    _dev(x, gamma, beta)
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+              add: Optional[torch.Tensor] = None, in_map=(0, 0, 0), out_map=(0, 0, 0), rows: Optional[int] = None,
+              out_rows: Optional[int] = None):
+    """y = LayerNorm(x) (+ optional y2 = y + add[r % len(add)]); optional grouped row remaps (see the header)."""
+    _dev(x, gamma, beta, add)
     x2 = x.reshape(-1, x.shape[-1])
-    assert x2.stride(1) == 1
-    y = torch.empty((x2.shape[0], x2.shape[1]), device=x.device, dtype=torch.float32)
-    N.check(N.load().sm_layernorm_f32(x2.data_ptr(), x2.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                      y.stride(0), x2.shape[0], x2.shape[1], eps, _stream()), "sm_layernorm_f32")
-    return y.view(x.shape)
+    assert x2.stride(1) == 1 and x2.shape[1] == N.EMBED
+    rows = x2.shape[0] if rows is None else rows
+    y = torch.empty((rows if out_rows is None else out_rows, N.EMBED), device=x.device, dtype=torch.float32)
+    a = N.LnArgs()
+    a.x, a.ldx, a.gamma, a.beta, a.y, a.ldy = x2.data_ptr(), x2.stride(0), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), N.EMBED
+    a.in_map, a.out_map = N.RowMap(*in_map), N.RowMap(*out_map)
+    a.rows, a.eps = rows, eps
+    y2 = None
+    if add is not None:
+        add = add.contiguous()
+        y2 = torch.empty((rows, N.EMBED), device=x.device, dtype=torch.float32)
+        a.y2, a.ldy2, a.add, a.add_rows = y2.data_ptr(), N.EMBED, add.data_ptr(), add.shape[0]
+    N.check(N.load().sm_layernorm_rows_f32(a, _stream()), "sm_layernorm_rows_f32")
+    if in_map == (0, 0, 0) and out_map == (0, 0, 0):
+        y = y.view(x.shape)
+    return (y, y2) if add is not None else y
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 0.125) -> torch.Tensor:

@@ -37,6 +37,7 @@ def test_argument_validation_without_gpu():
     g = N.GemmArgs()
     assert lib.sm_gemm_f32(g, None) == -1 and b"null pointer" in lib.sm_last_error()
     assert lib.sm_layernorm_f32(None, 384, None, None, None, 384, 4, 384, 1e-6, None) == -1
+    assert lib.sm_layernorm_rows_f32(N.LnArgs(), None) == -1
     w = N.Weights()
     w.patch = 7
     assert lib.sm_forward_workspace_bytes(w, 1, 224, 224) == 0

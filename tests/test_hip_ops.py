@@ -58,16 +58,24 @@ def test_gemm_epilogues(epi):
     assert _maxerr(c, ref) <= 2e-5
 
 
-def test_gemm_batched_and_a_add():
+def test_gemm_batched():
     B, M, Nn, K = 3, 120, 784, 384
     a, w = _rand(B, M, K, seed=8), _rand(B, Nn, K, seed=9, scale=0.1)
     c = ops.gemm(a.to(DEV), w.to(DEV))
     assert _maxerr(c, torch.einsum("bmk,bnk->bmn", a.double(), w.double())) <= 3e-5
-    # decoder "tgt + query_pos": A rows get A_add[m % 20]
-    t, qp, w2, b2 = _rand(60, K, seed=10), _rand(20, K, seed=11), _rand(768, K, seed=12, scale=0.05), _rand(768, seed=13)
-    c = ops.gemm(t.to(DEV), w2.to(DEV), b2.to(DEV), a_add=qp.to(DEV))
-    ref = (t + qp.repeat(3, 1)).double() @ w2.double().T + b2.double()
-    assert _maxerr(c, ref) <= 3e-5
+
+
+@pytest.mark.parametrize("tile", [(128, 128), (128, 64), (64, 64)])
+def test_gemm_pipeline_race_screen(tile):
+    """The LDS-DMA ring (counted vmcnt + one barrier per K-tile) must give the same bits on every launch and agree
+    with fp64 for short (K=32: fewer tiles than stages) and long K."""
+    for K in (32, 64, 96, 1536):
+        a, w = _rand(391, K, seed=80 + K), _rand(320, K, seed=81 + K, scale=0.1)
+        ad, wd = a.to(DEV), w.to(DEV)
+        first = ops.gemm(ad, wd, tile=tile)
+        assert _maxerr(first, a.double() @ w.double().T) <= 2e-5
+        for _ in range(20):
+            assert torch.equal(ops.gemm(ad, wd, tile=tile), first)
 
 
 def test_gemm_rejects_bad_shapes():
@@ -85,6 +93,26 @@ def test_layernorm(rows, eps):
     ref = F.layer_norm(x.double(), (384,), g.double(), b.double(), eps)
     assert _maxerr(y, ref) <= 2e-6
     assert _maxerr(y, ref) <= 3 * _maxerr(F.layer_norm(x, (384,), g, b, eps), ref) + 5e-7
+
+
+def test_layernorm_second_output_and_row_maps():
+    # y2 = y + add[r % 20]: the decoder's "tgt + query_pos" operand
+    x, g, b, qp = _rand(60, 384, seed=23), 1 + 0.1 * _rand(384, seed=24), 0.1 * _rand(384, seed=25), _rand(20, 384, seed=26)
+    y, y2 = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, add=qp.to(DEV))
+    ref = F.layer_norm(x.double(), (384,), g.double(), b.double(), 1e-5)
+    assert _maxerr(y, ref) <= 2e-6 and _maxerr(y2, ref + qp.repeat(3, 1).double()) <= 2e-6
+    # drop the cls row of each image: logical row r reads x row (r/n)*(n+1) + 1 + r%n
+    n, Bq = 5, 3
+    xt = _rand(Bq * (n + 1), 384, seed=27)
+    y = ops.layernorm(xt.to(DEV), g.to(DEV), b.to(DEV), 1e-6, in_map=(n, n + 1, 1), rows=Bq * n)
+    ref = F.layer_norm(xt.view(Bq, n + 1, 384)[:, 1:].reshape(-1, 384).double(), (384,), g.double(), b.double(), 1e-6)
+    assert _maxerr(y, ref) <= 2e-6
+    # scatter layer l of L into a (B, L, nq, 384) stack
+    L, l, nq = 4, 2, 5
+    xq = _rand(Bq * nq, 384, seed=28)
+    out = ops.layernorm(xq.to(DEV), g.to(DEV), b.to(DEV), 1e-5, out_map=(nq, L * nq, l * nq), out_rows=Bq * L * nq)
+    ref = F.layer_norm(xq.double(), (384,), g.double(), b.double(), 1e-5).view(Bq, nq, 384)
+    assert _maxerr(out.view(Bq, L, nq, 384)[:, l], ref) <= 2e-6
 
 
 def _attn_ref(q, k, v, scale):
