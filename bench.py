@@ -40,33 +40,68 @@ def forward_flops_per_image(P, S, L=6, nq=20):
     return enc + dec + head
 
 
-def time_dominant_kernel(B, N, iters=5):
-    """Average launch duration of the dominant kernel, gemm_f32_kernel<128,128>: in one forward it is launched 24
-    times on the encoder (12 x qkv [M,384]x[384,1152] and 12 x fc1 [M,384]x[384,1536]); replay exactly that
-    launch mix between two HIP events on the stream the library launches on (torch's current stream)."""
+def forward_gemm_launches(B, P, S, L=6, nq=20):
+    """Every sm_gemm_f32 launch of one MaskFormer.forward: (name, M, N, K, epilogue, batch, launches per forward)."""
+    from selfmask_amd import _native as Nn
+    g = S // P
+    n, N = g * g, g * g + 1
+    M, Mp, Md, Mo = B * N, B * n, B * nq, B * nq * L
+    return [
+        ("patch_embed", Mp, 384, 3 * P * P, Nn.EPI_BIAS, 1, 1),
+        ("enc.qkv", M, 1152, 384, Nn.EPI_BIAS, 1, 12), ("enc.proj", M, 384, 384, Nn.EPI_RESIDUAL, 1, 12),
+        ("enc.fc1", M, 1536, 384, Nn.EPI_GELU, 1, 12), ("enc.fc2", M, 384, 1536, Nn.EPI_RESIDUAL, 1, 12),
+        ("dec.sa_qk", Md, 768, 384, Nn.EPI_BIAS, 1, L), ("dec.sa_v", Md, 384, 384, Nn.EPI_BIAS, 1, L),
+        ("dec.sa_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L), ("dec.ca_q", Md, 384, 384, Nn.EPI_BIAS, 1, L),
+        ("dec.ca_kv", Mp, 768, 384, Nn.EPI_BIAS, 1, L), ("dec.ca_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L),
+        ("dec.lin1", Md, 1536, 384, Nn.EPI_RELU, 1, L), ("dec.lin2", Md, 384, 1536, Nn.EPI_RESIDUAL, 1, L),
+        ("mask_einsum", L * nq, 4 * n, 384, Nn.EPI_BIAS, B, 1),
+        ("obj.ffn0", Mo, 384, 384, Nn.EPI_RELU, 1, 1), ("obj.ffn1", Mo, 384, 384, Nn.EPI_RELU, 1, 1),
+    ]
+
+
+def time_gemm_kernels(B, P, S, iters=3):
+    """Live per-kernel timing of the GEMM instantiations (the kernels that hold >80 % of the forward): for each
+    kernel name (= workgroup tile) replay exactly the launch mix one forward issues, bracketed by HIP events on
+    the stream the library launches on (torch's current stream).  Returns {kernel: dict} sorted by time."""
+    import ctypes
     from selfmask_amd import ops, _native as Nn
-    M = B * N
+    lib = Nn.load()
     dev = "cuda"
-    a = torch.randn(M, 384, device=dev)
-    wq, bq = torch.randn(1152, 384, device=dev) * 0.02, torch.zeros(1152, device=dev)
-    w1, b1 = torch.randn(1536, 384, device=dev) * 0.02, torch.zeros(1536, device=dev)
-    cq = torch.empty(M, 1152, device=dev)
-    c1 = torch.empty(M, 1536, device=dev)
-    for _ in range(2):
-        ops.gemm(a, wq, bq, out=cq, tile=(128, 128))
-        ops.gemm(a, w1, b1, epilogue=Nn.EPI_GELU, out=c1, tile=(128, 128))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters * 12):
-        ops.gemm(a, wq, bq, out=cq, tile=(128, 128))
-        ops.gemm(a, w1, b1, epilogue=Nn.EPI_GELU, out=c1, tile=(128, 128))
-    e1.record()
-    torch.cuda.synchronize()
-    launches = iters * 24
-    avg_s = e0.elapsed_time(e1) * 1e-3 / launches
-    flops_per_launch = (2.0 * M * 384 * 1152 + 2.0 * M * 384 * 1536) / 2.0
-    return avg_s, flops_per_launch
+    groups = {}
+    for name, M, N, K, epi, batch, cnt in forward_gemm_launches(B, P, S):
+        ga = Nn.GemmArgs()
+        ga.M, ga.N, ga.K, ga.batch = M, N, K, batch
+        bm, bn = ctypes.c_int(), ctypes.c_int()
+        Nn.check(lib.sm_gemm_f32_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn)))
+        a = torch.randn(batch, M, K, device=dev)
+        w = torch.randn(batch, N, K, device=dev) * 0.03
+        bias = torch.zeros(N, device=dev)
+        c = torch.empty(batch, M, N, device=dev)
+        r = torch.randn(batch, M, N, device=dev) if epi == Nn.EPI_RESIDUAL else None
+        groups.setdefault((bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch))
+    out = {}
+    for (bm, bn), items in groups.items():
+        def run_mix():
+            for name, a, w, bias, c, r, epi, cnt, fl in items:
+                for _ in range(cnt):
+                    ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn))
+        run_mix()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            run_mix()
+        e1.record()
+        torch.cuda.synchronize()
+        launches = sum(i[7] for i in items)
+        flops = sum(i[7] * i[8] for i in items)
+        total_s = e0.elapsed_time(e1) * 1e-3 / iters
+        nst = {(128, 128): 2, (128, 64): 3, (64, 64): 4}[(bm, bn)]
+        out[f"gemm_f32_kernel<{bm}, {bn}, {nst}>"] = {
+            "launches_per_forward": launches, "avg_launch_us": total_s / launches * 1e6,
+            "flops_per_launch": flops / launches, "total_ms_per_forward": total_s * 1e3,
+            "achieved_tflops": flops / total_s / 1e12, "mix": [i[0] for i in items]}
+    return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms_per_forward"]))
 
 
 def cpu_baseline(P, S, budget_s=15.0):
@@ -96,8 +131,8 @@ def cpu_baseline(P, S, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
@@ -156,13 +191,11 @@ def main():
         dt = t.item()
 
     if rank == 0:
-        n = g = None
-        g = S // P
-        N = g * g + 1
         value = world * a.steps * B / dt
         flops_img = forward_flops_per_image(P, S)
-        avg_s, fl = time_dominant_kernel(B, N)
-        ach = fl / avg_s / 1e12
+        kern = time_gemm_kernels(B, P, S)
+        dom_name, dom = next(iter(kern.items()))
+        ach = dom["achieved_tflops"]
         res = {
             "metric": "images/sec (224^2, nq=20)", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -172,10 +205,17 @@ def main():
                        "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20,
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> (qkv + fc1 launches)",
+            "roofline": {"bound": "mfma", "kernel": dom_name, "launch_mix": dom["mix"],
                          "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "avg_launch_us": round(avg_s * 1e6, 2), "flops_per_launch": fl},
+                         "avg_launch_us": round(dom["avg_launch_us"], 2),
+                         "launches_per_forward": dom["launches_per_forward"],
+                         "flops_per_launch": dom["flops_per_launch"]},
+            "roofline_other_kernels": {k: {"achieved": round(v["achieved_tflops"], 2),
+                                           "frac": round(v["achieved_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                                           "avg_launch_us": round(v["avg_launch_us"], 2),
+                                           "launches_per_forward": v["launches_per_forward"]}
+                                       for k, v in list(kern.items())[1:]},
         }
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P, S)

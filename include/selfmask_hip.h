@@ -72,6 +72,8 @@ int sm_gemm_f32(const sm_gemm_args* args, void* stream);
 /* same with the workgroup tile forced (bm x bn in {128x128, 128x64, 64x64}); used by the parity tests to cover
  * every instantiation and by tuning runs */
 int sm_gemm_f32_tile(const sm_gemm_args* args, int bm, int bn, void* stream);
+/* the tile sm_gemm_f32 would launch for this shape (host-side heuristic, no GPU work) */
+int sm_gemm_f32_pick_tile(const sm_gemm_args* args, int* bm, int* bn);
 
 /* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
  * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */

@@ -256,13 +256,34 @@ extern "C" int sm_gemm_f32_tile(const sm_gemm_args* g, int bm, int bn, void* str
     return SM_EINVAL;
 }
 
+extern "C" int sm_gemm_f32_pick_tile(const sm_gemm_args* g, int* bm, int* bn) {
+    SM_REQUIRE(g && bm && bn && g->M > 0 && g->N > 0 && g->batch > 0, "sm_gemm_f32_pick_tile: bad arguments");
+    // Tile choice = argmax of (CU-quantisation utilisation) x (measured per-tile efficiency).  The kernel is
+    // MFMA-bound, so a launch takes ceil(workgroups / 256 CUs) rounds whatever the co-residency; e.g. proj/fc2
+    // (M=12608, N=384) is 297 tiles of 128x128 (2 rounds for 1.16 rounds of work) but 1182 of 64x64 (5 for 4.62).
+    // Efficiencies from scripts/gemm_sweep.py on MI355X: 128x128 1.00, 128x64 0.91, 64x64 0.84.
+    static const int tiles[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const double eff[3] = {1.00, 0.91, 0.84};
+    int best = 2;
+    double best_score = -1.0;
+    for (int t = 0; t < 3; ++t) {
+        const double wgs = (double)((g->M + tiles[t][0] - 1) / tiles[t][0]) * ((g->N + tiles[t][1] - 1) / tiles[t][1]) *
+                           g->batch;
+        const double rounds = wgs / 256.0;
+        const double util = rounds / (double)(long)(rounds + 0.999999);
+        const double score = util * eff[t];
+        if (score > best_score + 1e-9) { best_score = score; best = t; }
+    }
+    *bm = tiles[best][0];
+    *bn = tiles[best][1];
+    return SM_OK;
+}
+
 extern "C" int sm_gemm_f32(const sm_gemm_args* g, void* stream) {
     int rc = sm::validate(g);
     if (rc) return rc;
-    // pick the largest tile that still gives every CU (256) at least two workgroups
-    const long mt128 = (g->M + 127) / 128;
-    const long b = g->batch;
-    if (g->N % 128 == 0 && mt128 * (g->N / 128) * b >= 512) return sm_gemm_f32_tile(g, 128, 128, stream);
-    if (mt128 * ((g->N + 63) / 64) * b >= 512) return sm_gemm_f32_tile(g, 128, 64, stream);
-    return sm_gemm_f32_tile(g, 64, 64, stream);
+    int bm, bn;
+    rc = sm_gemm_f32_pick_tile(g, &bm, &bn);
+    if (rc) return rc;
+    return sm_gemm_f32_tile(g, bm, bn, stream);
 }

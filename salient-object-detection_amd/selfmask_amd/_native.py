@@ -77,6 +77,7 @@ SYMBOLS = {
     "sm_last_error": (C.c_char_p, []),
     "sm_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), fp]),
     "sm_gemm_f32_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, fp]),
+    "sm_gemm_f32_pick_tile": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),
     "sm_layernorm_rows_f32": (C.c_int, [C.POINTER(LnArgs), fp]),
     "sm_broadcast_rows_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, fp]),
