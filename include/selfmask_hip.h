@@ -136,6 +136,37 @@ int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float*
 /* features[b,:] = mean_q queries[b, last_layer, q, :]   (maskformer.py:198-203) */
 int sm_query_mean_f32(const float* queries, float* features, int32_t B, int32_t L, int32_t nq, void* stream);
 
+/* ---- evaluator post-processing + metrics ------------------------------------------- */
+typedef struct sm_eval_image {
+    int64_t gt_off; /* byte offset of this image's ground truth (H*W bytes, 0 / non-zero) inside `gt` */
+    int32_t H, W;   /* ground-truth (= output) size */
+} sm_eval_image;
+
+typedef struct sm_eval_args {
+    const float* mask_pred;      /* last decoder layer's probabilities: image b, query q at + b*mask_stride_b + q*mh*mw */
+    int64_t mask_stride_b;
+    const float* objectness;     /* last layer: image b, query q at + b*obj_stride_b + q                             */
+    int64_t obj_stride_b;
+    const uint8_t* gt;           /* concatenated ground-truth masks                                                  */
+    const sm_eval_image* images; /* device array [B]                                                                 */
+    const float* thresholds;     /* device array [255] = float32 arange(0, 1, 1/255) (metrics/f_measure.py:65)       */
+    float* rows;                 /* out [B][16]: 0-6 metrics of the arg-max-objectness mask, 7-13 of the upper-bound
+                                    mask, each in the order iou, pixel_acc, f_score, f_max, f_mean, mae, s_measure
+                                    (evaluator.pyc@L276 header order); 14 = picked query, 15 = upper-bound query      */
+    float* ious;                 /* out [B][nq] per-query IoU against the GT, or NULL                                 */
+    void* workspace;             /* sm_evaluate_workspace_bytes(B, nq), 16-B aligned                                  */
+    size_t workspace_bytes;
+    int32_t B, nq, mh, mw;
+    float scale;                 /* > 0: reference mode F.interpolate(scale_factor=scale)[..., :H, :W]
+                                    (evaluator.pyc@L209-211: 4 for ViT-S/8); 0: resize to (H, W) (batched mode)       */
+} sm_eval_args;
+
+/* Per image: bilinear up-sample of the nq query masks (align_corners=False), upper-bound query = arg-max IoU vs GT
+ * (evaluator.pyc@L101-134,216), pick = arg-max objectness (@L219-221), then compute_iou / FMeasure (f_measure,
+ * f_max over 255 thresholds, f_mean) / compute_mae / compute_pixel_accuracy / SMeasure (metrics/ *.py) for both. */
+size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq);
+int sm_evaluate_masks_f32(const sm_eval_args* args, void* stream);
+
 /* ---- whole forward --------------------------------------------------------------------------------------------- */
 typedef struct sm_enc_layer {
     const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w,

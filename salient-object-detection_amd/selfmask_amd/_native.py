@@ -71,6 +71,17 @@ class ForwardIO(C.Structure):
                 ("patch_tokens", fp), ("encoder_only", C.c_int32)]
 
 
+class EvalImage(C.Structure):
+    _fields_ = [("gt_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32)]
+
+
+class EvalArgs(C.Structure):
+    _fields_ = [("mask_pred", fp), ("mask_stride_b", C.c_int64), ("objectness", fp), ("obj_stride_b", C.c_int64),
+                ("gt", fp), ("images", fp), ("thresholds", fp), ("rows", fp), ("ious", fp), ("workspace", fp),
+                ("workspace_bytes", C.c_size_t), ("B", C.c_int32), ("nq", C.c_int32), ("mh", C.c_int32),
+                ("mw", C.c_int32), ("scale", C.c_float)]
+
+
 # every symbol include/selfmask_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sm_version": (C.c_int, []),
@@ -88,6 +99,8 @@ SYMBOLS = {
     "sm_upsample2x_tokens_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Weights), C.c_int32, C.c_int32, C.c_int32]),
     "sm_maskformer_forward": (C.c_int, [C.POINTER(Weights), C.POINTER(ForwardIO), fp, C.c_size_t, fp]),
 }

@@ -141,3 +141,57 @@ def rowdot_sigmoid(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.T
     N.check(N.load().sm_rowdot_sigmoid_f32(h2.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), h2.shape[0],
                                            _stream()), "sm_rowdot_sigmoid")
     return out
+
+
+_THRESHOLDS = {}
+
+
+def f_max_thresholds(device) -> torch.Tensor:
+    """The 255 strict thresholds of metrics/f_measure.py:65 as the float32 values torch.arange produces (constant)."""
+    t = _THRESHOLDS.get(device)
+    if t is None:
+        t = torch.arange(0, 1, 1 / 255).to(device)
+        assert t.numel() == 255 and t.dtype == torch.float32
+        _THRESHOLDS[device] = t
+    return t
+
+
+def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, gts, scale: float = 0.0,
+                   return_ious: bool = False):
+    """Evaluator post-processing + 14 metrics per image on the device (sm_evaluate_masks_f32).
+
+    mask_pred_last (B, nq, mh, mw) probabilities (any batch stride, e.g. ``out["mask_pred"][:, -1]``),
+    objectness_last (B, nq), gts: list of B uint8 {0,1} tensors (H_b, W_b) on the device.
+    scale > 0: reference mode (F.interpolate(scale_factor=scale)[..., :H, :W]); 0: resize to each GT's size.
+    Returns rows (B, 16) float32 [7 metrics of the picked mask, 7 of the upper bound, q*, ub] (+ ious (B, nq))."""
+    _dev(mask_pred_last, objectness_last)
+    B, nq, mh, mw = mask_pred_last.shape
+    assert mask_pred_last.stride(3) == 1 and mask_pred_last.stride(2) == mw and mask_pred_last.stride(1) == mh * mw
+    assert objectness_last.stride(1) == 1 and len(gts) == B
+    dev = mask_pred_last.device
+    descr = (N.EvalImage * B)()
+    off = 0
+    flat = []
+    for b, g in enumerate(gts):
+        if g.dtype != torch.uint8 or not g.is_cuda or g.dim() != 2:
+            raise RuntimeError("ground-truth masks must be 2-D uint8 tensors on the HIP device")
+        descr[b].gt_off, descr[b].H, descr[b].W = off, g.shape[0], g.shape[1]
+        if scale > 0:
+            assert g.shape[0] <= int(mh * scale) and g.shape[1] <= int(mw * scale), "GT larger than the up-sampled mask"
+        off += g.numel()
+        flat.append(g.reshape(-1))
+    gt_all = flat[0] if B == 1 else torch.cat(flat)
+    images = torch.frombuffer(bytearray(bytes(descr)), dtype=torch.uint8).to(dev)
+    rows = torch.empty((B, 16), device=dev, dtype=torch.float32)
+    ious = torch.empty((B, nq), device=dev, dtype=torch.float32) if return_ious else None
+    lib = N.load()
+    wsb = lib.sm_evaluate_workspace_bytes(B, nq)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    a = N.EvalArgs()
+    a.mask_pred, a.mask_stride_b = mask_pred_last.data_ptr(), mask_pred_last.stride(0)
+    a.objectness, a.obj_stride_b = objectness_last.data_ptr(), objectness_last.stride(0)
+    a.gt, a.images, a.thresholds = gt_all.data_ptr(), images.data_ptr(), f_max_thresholds(dev).data_ptr()
+    a.rows, a.ious, a.workspace, a.workspace_bytes = rows.data_ptr(), _ptr(ious), ws.data_ptr(), wsb
+    a.B, a.nq, a.mh, a.mw, a.scale = B, nq, mh, mw, float(scale)
+    N.check(lib.sm_evaluate_masks_f32(a, _stream()), "sm_evaluate_masks_f32")
+    return (rows, ious) if return_ious else rows
