@@ -159,15 +159,28 @@ def main():
     model = model.to(dev)
     # every rank owns a different shard of the (synthetic) image list: rank-strided seeds
     x = torch.from_numpy(synthetic_images(1234 + rank, (B, 3, S, S))).to(dev)
+    # synthetic ground truth at DUTS-like native sizes (300-400 px ellipses), packed once and resident in HBM
+    import numpy as np
+    from selfmask_amd import ops
+    rng = np.random.Generator(np.random.PCG64(99 + rank))
+    gts = []
+    for _ in range(B):
+        h, w = (int(v) for v in rng.integers(300, 401, size=2))
+        yy, xx = np.mgrid[:h, :w]
+        gts.append(torch.from_numpy(((((yy - h * rng.uniform(.3, .7)) / (h * rng.uniform(.1, .3))) ** 2 +
+                                      ((xx - w * rng.uniform(.3, .7)) / (w * rng.uniform(.1, .3))) ** 2) <= 1)
+                                    .astype(np.uint8)))
+    gt_batch = ops.GtBatch(gts, dev)
 
     def step():
+        # one evaluator iteration over a batch (evaluator.pyc@L193-228, batched mode): forward, last decoder
+        # layer, up-sample to each GT's size, upper-bound + arg-max-objectness query, 7 metrics x 2 -> 16 floats/image
         out = model(x)
-        # evaluator's selection (evaluator.pyc@L219-221): highest-objectness query of the last decoder layer
-        return out["objectness"][:, -1, :, 0].argmax(dim=1)
+        return ops.evaluate_masks(out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0], gt_batch, scale=0.0)
 
     for _ in range(a.warmup):
         step()
-    rows = torch.zeros((a.steps * B, 15), device=dev)  # per-image result rows: global index + 14 metric slots
+    rows = torch.zeros((a.steps * B, 16), device=dev)  # per-image result rows (14 metrics + the two query ids)
 
     def sync():
         torch.cuda.synchronize()
@@ -178,10 +191,9 @@ def main():
     sync()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        sel = step()
-        rows[k * B:(k + 1) * B, 0] = sel.float()
+        rows[k * B:(k + 1) * B] = step()
     if world > 1:  # the path's one exchange: all-gather of the per-image rows
-        gathered = torch.empty((world * rows.shape[0], 15), device=dev)
+        gathered = torch.empty((world * rows.shape[0], 16), device=dev)
         dist.all_gather_into_tensor(gathered, rows)
     sync()
     dt = time.perf_counter() - t0
@@ -201,7 +213,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
-                                   f"MaskFormer.forward + objectness arg-max (BASELINE.json configs[1])",
+                                   f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
                        "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20,
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),

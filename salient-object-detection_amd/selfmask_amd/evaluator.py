@@ -1,0 +1,116 @@
+"""Mirror of the reference's ``evaluator.Evaluator`` (bytecode-only in the reference; behaviour per SURVEY.md
+Appendix A, evaluator.pyc@L17-373) with the per-image work on the MI355X:
+
+  forward (HIP) -> last decoder layer -> bilinear up-sample + crop -> upper-bound query by IoU, arg-max-objectness
+  query -> 7 metrics x {pick, upper bound} (sm_evaluate_masks_f32) -> running means -> ``metrics_<dataset>.txt``.
+
+Two operating points: the reference's own (batch 1, native resolution, up-sample factor patch_size // scale_factor,
+i.e. the hard-coded 4 of evaluator.pyc@L209-211 for ViT-S/8) and a batched mode (``img_size`` given: inputs resized
+to S x S, masks resized to each GT's native size).  Images shard across ranks (distributed.py).
+"""
+import argparse
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .base_structure import BaseStructure
+from .datasets import get_dataset
+from .distributed import HEADER, KEYS, SingleComm, TorchDistComm, average_rows, gather_rows, shard_indices
+
+
+class Evaluator(BaseStructure):
+    def __init__(self, network: callable, arch: str = "vit_small", dir_dataset: str = "datasets",
+                 visualizer: Optional[callable] = None, debug: bool = False):
+        super().__init__(model=network, visualizer=visualizer)
+        assert os.path.exists(dir_dataset), dir_dataset  # evaluator.pyc@L27
+        self.arch, self.debug, self.dir_dataset, self.network = arch, debug, dir_dataset, network
+
+    @torch.no_grad()
+    def __call__(self, dataset_name: str, dir_ckpt: str, img_size: Optional[int] = None, scale_factor: int = 2,
+                 batch_size: int = 1, device: torch.device = torch.device("cuda:0"), cost_type: str = "iou",
+                 comm=None) -> dict:
+        assert cost_type == "iou", "the upper bound is chosen by IoU (evaluator.pyc@L216); other costs are unused"
+        if not getattr(self.model, "use_binary_classifier", True):
+            raise RuntimeError("the evaluator dereferences objectness unconditionally (evaluator.pyc@L219): "
+                               "use_binary_classifier=True is required")
+        if comm is None:
+            import torch.distributed as dist
+            comm = TorchDistComm() if dist.is_available() and dist.is_initialized() else SingleComm()
+        dataset = get_dataset(self.dir_dataset, dataset_name, mode="test", eval_img_size=img_size)
+        n_total = len(dataset)
+        mine = shard_indices(n_total, comm.rank, comm.world_size)
+        if self.debug:
+            mine = mine[:batch_size]
+        patch = self.model.encoder.patch_size
+        scale = 0.0 if img_size is not None else float(patch // scale_factor)
+        if img_size is None and batch_size != 1:
+            raise ValueError("native-resolution evaluation runs at batch_size=1 (images differ in size)")
+        rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
+        for s in range(0, len(mine), batch_size):
+            items = [dataset[i] for i in mine[s:s + batch_size]]
+            x = torch.stack([it["x"] for it in items])
+            out = self._forward({"x": x}, device=device)
+            mask_pred, obj = out["mask_pred"], out.get("objectness")
+            if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
+                mask_pred, obj = mask_pred[:, -1], obj[:, -1]
+            gts = [it["m"].squeeze().to(device) for it in items]
+            rows_local[s:s + len(items)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gts, scale=scale)
+        if self.debug:
+            n_total = len(mine) * comm.world_size
+            mine = list(range(comm.rank, n_total, comm.world_size))
+        rows = gather_rows(rows_local, mine, n_total, comm)
+        results = average_rows(rows)
+        if comm.rank == 0:
+            os.makedirs(dir_ckpt, exist_ok=True)
+            with open(os.path.join(dir_ckpt, f"metrics_{dataset_name}.txt"), "w") as f:  # evaluator.pyc@L275-293
+                f.write(HEADER)
+                f.write(",".join(str(results[k + sfx]) for sfx in ("", "_ub") for k in
+                                 ("iou", "pixel_accuarcy", "f_score", "f_max", "f_mean", "mae", "s_measure")))
+        self.last_rows = rows
+        return results
+
+
+def main(argv=None):
+    """CLI of evaluator.pyc@L312-373: --config --p_state_dict --dataset_name ... (yaml merged over the flags)."""
+    import yaml
+    from .maskformer import load_checkpoint
+    from .misc import get_model, set_seeds
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--p_state_dict", type=str, required=True)
+    ap.add_argument("--dataset_name", type=str, default="duts", choices=["dut_omron", "duts", "ecssd"])
+    ap.add_argument("--use_gpu", type=bool, default=True)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dir_root", type=str, default="..")
+    ap.add_argument("--gpu_id", type=int, default=0)
+    ap.add_argument("--suffix", type=str, default="")
+    ap.add_argument("--img_size", type=int, default=None, help="batched mode: resize inputs to S x S")
+    ap.add_argument("--batch_size", type=int, default=1)
+    args = ap.parse_args(argv)
+    base = yaml.safe_load(open(args.config))
+    vars(args).update(base)
+    set_seeds(args.seed)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else args.gpu_id
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    model = get_model("maskformer", configs=args)
+    load_checkpoint(model, args.p_state_dict)
+    model = model.to(device).eval()
+    ev = Evaluator(network=model, dir_dataset=args.dir_dataset)
+    ev.device = device
+    res = ev(args.dataset_name, dir_ckpt=os.path.join(args.dir_ckpt, "eval" + args.suffix), img_size=args.img_size,
+             scale_factor=args.scale_factor, batch_size=args.batch_size, device=device)
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(res)
+    return res
+
+
+if __name__ == "__main__":
+    main()

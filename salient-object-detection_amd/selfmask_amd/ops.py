@@ -156,32 +156,44 @@ def f_max_thresholds(device) -> torch.Tensor:
     return t
 
 
+class GtBatch:
+    """Ground-truth masks of one batch packed for sm_evaluate_masks_f32: one uint8 buffer + a device descriptor
+    array.  Build it once per batch (the evaluator's data loader side), reuse it across calls."""
+
+    def __init__(self, gts, device):
+        B = len(gts)
+        descr = (N.EvalImage * B)()
+        off, flat = 0, []
+        for b, g in enumerate(gts):
+            if g.dtype != torch.uint8 or g.dim() != 2:
+                raise RuntimeError("ground-truth masks must be 2-D uint8 tensors")
+            descr[b].gt_off, descr[b].H, descr[b].W = off, g.shape[0], g.shape[1]
+            off += g.numel()
+            flat.append(g.reshape(-1))
+        self.B = B
+        self.shapes = [(int(g.shape[0]), int(g.shape[1])) for g in gts]
+        self.gt_all = (flat[0] if B == 1 else torch.cat(flat)).to(device)
+        self.images = torch.frombuffer(bytearray(bytes(descr)), dtype=torch.uint8).to(device)
+
+
 def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, gts, scale: float = 0.0,
                    return_ious: bool = False):
     """Evaluator post-processing + 14 metrics per image on the device (sm_evaluate_masks_f32).
 
     mask_pred_last (B, nq, mh, mw) probabilities (any batch stride, e.g. ``out["mask_pred"][:, -1]``),
-    objectness_last (B, nq), gts: list of B uint8 {0,1} tensors (H_b, W_b) on the device.
+    objectness_last (B, nq), gts: list of B uint8 {0,1} tensors (H_b, W_b) or a prepacked GtBatch.
     scale > 0: reference mode (F.interpolate(scale_factor=scale)[..., :H, :W]); 0: resize to each GT's size.
     Returns rows (B, 16) float32 [7 metrics of the picked mask, 7 of the upper bound, q*, ub] (+ ious (B, nq))."""
     _dev(mask_pred_last, objectness_last)
     B, nq, mh, mw = mask_pred_last.shape
     assert mask_pred_last.stride(3) == 1 and mask_pred_last.stride(2) == mw and mask_pred_last.stride(1) == mh * mw
-    assert objectness_last.stride(1) == 1 and len(gts) == B
+    assert objectness_last.stride(1) == 1
     dev = mask_pred_last.device
-    descr = (N.EvalImage * B)()
-    off = 0
-    flat = []
-    for b, g in enumerate(gts):
-        if g.dtype != torch.uint8 or not g.is_cuda or g.dim() != 2:
-            raise RuntimeError("ground-truth masks must be 2-D uint8 tensors on the HIP device")
-        descr[b].gt_off, descr[b].H, descr[b].W = off, g.shape[0], g.shape[1]
-        if scale > 0:
-            assert g.shape[0] <= int(mh * scale) and g.shape[1] <= int(mw * scale), "GT larger than the up-sampled mask"
-        off += g.numel()
-        flat.append(g.reshape(-1))
-    gt_all = flat[0] if B == 1 else torch.cat(flat)
-    images = torch.frombuffer(bytearray(bytes(descr)), dtype=torch.uint8).to(dev)
+    gb = gts if isinstance(gts, GtBatch) else GtBatch(gts, dev)
+    assert gb.B == B
+    if scale > 0:
+        for (h, w) in gb.shapes:
+            assert h <= int(mh * scale) and w <= int(mw * scale), "GT larger than the up-sampled mask"
     rows = torch.empty((B, 16), device=dev, dtype=torch.float32)
     ious = torch.empty((B, nq), device=dev, dtype=torch.float32) if return_ious else None
     lib = N.load()
@@ -190,7 +202,7 @@ def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, 
     a = N.EvalArgs()
     a.mask_pred, a.mask_stride_b = mask_pred_last.data_ptr(), mask_pred_last.stride(0)
     a.objectness, a.obj_stride_b = objectness_last.data_ptr(), objectness_last.stride(0)
-    a.gt, a.images, a.thresholds = gt_all.data_ptr(), images.data_ptr(), f_max_thresholds(dev).data_ptr()
+    a.gt, a.images, a.thresholds = gb.gt_all.data_ptr(), gb.images.data_ptr(), f_max_thresholds(dev).data_ptr()
     a.rows, a.ious, a.workspace, a.workspace_bytes = rows.data_ptr(), _ptr(ious), ws.data_ptr(), wsb
     a.B, a.nq, a.mh, a.mw, a.scale = B, nq, mh, mw, float(scale)
     N.check(lib.sm_evaluate_masks_f32(a, _stream()), "sm_evaluate_masks_f32")
