@@ -167,6 +167,27 @@ typedef struct sm_eval_args {
 size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq);
 int sm_evaluate_masks_f32(const sm_eval_args* args, void* stream);
 
+/* ---- bilateral-solver refinement ---------------------------------------------------- */
+typedef struct sm_bilateral_args {
+    const uint8_t* img;    /* (H, W, 3) interleaved RGB = np.array(PIL image)   (bilateral_solver.py:159)            */
+    const double* target;  /* (H, W) fp64 soft mask (the reference casts to np.double, :181)                         */
+    double* soft;          /* out (H, W) fp64: output_solver (:186)                                                   */
+    uint8_t* binary;       /* out (H, W) 0/1: binary_solver (:184-192)                                                */
+    int32_t* info;         /* out [4] or NULL: vertices, PCG iterations, labelled components, chosen root (-2 = all ones) */
+    void* workspace;       /* sm_bilateral_workspace_bytes(...), 256-B aligned                                        */
+    size_t workspace_bytes;
+    double sigma_spatial, sigma_luma, sigma_chroma; /* 16, 16, 8 (:155-157); sigma_spatial integral, <= 32            */
+    double lam, a_diag_min, cg_tol, confidence;     /* 256, 1e-5, 1e-5, 0.999 (:161,170-175)                          */
+    int32_t cg_maxiter;                             /* 25                                                              */
+    int32_t H, W;
+} sm_bilateral_args;
+
+/* bilateral_solver_output (bilateral_solver.py:152-193): BilateralGrid (hash -> unique -> splat / blur matrices),
+ * bistochastize, Jacobi-PCG solve, slice, threshold 0.5, binary_fill_holes, 4-connected label, keep the second
+ * largest label (background included). */
+size_t sm_bilateral_workspace_bytes(int32_t H, int32_t W, double sigma_spatial, double sigma_luma, double sigma_chroma);
+int sm_bilateral_solver_f64(const sm_bilateral_args* args, void* stream);
+
 /* ---- whole forward --------------------------------------------------------------------------------------------- */
 typedef struct sm_enc_layer {
     const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w,

@@ -82,6 +82,13 @@ class EvalArgs(C.Structure):
                 ("mw", C.c_int32), ("scale", C.c_float)]
 
 
+class BilateralArgs(C.Structure):
+    _fields_ = [("img", fp), ("target", fp), ("soft", fp), ("binary", fp), ("info", fp), ("workspace", fp),
+                ("workspace_bytes", C.c_size_t), ("sigma_spatial", C.c_double), ("sigma_luma", C.c_double),
+                ("sigma_chroma", C.c_double), ("lam", C.c_double), ("a_diag_min", C.c_double), ("cg_tol", C.c_double),
+                ("confidence", C.c_double), ("cg_maxiter", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 # every symbol include/selfmask_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sm_version": (C.c_int, []),
@@ -101,6 +108,8 @@ SYMBOLS = {
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
+    "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "sm_bilateral_solver_f64": (C.c_int, [C.POINTER(BilateralArgs), fp]),
     "sm_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Weights), C.c_int32, C.c_int32, C.c_int32]),
     "sm_maskformer_forward": (C.c_int, [C.POINTER(Weights), C.POINTER(ForwardIO), fp, C.c_size_t, fp]),
 }
