@@ -154,9 +154,10 @@ typedef struct sm_eval_args {
                                     mask, each in the order iou, pixel_acc, f_score, f_max, f_mean, mae, s_measure
                                     (evaluator.pyc@L276 header order); 14 = picked query, 15 = upper-bound query      */
     float* ious;                 /* out [B][nq] per-query IoU against the GT, or NULL                                 */
-    void* workspace;             /* sm_evaluate_workspace_bytes(B, nq), 16-B aligned                                  */
+    void* workspace;             /* sm_evaluate_workspace_bytes(B, nq), 256-B aligned                                 */
     size_t workspace_bytes;
-    int32_t B, nq, mh, mw;
+    int32_t B, nq, mh, mw;       /* nq <= 32                                                                         */
+    int32_t max_pixels;          /* largest H*W among the batch's ground truths (<= 1024*1024): sizes the launch grid */
     float scale;                 /* > 0: reference mode F.interpolate(scale_factor=scale)[..., :H, :W]
                                     (evaluator.pyc@L209-211: 4 for ViT-S/8); 0: resize to (H, W) (batched mode)       */
 } sm_eval_args;

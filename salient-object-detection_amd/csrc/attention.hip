@@ -3,8 +3,7 @@
 // nn.MultiheadAttention in the decoder (transformer_decoder.py:273-289).
 //
 // One wave owns 32 query rows; the NW waves of a workgroup share one (batch, head) and stage its keys/values
-// through LDS in chunks of <= 224 keys (N = 197 fits in one chunk: no online-softmax rescale is ever taken there;
-// longer sequences (ViT-S/8: 785, 384^2: 577 / 2305) loop over chunks with a running max / sum).
+// through LDS in chunks of <= 128 keys with a running max / sum (online softmax) across chunks.
 //
 // Layout trick (wave64, v_mfma_f32_32x32x2_f32): scores are computed TRANSPOSED, S^T = K Q^T, so the accumulator
 // has the query on the lane (col = lane & 31) and the keys in the 16 registers x 2 lane halves.  A row softmax
@@ -17,13 +16,14 @@
 
 namespace sm {
 
-constexpr int ATT_KB = 7;           // 32-key blocks per LDS chunk
+constexpr int ATT_KB = 4;           // 32-key blocks per LDS chunk (128 keys: 66 KiB of LDS -> two workgroups per CU)
 constexpr int ATT_KCH = ATT_KB * 32;
 constexpr int ATT_KLD = 68;         // padded K row: conflict-free ds_read_b128
 constexpr int ATT_VLD = 64;         // V rows are read with ds_read_b32 along d: conflict-free unpadded
 
+// __launch_bounds__(.., 2): at most 256 registers per lane so two workgroups (one wave each per SIMD) share a CU
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attention_f32_kernel(sm_attn_args a, int kc_rows) {
+__global__ __launch_bounds__(NW * 64, 2) void attention_f32_kernel(sm_attn_args a, int kc_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;
     float* Vs = smem + kc_rows * ATT_KLD;
@@ -39,14 +39,18 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(sm_attn_args a, 
     const float* Vp = a.V + b * a.sVb + head * SM_HEAD_DIM;
 
     // Q fragments: B operand of S^T = K Q^T.  lane (r,h) holds Q[q0+r][8t+4h .. +3], t = 0..7 (same k-permutation
-    // as the K reads below); pre-scaled (scale = 1/8 is a power of two: exact, = scaling the product).
+    // as the K reads below); pre-scaled by scale * log2(e) so the scores come out in log2 units and the softmax
+    // exponential is ONE v_exp_f32 (exp2) per element instead of expf's 12-instruction range reduction.  The
+    // argument error this adds (|y| * 2^-24 relative) is weighted by the probability itself (p * |y| <= 0.53), i.e.
+    // < 3e-8 absolute per attention weight: below fp32 resolution of the normalised weights.
     int qrow = q0 + r;
     qrow = qrow < a.n_q ? qrow : a.n_q - 1;
     float4 qf[8];
+    const float qscale = a.scale * 1.44269504088896340736f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         qf[t] = *reinterpret_cast<const float4*>(Qp + (int64_t)qrow * a.sQr + 8 * t + 4 * h);
-        qf[t].x *= a.scale; qf[t].y *= a.scale; qf[t].z *= a.scale; qf[t].w *= a.scale;
+        qf[t].x *= qscale; qf[t].y *= qscale; qf[t].z *= qscale; qf[t].w *= qscale;
     }
 
     f32x16 o[2];
@@ -79,13 +83,16 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(sm_attn_args a, 
             for (int v = 0; v < 16; ++v) s[kb][v] = 0.f;
             if (kb < nb) {
                 const float* kr = Ks + (kb * 32 + r) * ATT_KLD + 4 * h;
+                float4 kf[8];  // all eight fragment reads of the block in flight before the first MFMA needs one
+#pragma unroll
+                for (int t = 0; t < 8; ++t) kf[t] = *reinterpret_cast<const float4*>(kr + 8 * t);
+                __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs (hipcc sinks them otherwise)
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const float4 kf = *reinterpret_cast<const float4*>(kr + 8 * t);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s[kb], 0, 0, 0);
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t].x, qf[t].x, s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t].y, qf[t].y, s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t].z, qf[t].z, s[kb], 0, 0, 0);
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t].w, qf[t].w, s[kb], 0, 0, 0);
                 }
             }
         }
@@ -94,17 +101,18 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(sm_attn_args a, 
 #pragma unroll
         for (int kb = 0; kb < ATT_KB; ++kb) {
             if (kb < nb) {
+                if ((kb + 1) * 32 > ck) {  // only the last block of the last chunk has padded keys (uniform branch)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int key = kb * 32 + acc_row(v, h);
-                    if (key >= ck) s[kb][v] = -INFINITY;
-                    cmax = fmaxf(cmax, s[kb][v]);
+                    for (int v = 0; v < 16; ++v)
+                        if (kb * 32 + acc_row(v, h) >= ck) s[kb][v] = -INFINITY;
                 }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, s[kb][v]);
             }
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));  // the other half holds the other 16 keys of each block
         const float m_new = fmaxf(m_run, cmax);
-        const float alpha = expf(m_run - m_new);  // first chunk: exp(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first chunk: exp2(-inf) = 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(sm_attn_args a, 
             if (kb < nb) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const float p = expf(s[kb][v] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(s[kb][v] - m_new);
                     s[kb][v] = p;
                     psum += p;
                 }
@@ -127,11 +135,18 @@ __global__ __launch_bounds__(NW * 64) void attention_f32_kernel(sm_attn_args a, 
 #pragma unroll
         for (int kb = 0; kb < ATT_KB; ++kb) {
             if (kb < nb) {
+                float v0[16], v1[16];  // the block's 32 V operands are read ahead of its 32 MFMAs
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float* vr = Vs + (kb * 32 + acc_row(v, h)) * ATT_VLD + r;
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], s[kb][v], o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[kb][v], o[1], 0, 0, 0);
+                    v0[v] = vr[0];
+                    v1[v] = vr[32];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[v], s[kb][v], o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[v], s[kb][v], o[1], 0, 0, 0);
                 }
             }
         }
@@ -182,17 +197,14 @@ extern "C" int sm_attention_f32(const sm_attn_args* a, void* stream) {
                "sm_attention_f32: pointers must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;
     const int nqb = (a->n_q + 31) / 32;
-    // waves per workgroup: as even a split of the 32-row query blocks as possible, at most 8
-    const int groups = (nqb + 7) / 8;
+    // waves per workgroup: as even a split of the 32-row query blocks as possible, at most 4 (one per SIMD; two
+    // workgroups share a CU, so a SIMD alternates one wave's MFMAs with the other's softmax VALU work)
+    const int groups = (nqb + 3) / 4;
     const int nw = (nqb + groups - 1) / groups;
     switch (nw) {
         case 1: return sm::launch_attn<1>(*a, nqb, st);
         case 2: return sm::launch_attn<2>(*a, nqb, st);
         case 3: return sm::launch_attn<3>(*a, nqb, st);
-        case 4: return sm::launch_attn<4>(*a, nqb, st);
-        case 5: return sm::launch_attn<5>(*a, nqb, st);
-        case 6: return sm::launch_attn<6>(*a, nqb, st);
-        case 7: return sm::launch_attn<7>(*a, nqb, st);
-        default: return sm::launch_attn<8>(*a, nqb, st);
+        default: return sm::launch_attn<4>(*a, nqb, st);
     }
 }

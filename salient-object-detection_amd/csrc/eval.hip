@@ -51,51 +51,90 @@ __device__ __forceinline__ float up_sample(const float* __restrict__ m, int mw, 
 }
 
 template <typename T>
-__device__ __forceinline__ T block_sum(T v, T* red) {  // 256 threads; red: >= 4 entries of LDS
+__device__ __forceinline__ T wave_total(T v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    return v;
 }
 
-struct QueryStats { unsigned inter, uni; double sum_p; };
-struct GtStats { double sum_g, sum_gx, sum_gy; };
+constexpr int EV_THREADS = 256;
+constexpr int EV_PPT = 8;                       // pixels per thread
+constexpr int EV_CHUNK = EV_THREADS * EV_PPT;   // pixels per workgroup
+constexpr int EV_MAXQ = 32;                     // queries handled per pass of the query kernel
+constexpr int EV_NACC = 22;                     // fp64 partial sums per (image, which, chunk)
 
-__global__ __launch_bounds__(256) void eval_query_kernel(sm_eval_args a, QueryStats* qs, GtStats* gs) {
-    __shared__ double redd[4];
-    __shared__ unsigned redu[4];
-    const int q = blockIdx.x, b = blockIdx.y;
+struct QueryStats { unsigned inter, uni; };
+struct GtStats { unsigned long long sum_g, sum_gx, sum_gy; };
+
+// pixel index -> (y, x) without an integer division: float reciprocal + one correction step (idx < 2^24)
+__device__ __forceinline__ void split_idx(int idx, int W, float inv_w, int& y, int& x) {
+    y = (int)((float)idx * inv_w);
+    x = idx - y * W;
+    if (x < 0) { --y; x += W; } else if (x >= W) { ++y; x -= W; }
+}
+
+// K1: one workgroup per (pixel chunk, image): every thread up-samples ALL queries at its pixels (index math and the
+// GT byte are shared by the nq queries), integer counts go to global memory with integer atomics (deterministic).
+__global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, QueryStats* qs, GtStats* gs) {
+    const int b = blockIdx.y;
     const sm_eval_image im = a.images[b];
+    const int npx = im.H * im.W;
+    const int base = blockIdx.x * EV_CHUNK;
+    if (base >= npx) return;
     const unsigned char* __restrict__ gt = a.gt + im.gt_off;
-    const float* __restrict__ m = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)q * a.mh * a.mw;
+    const float* __restrict__ m0 = a.mask_pred + (int64_t)b * a.mask_stride_b;
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
-    unsigned inter = 0, uni = 0;
-    double sp = 0.0, sg = 0.0, sgx = 0.0, sgy = 0.0;
-    const int npx = im.H * im.W;
-    for (int idx = threadIdx.x; idx < npx; idx += 256) {
-        const int y = idx / im.W, x = idx - y * im.W;
-        const float p = up_sample(m, a.mw, up_index(y, sy, a.mh), up_index(x, sx, a.mw));
-        const unsigned g = gt[idx] != 0, bin = p > 0.5f;
-        inter += bin & g;
-        uni += bin | g;
-        sp += (double)p;
-        if (q == 0 && g) { sg += 1.0; sgx += (double)x; sgy += (double)y; }
+    const float inv_w = 1.0f / (float)im.W;
+    const int plane = a.mh * a.mw;
+    unsigned inter[EV_MAXQ], uni[EV_MAXQ];
+#pragma unroll
+    for (int q = 0; q < EV_MAXQ; ++q) { inter[q] = 0; uni[q] = 0; }
+    unsigned long long sg = 0, sgx = 0, sgy = 0;
+    for (int k = 0; k < EV_PPT; ++k) {
+        const int idx = base + k * EV_THREADS + threadIdx.x;
+        if (idx >= npx) break;
+        int y, x;
+        split_idx(idx, im.W, inv_w, y, x);
+        const UpIdx uy = up_index(y, sy, a.mh), ux = up_index(x, sx, a.mw);
+        const unsigned g = gt[idx] != 0;
+        if (g) { sg += 1; sgx += (unsigned)x; sgy += (unsigned)y; }
+#pragma unroll
+        for (int q = 0; q < EV_MAXQ; ++q) {
+            if (q < a.nq) {
+                const unsigned bin = up_sample(m0 + q * plane, a.mw, uy, ux) > 0.5f;
+                inter[q] += bin & g;
+                uni[q] += bin | g;
+            }
+        }
     }
-    inter = block_sum<unsigned>(inter, redu);
-    uni = block_sum<unsigned>(uni, redu);
-    sp = block_sum<double>(sp, redd);
-    if (q == 0) {
-        sg = block_sum<double>(sg, redd);
-        sgx = block_sum<double>(sgx, redd);
-        sgy = block_sum<double>(sgy, redd);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < EV_MAXQ; ++q) {
+        if (q < a.nq) {
+            const unsigned i = wave_total(inter[q]), u = wave_total(uni[q]);
+            if (lane == 0) { atomicAdd(&qs[b * a.nq + q].inter, i); atomicAdd(&qs[b * a.nq + q].uni, u); }
+        }
     }
-    if (threadIdx.x == 0) {
-        QueryStats s; s.inter = inter; s.uni = uni; s.sum_p = sp;
-        qs[b * a.nq + q] = s;
-        if (q == 0) { GtStats t; t.sum_g = sg; t.sum_gx = sgx; t.sum_gy = sgy; gs[b] = t; }
+    sg = wave_total(sg); sgx = wave_total(sgx); sgy = wave_total(sgy);
+    if (lane == 0) { atomicAdd(&gs[b].sum_g, sg); atomicAdd(&gs[b].sum_gx, sgx); atomicAdd(&gs[b].sum_gy, sgy); }
+}
+
+// selection (evaluator.pyc@L216-221): which = 0 arg-max objectness, which = 1 arg-max IoU (first maximum)
+__device__ int select_query(const sm_eval_args& a, const QueryStats* qs, int b, int which, bool write_ious) {
+    int best = 0;
+    if (which == 0) {
+        const float* o = a.objectness + (int64_t)b * a.obj_stride_b;
+        for (int q = 1; q < a.nq; ++q) if (o[q] > o[best]) best = q;
+    } else {
+        float bi = -1.f;
+        for (int q = 0; q < a.nq; ++q) {
+            const QueryStats s = qs[b * a.nq + q];
+            const float iou = SM_DIV((float)s.inter, SM_ADD((float)s.uni, 1e-7f));
+            if (write_ious && a.ious) a.ious[b * a.nq + q] = iou;
+            if (iou > bi) { bi = iou; best = q; }
+        }
     }
+    return best;
 }
 
 // fp32 ratios exactly as torch evaluates them (int64 counts -> float32, python scalars -> float32, no fma)
@@ -131,82 +170,141 @@ __device__ float object_score(double n, double s, double ss) {
     return 2.0f * x / (x * x + 1.0f + sigma + 1e-20f);
 }
 
-__global__ __launch_bounds__(256) void eval_metrics_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs) {
+// K2: sum of the selected mask's probabilities per chunk (needed for the adaptive threshold 2*mean before K3)
+__global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, const QueryStats* qs, double* part,
+                                                              int nchunk) {
+    __shared__ double red[EV_THREADS / 64];
+    __shared__ int sel_q;
+    const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x;
+    const sm_eval_image im = a.images[b];
+    const int npx = im.H * im.W, base = c * EV_CHUNK;
+    double* slot = part + ((int64_t)(b * 2 + which) * nchunk + c) * EV_NACC;
+    if (base >= npx) { if (threadIdx.x == 0) slot[0] = 0.0; return; }
+    if (threadIdx.x == 0) sel_q = select_query(a, qs, b, which, c == 0);
+    __syncthreads();
+    const float* __restrict__ m = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)sel_q * a.mh * a.mw;
+    const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
+    const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
+    const float inv_w = 1.0f / (float)im.W;
+    double sp = 0.0;
+    for (int k = 0; k < EV_PPT; ++k) {
+        const int idx = base + k * EV_THREADS + threadIdx.x;
+        if (idx >= npx) break;
+        int y, x;
+        split_idx(idx, im.W, inv_w, y, x);
+        sp += (double)up_sample(m, a.mw, up_index(y, sy, a.mh), up_index(x, sx, a.mw));
+    }
+    sp = wave_total(sp);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sp;
+    __syncthreads();
+    if (threadIdx.x == 0) slot[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+struct MetricCounts { unsigned tp5, np5, ng, eq5, tpa, npa; unsigned hist[2][256]; };
+
+// K3: everything else in one pass per chunk.  Integer counts and the 2x256-bin histogram use integer atomics;
+// the fp64 moments are written as per-chunk partials and summed in a fixed order by K4 (bit-reproducible).
+__global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs,
+                                                                  double* part, MetricCounts* cnt, int nchunk) {
     __shared__ unsigned hist[2][256];
     __shared__ float thr[256];
-    __shared__ double redd[4];
-    __shared__ unsigned redu[4];
+    __shared__ double red[EV_THREADS / 64][EV_NACC];
     __shared__ int sel_q;
-    const int which = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float s_thr_adapt;
+    const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
-    const int npx = im.H * im.W;
-
-    // ---- selection (evaluator.pyc@L216-221): upper bound = arg-max IoU, pick = arg-max objectness (first max) -------
+    const int npx = im.H * im.W, base = c * EV_CHUNK;
+    double* slot = part + ((int64_t)(b * 2 + which) * nchunk + c) * EV_NACC;
+    if (base >= npx) {
+        if (tid < EV_NACC && tid > 0) slot[tid] = 0.0;
+        return;
+    }
     if (tid == 0) {
-        int best = 0;
-        if (which == 0) {
-            const float* o = a.objectness + (int64_t)b * a.obj_stride_b;
-            for (int q = 1; q < a.nq; ++q) if (o[q] > o[best]) best = q;
-        } else {
-            float bi = -1.f;
-            for (int q = 0; q < a.nq; ++q) {
-                const QueryStats s = qs[b * a.nq + q];
-                const float iou = SM_DIV((float)s.inter, SM_ADD((float)s.uni, 1e-7f));
-                if (a.ious) a.ious[b * a.nq + q] = iou;
-                if (iou > bi) { bi = iou; best = q; }
-            }
-        }
-        sel_q = best;
+        sel_q = select_query(a, qs, b, which, false);
+        double sp = 0.0;  // fixed-order sum of the per-chunk partials of K2
+        const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
+        for (int k = 0; k < nchunk; ++k) sp += p0[(int64_t)k * EV_NACC];
+        s_thr_adapt = SM_MUL(2.0f, (float)(sp / (double)npx));  // f_measure.py:76
     }
     hist[0][tid] = 0; hist[1][tid] = 0;
     thr[tid] = tid < 255 ? a.thresholds[tid] : INFINITY;
     __syncthreads();
-    const int q = sel_q;
-    const float* __restrict__ m = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)q * a.mh * a.mw;
+    const float* __restrict__ m = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)sel_q * a.mh * a.mw;
     const unsigned char* __restrict__ gt = a.gt + im.gt_off;
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
-    const float mean_p = (float)(qs[b * a.nq + q].sum_p / (double)npx);
-    const float thr_adapt = SM_MUL(2.0f, mean_p);  // f_measure.py:76 (2 * mean; the mean itself is fp64-summed here)
+    const float inv_w = 1.0f / (float)im.W;
+    const float thr_adapt = s_thr_adapt;
     const GtStats g0 = gs[b];
-    // centroid (s_measure.py:13-31): round-half-even of the fp32 quotient; gt all-zero takes the early exit below
-    const int X = (int)rintf((float)g0.sum_gx / (float)g0.sum_g), Y = (int)rintf((float)g0.sum_gy / (float)g0.sum_g);
+    // centroid (s_measure.py:13-31): round-half-even of the fp32 quotient of exact integer sums
+    const int X = (int)rintf(SM_DIV((float)g0.sum_gx, (float)g0.sum_g)), Y = (int)rintf(SM_DIV((float)g0.sum_gy, (float)g0.sum_g));
 
     unsigned tp5 = 0, np5 = 0, ng = 0, eq5 = 0, tpa = 0, npa = 0;
-    double sabs = 0.0;
-    double qp[4] = {0, 0, 0, 0}, qg[4] = {0, 0, 0, 0}, qpp[4] = {0, 0, 0, 0}, qpg[4] = {0, 0, 0, 0};
-    double f_s = 0.0, f_ss = 0.0, b_s = 0.0, b_ss = 0.0;
-    for (int idx = tid; idx < npx; idx += 256) {
-        const int y = idx / im.W, x = idx - y * im.W;
+    double acc[EV_NACC];
+#pragma unroll
+    for (int k = 0; k < EV_NACC; ++k) acc[k] = 0.0;
+    // acc: 1 = sum|p-g|; 2+4k.. = quadrant k {sum p, sum g, sum p^2, sum p g}; 18,19 = fg {sum p, sum p^2};
+    //      20,21 = bg {sum (1-p), sum (1-p)^2}
+    for (int k = 0; k < EV_PPT; ++k) {
+        const int idx = base + k * EV_THREADS + tid;
+        if (idx >= npx) break;
+        int y, x;
+        split_idx(idx, im.W, inv_w, y, x);
         const float p = up_sample(m, a.mw, up_index(y, sy, a.mh), up_index(x, sx, a.mw));
         const unsigned g = gt[idx] != 0, b5 = p > 0.5f, ba = p > thr_adapt;
         tp5 += b5 & g; np5 += b5; ng += g; eq5 += (b5 == g); tpa += ba & g; npa += ba;
         const float gf = (float)g;
-        sabs += (double)fabsf(p - gf);
-        // number of thresholds strictly below p (binary search over the 255 ascending values; thr[255] = +inf)
-        int lo = 0, hi = 255;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (thr[mid] < p) lo = mid + 1; else hi = mid; }
+        acc[1] += (double)fabsf(p - gf);
+        // number of thresholds strictly below p: start from floor(p*255) and correct (the table is ascending, ~k/255)
+        int lo = (int)(p * 255.0f);
+        lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+        while (lo > 0 && !(thr[lo - 1] < p)) --lo;
+        while (lo < 255 && thr[lo] < p) ++lo;
         atomicAdd(&hist[g][lo], 1u);
-        const double pd = (double)p;
+        const double pd = (double)p, gd = (double)gf;
         const int quad = (y >= Y ? 2 : 0) + (x >= X ? 1 : 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (quad == k) { qp[k] += pd; qg[k] += (double)gf; qpp[k] += pd * pd; qpg[k] += pd * (double)gf; }
+        for (int qd = 0; qd < 4; ++qd) {
+            if (quad == qd) { acc[2 + 4 * qd] += pd; acc[3 + 4 * qd] += gd; acc[4 + 4 * qd] += pd * pd; acc[5 + 4 * qd] += pd * gd; }
         }
-        if (g) { f_s += pd; f_ss += pd * pd; } else { const double o = (double)(1.0f - p); b_s += o; b_ss += o * o; }
+        if (g) { acc[18] += pd; acc[19] += pd * pd; } else { const double o = (double)(1.0f - p); acc[20] += o; acc[21] += o * o; }
     }
-    tp5 = block_sum<unsigned>(tp5, redu); np5 = block_sum<unsigned>(np5, redu); ng = block_sum<unsigned>(ng, redu);
-    eq5 = block_sum<unsigned>(eq5, redu); tpa = block_sum<unsigned>(tpa, redu); npa = block_sum<unsigned>(npa, redu);
-    sabs = block_sum<double>(sabs, redd);
+    const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        qp[k] = block_sum<double>(qp[k], redd); qg[k] = block_sum<double>(qg[k], redd);
-        qpp[k] = block_sum<double>(qpp[k], redd); qpg[k] = block_sum<double>(qpg[k], redd);
+    for (int k = 1; k < EV_NACC; ++k) {
+        const double v = wave_total(acc[k]);
+        if (lane == 0) red[wv][k] = v;
     }
-    f_s = block_sum<double>(f_s, redd); f_ss = block_sum<double>(f_ss, redd);
-    b_s = block_sum<double>(b_s, redd); b_ss = block_sum<double>(b_ss, redd);
+    tp5 = wave_total(tp5); np5 = wave_total(np5); ng = wave_total(ng); eq5 = wave_total(eq5);
+    tpa = wave_total(tpa); npa = wave_total(npa);
+    MetricCounts* mc = cnt + (b * 2 + which);
+    if (lane == 0) {
+        atomicAdd(&mc->tp5, tp5); atomicAdd(&mc->np5, np5); atomicAdd(&mc->ng, ng); atomicAdd(&mc->eq5, eq5);
+        atomicAdd(&mc->tpa, tpa); atomicAdd(&mc->npa, npa);
+    }
     __syncthreads();
-    if (tid != 0) return;
+    if (tid > 0 && tid < EV_NACC) slot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (hist[0][tid]) atomicAdd(&mc->hist[0][tid], hist[0][tid]);
+    if (hist[1][tid]) atomicAdd(&mc->hist[1][tid], hist[1][tid]);
+}
+
+// K4: finalise the 7 metrics of (image, which) with the reference's fp32 operation order
+__global__ __launch_bounds__(64) void eval_finalize_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs,
+                                                           const double* part, const MetricCounts* cnt, int nchunk) {
+    const int which = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x != 0) return;
+    const sm_eval_image im = a.images[b];
+    const int npx = im.H * im.W;
+    const MetricCounts& mc = cnt[b * 2 + which];
+    double acc[EV_NACC];
+    for (int k = 0; k < EV_NACC; ++k) acc[k] = 0.0;
+    const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
+    for (int c = 0; c < nchunk; ++c)
+        for (int k = 0; k < EV_NACC; ++k) acc[k] += p0[(int64_t)c * EV_NACC + k];
+    const unsigned tp5 = mc.tp5, np5 = mc.np5, ng = mc.ng, eq5 = mc.eq5, tpa = mc.tpa, npa = mc.npa;
+    const GtStats g0 = gs[b];
+    const int X = (int)rintf(SM_DIV((float)g0.sum_gx, (float)g0.sum_g)), Y = (int)rintf(SM_DIV((float)g0.sum_gy, (float)g0.sum_g));
+    const int q = select_query(a, qs, b, which, false);
 
     float* row = a.rows + (int64_t)b * 16 + which * 7;
     const float N = (float)npx;
@@ -217,16 +315,16 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(sm_eval_args a, const
         unsigned tp = 0, np = 0;
         float best = -INFINITY;
         for (int k = 254; k >= 0; --k) {
-            tp += hist[1][k + 1]; np += hist[0][k + 1] + hist[1][k + 1];
+            tp += mc.hist[1][k + 1]; np += mc.hist[0][k + 1] + mc.hist[1][k + 1];
             best = fmaxf(best, f_measure_from_counts(tp, np, ng));
         }
         row[3] = best;
     }
     row[4] = f_measure_from_counts(tpa, npa, ng);                                  // f_measure.py:71-81
-    row[5] = (float)(sabs / (double)npx);                                          // mae.py:9
+    row[5] = (float)(acc[1] / (double)npx);                                        // mae.py:9
     {   // S-measure (s_measure.py:105-124)
         const double n1 = (double)ng, n0 = (double)npx - (double)ng;
-        const double sum_p = qp[0] + qp[1] + qp[2] + qp[3];
+        const double sum_p = acc[2] + acc[6] + acc[10] + acc[14];
         float Q;
         if (ng == 0) {
             Q = 1.0f - (float)(sum_p / (double)npx);
@@ -234,16 +332,16 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(sm_eval_args a, const
             Q = (float)(sum_p / (double)npx);
         } else {
             const float u = SM_DIV((float)ng, N);
-            const float s_obj = u * object_score(n1, f_s, f_ss) + (1.0f - u) * object_score(n0, b_s, b_ss);
+            const float s_obj = u * object_score(n1, acc[18], acc[19]) + (1.0f - u) * object_score(n0, acc[20], acc[21]);
             const float area = (float)npx, Xf = (float)X, Yf = (float)Y;
             const float w1 = Xf * Yf / area, w2 = ((float)im.W - Xf) * Yf / area, w3 = Xf * ((float)im.H - Yf) / area;
             const float w4 = 1.0f - w1 - w2 - w3;
             const double nLT = (double)X * Y, nRT = (double)(im.W - X) * Y, nLB = (double)X * (im.H - Y),
                          nRB = (double)(im.W - X) * (im.H - Y);
-            const float s_reg = w1 * ssim_quadrant(nLT, qp[0], qg[0], qpp[0], qpg[0]) +
-                                w2 * ssim_quadrant(nRT, qp[1], qg[1], qpp[1], qpg[1]) +
-                                w3 * ssim_quadrant(nLB, qp[2], qg[2], qpp[2], qpg[2]) +
-                                w4 * ssim_quadrant(nRB, qp[3], qg[3], qpp[3], qpg[3]);
+            const float s_reg = w1 * ssim_quadrant(nLT, acc[2], acc[3], acc[4], acc[5]) +
+                                w2 * ssim_quadrant(nRT, acc[6], acc[7], acc[8], acc[9]) +
+                                w3 * ssim_quadrant(nLB, acc[10], acc[11], acc[12], acc[13]) +
+                                w4 * ssim_quadrant(nRB, acc[14], acc[15], acc[16], acc[17]);
             Q = 0.5f * s_obj + 0.5f * s_reg;
             if (Q < 0.f) Q = 0.f;
         }
@@ -252,25 +350,52 @@ __global__ __launch_bounds__(256) void eval_metrics_kernel(sm_eval_args a, const
     a.rows[(int64_t)b * 16 + 14 + which] = (float)q;
 }
 
+struct EvalWs { QueryStats* qs; GtStats* gs; MetricCounts* cnt; double* part; size_t zero_bytes, total; };
+
+static EvalWs carve_eval(int B, int nq, int nchunk, char* base) {
+    EvalWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
+    // the first three regions are accumulated with atomics: zeroed by ONE memset node ahead of the launches
+    w.qs = (QueryStats*)take((size_t)B * nq * sizeof(QueryStats));
+    w.gs = (GtStats*)take((size_t)B * sizeof(GtStats));
+    w.cnt = (MetricCounts*)take((size_t)B * 2 * sizeof(MetricCounts));
+    w.zero_bytes = off;
+    w.part = (double*)take((size_t)B * 2 * nchunk * EV_NACC * sizeof(double));
+    w.total = off;
+    return w;
+}
+
 }  // namespace sm
 
+// workspace is sized for the largest supported ground truth (1024 x 1024 pixels per image)
+static const int SM_EVAL_MAX_PIXELS = 1 << 20;
+
 extern "C" size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq) {
-    if (B <= 0 || nq <= 0) return 0;
-    return (size_t)B * nq * sizeof(sm::QueryStats) + (size_t)B * sizeof(sm::GtStats) + 256;
+    if (B <= 0 || nq <= 0 || nq > sm::EV_MAXQ) return 0;
+    return sm::carve_eval(B, nq, SM_EVAL_MAX_PIXELS / sm::EV_CHUNK, nullptr).total;
 }
 
 extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
     SM_REQUIRE(a && a->mask_pred && a->objectness && a->gt && a->images && a->thresholds && a->rows && a->workspace,
                "sm_evaluate_masks_f32: null pointer");
-    SM_REQUIRE(a->B > 0 && a->nq > 0 && a->mh > 0 && a->mw > 0 && a->scale >= 0.f, "sm_evaluate_masks_f32: bad shape");
-    SM_REQUIRE(a->workspace_bytes >= sm_evaluate_workspace_bytes(a->B, a->nq) && ((uintptr_t)a->workspace % 16) == 0,
+    SM_REQUIRE(a->B > 0 && a->nq > 0 && a->nq <= sm::EV_MAXQ && a->mh > 0 && a->mw > 0 && a->scale >= 0.f,
+               "sm_evaluate_masks_f32: bad shape (nq <= %d)", sm::EV_MAXQ);
+    SM_REQUIRE(a->max_pixels > 0 && a->max_pixels <= SM_EVAL_MAX_PIXELS,
+               "sm_evaluate_masks_f32: max_pixels=%d (largest H*W of the batch, <= %d)", a->max_pixels, SM_EVAL_MAX_PIXELS);
+    SM_REQUIRE(a->workspace_bytes >= sm_evaluate_workspace_bytes(a->B, a->nq) && ((uintptr_t)a->workspace % 256) == 0,
                "sm_evaluate_masks_f32: workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;
-    sm::QueryStats* qs = (sm::QueryStats*)a->workspace;
-    sm::GtStats* gs = (sm::GtStats*)(qs + (size_t)a->B * a->nq);
-    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(a->nq, a->B), dim3(256), 0, st, *a, qs, gs);
-    int rc = sm::check_launch("sm_evaluate_masks_f32/query");
-    if (rc) return rc;
-    hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(2, a->B), dim3(256), 0, st, *a, qs, gs);
-    return sm::check_launch("sm_evaluate_masks_f32/metrics");
+    const int nchunk = (a->max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK;
+    const sm::EvalWs w = sm::carve_eval(a->B, a->nq, SM_EVAL_MAX_PIXELS / sm::EV_CHUNK, (char*)a->workspace);
+    if (hipMemsetAsync(a->workspace, 0, w.zero_bytes, st) != hipSuccess) {
+        sm::set_error("sm_evaluate_masks_f32: hipMemsetAsync failed");
+        return SM_ELAUNCH;
+    }
+    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.gs);
+    hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.part, nchunk);
+    hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.gs, w.part,
+                       w.cnt, nchunk);
+    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.qs, w.gs, w.part, w.cnt, nchunk);
+    return sm::check_launch("sm_evaluate_masks_f32");
 }

@@ -79,7 +79,7 @@ class EvalArgs(C.Structure):
     _fields_ = [("mask_pred", fp), ("mask_stride_b", C.c_int64), ("objectness", fp), ("obj_stride_b", C.c_int64),
                 ("gt", fp), ("images", fp), ("thresholds", fp), ("rows", fp), ("ious", fp), ("workspace", fp),
                 ("workspace_bytes", C.c_size_t), ("B", C.c_int32), ("nq", C.c_int32), ("mh", C.c_int32),
-                ("mw", C.c_int32), ("scale", C.c_float)]
+                ("mw", C.c_int32), ("max_pixels", C.c_int32), ("scale", C.c_float)]
 
 
 class BilateralArgs(C.Structure):

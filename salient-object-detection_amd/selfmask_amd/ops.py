@@ -205,5 +205,6 @@ def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, 
     a.gt, a.images, a.thresholds = gb.gt_all.data_ptr(), gb.images.data_ptr(), f_max_thresholds(dev).data_ptr()
     a.rows, a.ious, a.workspace, a.workspace_bytes = rows.data_ptr(), _ptr(ious), ws.data_ptr(), wsb
     a.B, a.nq, a.mh, a.mw, a.scale = B, nq, mh, mw, float(scale)
+    a.max_pixels = max(h * w for (h, w) in gb.shapes)
     N.check(lib.sm_evaluate_masks_f32(a, _stream()), "sm_evaluate_masks_f32")
     return (rows, ious) if return_ious else rows
