@@ -41,21 +41,22 @@ def forward_flops_per_image(P, S, L=6, nq=20):
 
 
 def forward_gemm_launches(B, P, S, L=6, nq=20):
-    """Every sm_gemm_f32 launch of one MaskFormer.forward: (name, M, N, K, epilogue, batch, launches per forward)."""
+    """Every sm_gemm_f32 launch of one MaskFormer.forward:
+    (name, M, N, K, epilogue, batch, launches per forward, split_k)."""
     from selfmask_amd import _native as Nn
     g = S // P
     n, N = g * g, g * g + 1
     M, Mp, Md, Mo = B * N, B * n, B * nq, B * nq * L
     return [
-        ("patch_embed", Mp, 384, 3 * P * P, Nn.EPI_BIAS, 1, 1),
-        ("enc.qkv", M, 1152, 384, Nn.EPI_BIAS, 1, 12), ("enc.proj", M, 384, 384, Nn.EPI_RESIDUAL, 1, 12),
-        ("enc.fc1", M, 1536, 384, Nn.EPI_GELU, 1, 12), ("enc.fc2", M, 384, 1536, Nn.EPI_RESIDUAL, 1, 12),
-        ("dec.sa_qk", Md, 768, 384, Nn.EPI_BIAS, 1, L), ("dec.sa_v", Md, 384, 384, Nn.EPI_BIAS, 1, L),
-        ("dec.sa_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L), ("dec.ca_q", Md, 384, 384, Nn.EPI_BIAS, 1, L),
-        ("dec.ca_kv", Mp, 768, 384, Nn.EPI_BIAS, 1, L), ("dec.ca_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L),
-        ("dec.lin1", Md, 1536, 384, Nn.EPI_RELU, 1, L), ("dec.lin2", Md, 384, 1536, Nn.EPI_RESIDUAL, 1, L),
-        ("mask_einsum", L * nq, 4 * n, 384, Nn.EPI_BIAS, B, 1),
-        ("obj.ffn0", Mo, 384, 384, Nn.EPI_RELU, 1, 1), ("obj.ffn1", Mo, 384, 384, Nn.EPI_RELU, 1, 1),
+        ("patch_embed", Mp, 384, 3 * P * P, Nn.EPI_BIAS, 1, 1, 1),
+        ("enc.qkv", M, 1152, 384, Nn.EPI_BIAS, 1, 12, 1), ("enc.proj", M, 384, 384, Nn.EPI_RESIDUAL, 1, 12, 1),
+        ("enc.fc1", M, 1536, 384, Nn.EPI_GELU, 1, 12, 1), ("enc.fc2", M, 384, 1536, Nn.EPI_RESIDUAL, 1, 12, 1),
+        ("dec.ca_kv_all_layers", Mp, L * 768, 384, Nn.EPI_BIAS, 1, 1, 1),
+        ("dec.sa_qkv", Md, 1152, 384, Nn.EPI_BIAS, 1, L, 1), ("dec.sa_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1),
+        ("dec.ca_q", Md, 384, 384, Nn.EPI_BIAS, 1, L, 1), ("dec.ca_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1),
+        ("dec.lin1", Md, 1536, 384, Nn.EPI_RELU, 1, L, 1), ("dec.lin2_splitk4", Md, 384, 1536, Nn.EPI_BIAS, 1, L, 4),
+        ("mask_einsum", L * nq, 4 * n, 384, Nn.EPI_BIAS, B, 1, 1),
+        ("obj.ffn0", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1), ("obj.ffn1", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1),
     ]
 
 
@@ -68,23 +69,23 @@ def time_gemm_kernels(B, P, S, iters=3):
     lib = Nn.load()
     dev = "cuda"
     groups = {}
-    for name, M, N, K, epi, batch, cnt in forward_gemm_launches(B, P, S):
+    for name, M, N, K, epi, batch, cnt, split in forward_gemm_launches(B, P, S):
         ga = Nn.GemmArgs()
-        ga.M, ga.N, ga.K, ga.batch = M, N, K, batch
+        ga.M, ga.N, ga.K, ga.batch, ga.split_k = M, N, K, batch, split
         bm, bn = ctypes.c_int(), ctypes.c_int()
         Nn.check(lib.sm_gemm_f32_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn)))
         a = torch.randn(batch, M, K, device=dev)
         w = torch.randn(batch, N, K, device=dev) * 0.03
-        bias = torch.zeros(N, device=dev)
-        c = torch.empty(batch, M, N, device=dev)
+        bias = torch.zeros(N, device=dev) if split == 1 else None
+        c = torch.empty(max(batch, split), M, N, device=dev)
         r = torch.randn(batch, M, N, device=dev) if epi == Nn.EPI_RESIDUAL else None
-        groups.setdefault((bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch))
+        groups.setdefault((bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch, split))
     out = {}
     for (bm, bn), items in groups.items():
         def run_mix():
-            for name, a, w, bias, c, r, epi, cnt, fl in items:
+            for name, a, w, bias, c, r, epi, cnt, fl, split in items:
                 for _ in range(cnt):
-                    ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn))
+                    ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn), split_k=split)
         run_mix()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()

@@ -55,14 +55,18 @@ typedef struct sm_gemm_args {
     float* C;            /* [batch][M][ldc]                                                                      */
     const float* R;      /* residual [batch][M][ldr] (SM_EPI_RESIDUAL; may alias C) or pos_embed (SM_EPI_PATCH)  */
     float* C2;           /* second output (SM_EPI_SIGMOID2) or NULL                                              */
-    const float* A_add;  /* reserved, must be NULL (the "tgt + query_pos" add lives in sm_layernorm_rows_f32)     */
+    const float* A_alt;  /* optional second A operand (same M, K, lda): output columns n >= alt_from_n use it.
+                            Lets one launch compute [q|k] = (tgt+qpos) W_qk^T and v = tgt W_v^T of the decoder
+                            self-attention (transformer_decoder.py:271-276)                                        */
     int64_t strideA, strideW, strideC, strideR; /* batch strides in elements (0 = shared)                        */
     int32_t M, N, K;     /* any M, N >= 1; K % 32 == 0                                                           */
     int32_t lda, ldw, ldc, ldr;
     int32_t batch;       /* >= 1                                                                                 */
     int32_t epilogue;    /* SM_EPI_*                                                                             */
-    int32_t a_add_rows;  /* reserved, must be 0                                                                  */
-    int32_t lda2;
+    int32_t alt_from_n;  /* multiple of 128 (0 = A_alt unused)                                                   */
+    int32_t split_k;     /* 0/1 = off; S > 1: blockIdx.z = K-slice, slice s writes its raw partial products to
+                            C + s*strideC (batch must be 1, epilogue SM_EPI_BIAS with bias == NULL, K/32 % S == 0);
+                            the consumer sums the slices in a fixed order (sm_layernorm_rows_f32 partials)          */
     int32_t patch_n;     /* SM_EPI_PATCH: patches per image n                                                    */
 } sm_gemm_args;
 
@@ -88,13 +92,19 @@ int sm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const floa
  * that writes tgt, so the following projection GEMM reads it with plain LDS-DMA. */
 typedef struct sm_row_map { int32_t group, stride, offset; } sm_row_map;
 typedef struct sm_ln_args {
-    const float* x;  int64_t ldx;  sm_row_map in_map;
+    const float* x;  int64_t ldx;  sm_row_map in_map;   /* with n_partials > 0: slice 0 of a split-K GEMM output    */
     const float *gamma, *beta;
     float* y;        int64_t ldy;  sm_row_map out_map;
     float* y2;       int64_t ldy2;          /* NULL = none; indexed by the logical row r */
     const float* add; int32_t add_rows;      /* (add_rows,384), row stride 384 */
     int32_t rows;
     float eps;
+    /* optional split-K reduction fused in front of the normalisation (decoder linear2, K = 1536):
+     * value = (sum_{s < n_partials} x[s*partial_stride + row]) + pre_bias + residual[row], summed in slice order */
+    int32_t n_partials;          /* 0 = off */
+    int64_t partial_stride;      /* elements between slices */
+    const float* pre_bias;       /* (384) */
+    const float* residual;       /* (rows,384), row stride ldx */
 } sm_ln_args;
 int sm_layernorm_rows_f32(const sm_ln_args* args, void* stream);
 
@@ -214,6 +224,9 @@ typedef struct sm_weights {
     sm_dec_layer dec[SM_MAX_DEC_LAYERS];
     const float *dec_norm_w, *dec_norm_b;
     const float *ffn0_w, *ffn0_b, *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b; /* objectness MLP 384->384->384->1 */
+    const float* dec_kv_w; /* packed by the host from the state_dict: rows [384:1152) of every decoder layer's      */
+    const float* dec_kv_b; /*   multihead_attn.in_proj_{weight,bias}, concatenated -> (L*768, 384) / (L*768): the   */
+                           /*   cross-attention K/V of ALL layers is one GEMM over the encoder memory               */
     int32_t patch;         /* 8 or 16 */
     int32_t pos_grid;      /* g0: trained grid side (224/patch) */
     int32_t n_queries;

@@ -21,7 +21,7 @@ static Shape make_shape(const sm_weights* w, int B, int H, int W) {
 
 // workspace carve-up (floats, every region 256-B aligned)
 struct Ws {
-    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *KV, *UP, *TGT, *TGTQ, *T2, *QK, *Vd, *Qc, *AOd, *HIDd, *QD, *LOG, *O1, *O2;
+    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *KV, *UP, *TGT, *TGTQ, *T2, *QK, *Vd, *Qc, *AOd, *HIDd, *PART, *QD, *LOG, *O1, *O2;
     size_t total;
 };
 
@@ -43,7 +43,7 @@ static Ws carve(const Shape& s, float* base) {
     size_t hid = s.M * SM_MLP, cols = (size_t)s.Mp * 3 * s.P * s.P;
     w.HID = take(hid > cols ? hid : cols);
     w.TOK = take(s.Mp * D);
-    w.KV = take(s.Mp * 2 * D);
+    w.KV = take(s.Mp * 2 * D * s.L);   // cross-attention K|V of ALL decoder layers: (B*n, L*768)
     w.UP = take(s.Mp * 4 * D);
     w.TGT = take(s.Md * D);
     w.TGTQ = take(s.Md * D);
@@ -53,6 +53,7 @@ static Ws carve(const Shape& s, float* base) {
     w.Qc = take(s.Md * D);
     w.AOd = take(s.Md * D);
     w.HIDd = take(s.Md * SM_MLP);
+    w.PART = take(s.Md * D * 4);        // split-K partials of linear2
     w.QD = take(s.Mo * D);
     w.LOG = take(s.Mo * 4 * s.n);
     w.O1 = take(s.Mo * D);
@@ -72,11 +73,13 @@ static int linear(const float* A, int lda, const float* W, const float* b, float
 
 static int ln(const float* x, const float* gw, const float* gb, float* y, int64_t rows, float eps, hipStream_t st,
               sm_row_map in_map = {0, 0, 0}, sm_row_map out_map = {0, 0, 0}, float* y2 = nullptr,
-              const float* add = nullptr, int add_rows = 0) {
+              const float* add = nullptr, int add_rows = 0, int n_partials = 0, int64_t partial_stride = 0,
+              const float* pre_bias = nullptr, const float* residual = nullptr) {
     sm_ln_args a = {};
     a.x = x; a.ldx = SM_EMBED; a.in_map = in_map; a.gamma = gw; a.beta = gb; a.y = y; a.ldy = SM_EMBED;
     a.out_map = out_map; a.y2 = y2; a.ldy2 = SM_EMBED; a.add = add; a.add_rows = add_rows;
     a.rows = (int)rows; a.eps = eps;
+    a.n_partials = n_partials; a.partial_stride = partial_stride; a.pre_bias = pre_bias; a.residual = residual;
     return sm_layernorm_rows_f32(&a, st);
 }
 
@@ -88,7 +91,7 @@ static int ln(const float* x, const float* gw, const float* gb, float* y, int64_
 
 static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, hipStream_t st) {
     const Shape s = make_shape(w, io->B, io->H, io->W);
-    const Ws ws = carve(s, wsbase);
+    Ws ws = carve(s, wsbase);
     const int D = SM_EMBED;
     const sm_row_map id = {0, 0, 0};
 
@@ -142,34 +145,48 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     }
     const float* qpos = w->query_embed;
     TRY(sm_broadcast_rows_f32(qpos, ws.TGTQ, s.nq, s.B, st));  // tgt + query_pos with tgt = 0
+    // cross-attention keys/values of every layer depend only on the encoder memory: one large GEMM
+    // (B*n x 384) x (384 x L*768) instead of L small ones on the critical chain
+    const int KVW = s.L * 2 * D;
+    TRY(linear(tok, D, w->dec_kv_w, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0, st));
     for (int l = 0; l < s.L; ++l) {
         const sm_dec_layer& d = w->dec[l];
-        // self-attention: q = k = tgt + query_pos, v = tgt
-        TRY(linear(ws.TGTQ, D, d.sa_in_w, d.sa_in_b, ws.QK, 2 * D, s.Md, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st));
-        TRY(linear(ws.TGT, D, d.sa_in_w + 2 * D * D, d.sa_in_b + 2 * D, ws.Vd, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st));
+        // self-attention: q = k = tgt + query_pos, v = tgt  ->  ONE launch: columns [0,768) read TGTQ, [768,1152) TGT
+        {
+            sm_gemm_args g = {};
+            g.A = ws.TGTQ; g.A_alt = ws.TGT; g.alt_from_n = 2 * D; g.W = d.sa_in_w; g.bias = d.sa_in_b; g.C = ws.QK;
+            g.M = (int)s.Md; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * D; g.batch = 1; g.epilogue = SM_EPI_BIAS;
+            TRY(sm_gemm_f32(&g, st));
+        }
         sm_attn_args a = {};
-        a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.Vd; a.O = ws.AOd;
-        a.sQb = a.sKb = (int64_t)s.nq * 2 * D; a.sQr = a.sKr = 2 * D;
-        a.sVb = (int64_t)s.nq * D; a.sVr = D; a.sOb = (int64_t)s.nq * D; a.sOr = D;
+        a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.QK + 2 * D; a.O = ws.AOd;
+        a.sQb = a.sKb = a.sVb = (int64_t)s.nq * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
+        a.sOb = (int64_t)s.nq * D; a.sOr = D;
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
         TRY(sm_attention_f32(&a, st));
         TRY(linear(ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
         TRY(ln(ws.T2, d.norm1_w, d.norm1_b, ws.TGT, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq));
         // cross-attention: q = tgt + query_pos, k = v = memory (pos = None)
         TRY(linear(ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st));
-        TRY(linear(tok, D, d.ca_in_w + D * D, d.ca_in_b + D, ws.KV, 2 * D, s.Mp, 2 * D, D, SM_EPI_BIAS, nullptr, 0, st));
         a = {};
-        a.Q = ws.Qc; a.K = ws.KV; a.V = ws.KV + D; a.O = ws.AOd;
-        a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * 2 * D; a.sKr = a.sVr = 2 * D;
+        a.Q = ws.Qc; a.K = ws.KV + (int64_t)l * 2 * D; a.V = a.K + D; a.O = ws.AOd;
+        a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * KVW; a.sKr = a.sVr = KVW;
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
         TRY(sm_attention_f32(&a, st));
         TRY(linear(ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
         TRY(ln(ws.T2, d.norm2_w, d.norm2_b, ws.TGT, s.Md, 1e-5f, st));
-        // FFN
+        // FFN: linear2 (K = 1536, only M/64 x 6 tiles) is split 4-way along K; norm3 sums the slices + bias + residual
         TRY(linear(ws.TGT, D, d.lin1_w, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, st));
-        TRY(linear(ws.HIDd, SM_MLP, d.lin2_w, d.lin2_b, ws.T2, D, s.Md, D, SM_MLP, SM_EPI_RESIDUAL, ws.TGT, D, st));
-        TRY(ln(ws.T2, d.norm3_w, d.norm3_b, ws.TGT, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq));
+        {
+            sm_gemm_args g = {};
+            g.A = ws.HIDd; g.W = d.lin2_w; g.C = ws.PART; g.M = (int)s.Md; g.N = D; g.K = SM_MLP; g.lda = SM_MLP;
+            g.ldw = SM_MLP; g.ldc = D; g.batch = 1; g.epilogue = SM_EPI_BIAS; g.split_k = 4; g.strideC = s.Md * D;
+            TRY(sm_gemm_f32(&g, st));
+        }
+        TRY(ln(ws.PART, d.norm3_w, d.norm3_b, ws.T2, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq, 4, s.Md * D, d.lin2_b,
+               ws.TGT));
+        { float* t = ws.TGT; ws.TGT = ws.T2; ws.T2 = t; }  // norm3 wrote the new tgt
         // shared final norm on every layer's output, scattered into (B, L, nq, 384)
         const sm_row_map stack = {s.nq, s.L * s.nq, l * s.nq};
         TRY(ln(ws.TGT, w->dec_norm_w, w->dec_norm_b, QD, s.Md, 1e-5f, st, id, stack));
@@ -199,6 +216,7 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
     SM_REQUIRE(w->n_dec_layers >= 1 && w->n_dec_layers <= SM_MAX_DEC_LAYERS, "sm_maskformer_forward: n_dec_layers=%d",
                w->n_dec_layers);
     SM_REQUIRE(w->n_queries >= 1 && w->pos_grid >= 1, "sm_maskformer_forward: bad n_queries/pos_grid");
+    SM_REQUIRE(w->dec_kv_w && w->dec_kv_b, "sm_maskformer_forward: dec_kv_w/dec_kv_b (packed cross-attention K/V) missing");
     SM_REQUIRE(io->x && io->B > 0 && io->H > 0 && io->W > 0, "sm_maskformer_forward: bad input shape");
     if (!io->encoder_only)
         SM_REQUIRE(io->mask_pred && io->objectness && io->features, "sm_maskformer_forward: null output");

@@ -76,11 +76,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int64_t bz = blockIdx.z;
-    const float* __restrict__ A = g.A + bz * g.strideA;
-    const float* __restrict__ W = g.W + bz * g.strideW;
     const int M = g.M, N = g.N;
-    const int nk = g.K / BK;
+    // split-K: blockIdx.z is the K-slice (batch == 1); otherwise it is the batch index
+    const int split = g.split_k > 1 ? g.split_k : 1;
+    const int64_t bz = split > 1 ? 0 : (int64_t)blockIdx.z;
+    const int nk = g.K / BK / split;
+    const int k_begin = split > 1 ? (int)blockIdx.z * nk * BK : 0;
+    const float* __restrict__ A = ((g.alt_from_n > 0 && n0 >= g.alt_from_n) ? g.A_alt : g.A) + bz * g.strideA + k_begin;
+    const float* __restrict__ W = g.W + bz * g.strideW + k_begin;
 
     // ---- LDS-DMA source pointers: lane L of instruction I fills LDS row (8*(wave*INST+I) + L/8), chunk L%8 --------
     const float* a_src[A_INST];
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
             for (int v = 0; v < 16; ++v) tot[i][j][v] += acc[i][j][v];
 
     // ---- epilogue (one specialised loop per epilogue kind; the kind is kernel-uniform) ---------------------------
-    float* C = g.C + bz * g.strideC;  // may alias R (in-place residual)
+    float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : bz) * g.strideC;  // may alias R (in-place residual)
     auto run = [&](auto epi_tag) {
         constexpr int EPI = decltype(epi_tag)::value;
 #pragma unroll
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
 
 template <int BM, int BN, int NST>
 static int launch_gemm(const sm_gemm_args& g, hipStream_t st) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch);
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.split_k > 1 ? g.split_k : g.batch);
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
@@ -238,7 +241,12 @@ static int validate(const sm_gemm_args* g) {
     if (g->epilogue == SM_EPI_SIGMOID2) SM_REQUIRE(g->C2, "sm_gemm_f32: SIGMOID2 needs C2");
     if (g->epilogue == SM_EPI_PATCH)
         SM_REQUIRE(g->R && g->patch_n > 0 && g->ldr >= g->N && g->batch == 1, "sm_gemm_f32: PATCH needs R/patch_n");
-    SM_REQUIRE(g->a_add_rows == 0, "sm_gemm_f32: A_add is not supported (fold it into the producing LayerNorm)");
+    if (g->alt_from_n > 0)
+        SM_REQUIRE(g->A_alt && g->alt_from_n % 128 == 0 && ((uintptr_t)g->A_alt % 16 == 0),
+                   "sm_gemm_f32: A_alt needs a pointer and alt_from_n %% 128 == 0");
+    if (g->split_k > 1)
+        SM_REQUIRE(g->batch == 1 && g->epilogue == SM_EPI_BIAS && !g->bias && (g->K / BK) % g->split_k == 0,
+                   "sm_gemm_f32: split_k needs batch 1, no bias/epilogue and K/32 divisible by split_k");
     return SM_OK;
 }
 
@@ -268,7 +276,7 @@ extern "C" int sm_gemm_f32_pick_tile(const sm_gemm_args* g, int* bm, int* bn) {
     double best_score = -1.0;
     for (int t = 0; t < 3; ++t) {
         const double wgs = (double)((g->M + tiles[t][0] - 1) / tiles[t][0]) * ((g->N + tiles[t][1] - 1) / tiles[t][1]) *
-                           g->batch;
+                           (g->split_k > 1 ? g->split_k : g->batch);
         const double rounds = wgs / 256.0;
         const double util = rounds / (double)(long)(rounds + 0.999999);
         const double score = util * eff[t];

@@ -18,6 +18,22 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
     float2 v[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2);
+    if (a.n_partials > 0) {  // fused split-K reduction: slices in order, then bias, then the residual
+        for (int sidx = 1; sidx < a.n_partials; ++sidx) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float2 t = *reinterpret_cast<const float2*>(xr + sidx * a.partial_stride + i * 128 + lane * 2);
+                v[i].x += t.x; v[i].y += t.y;
+            }
+        }
+        const float* rr = a.residual + map_row(row, a.in_map) * a.ldx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float2 bb = *reinterpret_cast<const float2*>(a.pre_bias + i * 128 + lane * 2);
+            const float2 t = *reinterpret_cast<const float2*>(rr + i * 128 + lane * 2);
+            v[i].x = t.x + (v[i].x + bb.x); v[i].y = t.y + (v[i].y + bb.y);
+        }
+    }
     float s = (v[0].x + v[0].y) + (v[1].x + v[1].y) + (v[2].x + v[2].y);
     const float mean = wave_sum(s) * (1.0f / 384.0f);
     float q = 0.f;
@@ -62,6 +78,7 @@ extern "C" int sm_layernorm_rows_f32(const sm_ln_args* a, void* stream) {
     SM_REQUIRE(a->rows >= 0 && a->ldx >= SM_EMBED && a->ldy >= SM_EMBED && a->ldx % 2 == 0 && a->ldy % 2 == 0,
                "sm_layernorm_f32: bad rows/strides");
     SM_REQUIRE(a->in_map.group >= 0 && a->out_map.group >= 0, "sm_layernorm_f32: bad row map");
+    if (a->n_partials > 0) SM_REQUIRE(a->pre_bias && a->residual && a->partial_stride > 0, "sm_layernorm_f32: bad partials");
     if (a->y2) SM_REQUIRE(a->add && a->add_rows > 0 && a->ldy2 >= SM_EMBED && a->ldy2 % 2 == 0, "sm_layernorm_f32: bad y2/add");
     if (a->rows == 0) return SM_OK;
     hipLaunchKernelGGL(sm::layernorm384_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);

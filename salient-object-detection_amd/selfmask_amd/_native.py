@@ -15,11 +15,11 @@ fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 
 class GemmArgs(C.Structure):
-    _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("R", fp), ("C2", fp), ("A_add", fp),
+    _fields_ = [("A", fp), ("W", fp), ("bias", fp), ("C", fp), ("R", fp), ("C2", fp), ("A_alt", fp),
                 ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64), ("strideR", C.c_int64),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
-                ("batch", C.c_int32), ("epilogue", C.c_int32), ("a_add_rows", C.c_int32), ("lda2", C.c_int32),
+                ("batch", C.c_int32), ("epilogue", C.c_int32), ("alt_from_n", C.c_int32), ("split_k", C.c_int32),
                 ("patch_n", C.c_int32)]
 
 
@@ -30,7 +30,8 @@ class RowMap(C.Structure):
 class LnArgs(C.Structure):
     _fields_ = [("x", fp), ("ldx", C.c_int64), ("in_map", RowMap), ("gamma", fp), ("beta", fp),
                 ("y", fp), ("ldy", C.c_int64), ("out_map", RowMap), ("y2", fp), ("ldy2", C.c_int64),
-                ("add", fp), ("add_rows", C.c_int32), ("rows", C.c_int32), ("eps", C.c_float)]
+                ("add", fp), ("add_rows", C.c_int32), ("rows", C.c_int32), ("eps", C.c_float), ("n_partials", C.c_int32),
+                ("partial_stride", C.c_int64), ("pre_bias", fp), ("residual", fp)]
 
 
 class AttnArgs(C.Structure):
@@ -61,7 +62,7 @@ class Weights(C.Structure):
                 ("enc", EncLayer * ENC_DEPTH), ("enc_norm_w", fp), ("enc_norm_b", fp),
                 ("dec", DecLayer * MAX_DEC_LAYERS), ("dec_norm_w", fp), ("dec_norm_b", fp),
                 ("ffn0_w", fp), ("ffn0_b", fp), ("ffn1_w", fp), ("ffn1_b", fp), ("ffn2_w", fp), ("ffn2_b", fp),
-                ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
+                ("dec_kv_w", fp), ("dec_kv_b", fp), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
                 ("n_dec_layers", C.c_int32)]
 
 

@@ -146,14 +146,23 @@ class MaskFormer(nn.Module):
         self.n_queries = n_queries
         self.n_decoder_layers = n_decoder_layers
         self._table = None       # (Weights struct, key) cache
+        self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
         self._workspace = {}     # (device, B, H, W) -> uint8 tensor
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_packed())
         self.eval()
 
     # ---- weight pointer table -------------------------------------------------------------------------------
     def _apply(self, fn, *a, **kw):  # .to() / .cuda() / .float() move storage: drop cached pointers
         self._table = None
+        self._packed = None
         self._workspace = {}
         return super()._apply(fn, *a, **kw)
+
+    def refresh_packed(self):
+        """Drop the weight pointer table and the packed (derived) weights; call after editing parameters in place.
+        ``load_state_dict`` and ``.to()`` do it automatically."""
+        self._table = None
+        self._packed = None
 
     def _weights(self) -> N.Weights:
         key = (self.query_embed.data_ptr(), self.ffn.layers[2].bias.data_ptr(), self.encoder.pos_embed.data_ptr())
@@ -196,6 +205,14 @@ class MaskFormer(nn.Module):
         w.ffn0_w, w.ffn0_b = f[0].weight.data_ptr(), f[0].bias.data_ptr()
         w.ffn1_w, w.ffn1_b = f[1].weight.data_ptr(), f[1].bias.data_ptr()
         w.ffn2_w, w.ffn2_b = f[2].weight.data_ptr(), f[2].bias.data_ptr()
+        # cross-attention K/V projections of all layers packed into one (L*768, 384) weight: rows [384:1152) of each
+        # multihead_attn.in_proj_weight (transformer_decoder.py:283-289 with key = value = memory)
+        d = N.EMBED
+        self._packed = {
+            "dec_kv_w": torch.cat([lay.multihead_attn.in_proj_weight.detach()[d:] for lay in self.decoder.layers]).contiguous(),
+            "dec_kv_b": torch.cat([lay.multihead_attn.in_proj_bias.detach()[d:] for lay in self.decoder.layers]).contiguous(),
+        }
+        w.dec_kv_w, w.dec_kv_b = self._packed["dec_kv_w"].data_ptr(), self._packed["dec_kv_b"].data_ptr()
         w.patch = e.patch_size
         w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))
         w.n_queries = self.n_queries

@@ -27,7 +27,8 @@ def _ptr(t: Optional[torch.Tensor]):
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = N.EPI_BIAS,
          residual: Optional[torch.Tensor] = None,
          tile: Optional[Tuple[int, int]] = None, out: Optional[torch.Tensor] = None,
-         out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         out2: Optional[torch.Tensor] = None, a_alt: Optional[torch.Tensor] = None, alt_from_n: int = 0,
+         split_k: int = 1) -> torch.Tensor:
     """C = epilogue(A W^T + bias).  a: (M,K) or (batch,M,K); w: (N,K) or (batch,N,K) (torch Linear layout)."""
     _dev(a, w, bias, residual)
     lib = N.load()
@@ -37,7 +38,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     batch = max(a3.shape[0], w3.shape[0])
     M, K = a3.shape[1], a3.shape[2]
     Nn = w3.shape[1]
-    c = out if out is not None else torch.empty((batch, M, Nn), device=a.device, dtype=torch.float32)
+    c = out if out is not None else torch.empty((max(batch, split_k), M, Nn), device=a.device, dtype=torch.float32)
     c3 = c if c.dim() == 3 else c.unsqueeze(0)
     g = N.GemmArgs()
     g.A, g.W, g.bias, g.C = a3.data_ptr(), w3.data_ptr(), _ptr(bias), c3.data_ptr()
@@ -47,6 +48,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     g.M, g.N, g.K = M, Nn, K
     g.lda, g.ldw, g.ldc = a3.stride(1), w3.stride(1), c3.stride(1)
     g.batch, g.epilogue = batch, epilogue
+    if split_k > 1:  # slice s of the K range lands in c[s] (raw partial products; the caller sums the slices)
+        assert batch == 1 and c3.shape[0] >= split_k
+        g.split_k = split_k
+    if a_alt is not None:
+        g.A_alt, g.alt_from_n = a_alt.data_ptr(), alt_from_n
     if residual is not None:
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
         g.R, g.ldr = r3.data_ptr(), r3.stride(1)
@@ -58,7 +64,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         N.check(lib.sm_gemm_f32(g, _stream()), "sm_gemm_f32")
     else:
         N.check(lib.sm_gemm_f32_tile(g, tile[0], tile[1], _stream()), "sm_gemm_f32_tile")
-    res = c if a.dim() == 3 or w.dim() == 3 or out is not None else c[0]
+    res = c if a.dim() == 3 or w.dim() == 3 or out is not None or split_k > 1 else c[0]
     if epilogue == N.EPI_SIGMOID2:
         return res, (c2 if c2.dim() == res.dim() else c2[0])
     return res

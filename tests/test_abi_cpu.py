@@ -24,11 +24,35 @@ def test_library_exports_every_declared_symbol():
     assert lib.sm_version() >= 100
 
 
-def test_struct_sizes_match_header_layout():
-    assert ctypes.sizeof(N.EncLayer) == 12 * 8 and ctypes.sizeof(N.DecLayer) == 18 * 8
-    assert ctypes.sizeof(N.GemmArgs) == 7 * 8 + 4 * 8 + 12 * 4
-    assert ctypes.sizeof(N.AttnArgs) == 4 * 8 + 8 * 8 + 4 * 4 + 4 + 4  # trailing pad to 8
-    assert ctypes.sizeof(N.Weights) == (5 + 12 * 12 + 2 + 8 * 18 + 2 + 6) * 8 + 4 * 4
+def test_struct_sizes_match_header_layout(tmp_path):
+    """sizeof()/offsetof() as the C compiler sees the header vs the ctypes mirrors (gcc is part of the image)."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    pairs = {"sm_gemm_args": N.GemmArgs, "sm_ln_args": N.LnArgs, "sm_attn_args": N.AttnArgs, "sm_weights": N.Weights,
+             "sm_forward_io": N.ForwardIO, "sm_eval_args": N.EvalArgs, "sm_eval_image": N.EvalImage,
+             "sm_bilateral_args": N.BilateralArgs, "sm_enc_layer": N.EncLayer, "sm_dec_layer": N.DecLayer,
+             "sm_row_map": N.RowMap}
+    last = {"sm_gemm_args": "patch_n", "sm_ln_args": "residual", "sm_attn_args": "scale", "sm_weights": "n_dec_layers",
+            "sm_forward_io": "encoder_only", "sm_eval_args": "scale", "sm_bilateral_args": "W"}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "selfmask_hip.h")}"',
+           'int main(void){']
+    for cname in pairs:
+        src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+    for cname, field in last.items():
+        src.append(f'printf("{cname}.{field} %zu\\n", offsetof({cname}, {field}));')
+    src.append('return 0;}')
+    c = tmp_path / "sz.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "sz"
+    subprocess.run([cc, "-o", str(exe), str(c)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in pairs.items():
+        assert int(out[cname]) == ctypes.sizeof(ct), (cname, out[cname], ctypes.sizeof(ct))
+    for cname, field in last.items():
+        assert int(out[f"{cname}.{field}"]) == getattr(pairs[cname], field).offset, (cname, field)
 
 
 def test_argument_validation_without_gpu():

@@ -58,6 +58,34 @@ def test_gemm_epilogues(epi):
     assert _maxerr(c, ref) <= 2e-5
 
 
+def test_gemm_split_k_and_alt_operand():
+    M, Nn, K = 300, 384, 1536
+    a, w = _rand(M, K, seed=14), _rand(Nn, K, seed=15, scale=0.05)
+    parts = ops.gemm(a.to(DEV), w.to(DEV), split_k=4)  # (4, M, N) raw partials
+    assert parts.shape == (4, M, Nn)
+    assert _maxerr(parts.sum(0), a.double() @ w.double().T) <= 2e-5
+    for s_ in range(4):
+        ks = slice(s_ * 384, (s_ + 1) * 384)
+        assert _maxerr(parts[s_], a[:, ks].double() @ w[:, ks].double().T) <= 1e-5
+    # fused split-K reduction in LayerNorm: LN(residual + (sum of slices + bias))
+    g, b, bias, res = 1 + 0.1 * _rand(384, seed=16), 0.1 * _rand(384, seed=17), _rand(384, seed=18), _rand(M, 384, seed=19)
+    from selfmask_amd import _native as Nn_
+    y = torch.empty(M, 384, device=DEV)
+    la = Nn_.LnArgs()
+    gd, bd, biasd, resd = g.to(DEV), b.to(DEV), bias.to(DEV), res.to(DEV)
+    la.x, la.ldx, la.gamma, la.beta, la.y, la.ldy = parts.data_ptr(), 384, gd.data_ptr(), bd.data_ptr(), y.data_ptr(), 384
+    la.rows, la.eps, la.n_partials, la.partial_stride = M, 1e-5, 4, M * 384
+    la.pre_bias, la.residual = biasd.data_ptr(), resd.data_ptr()
+    Nn_.check(Nn_.load().sm_layernorm_rows_f32(la, torch.cuda.current_stream().cuda_stream))
+    ref = F.layer_norm(res.double() + a.double() @ w.double().T + bias.double(), (384,), g.double(), b.double(), 1e-5)
+    assert _maxerr(y, ref) <= 2e-5
+    # A_alt: columns >= 768 use the second A operand (decoder self-attention q|k from tgt+qpos, v from tgt)
+    a1, a2, w3, b3 = _rand(60, 384, seed=20), _rand(60, 384, seed=21), _rand(1152, 384, seed=22, scale=0.05), _rand(1152, seed=23)
+    c = ops.gemm(a1.to(DEV), w3.to(DEV), b3.to(DEV), a_alt=a2.to(DEV), alt_from_n=768)
+    ref = torch.cat([a1.double() @ w3[:768].double().T, a2.double() @ w3[768:].double().T], 1) + b3.double()
+    assert _maxerr(c, ref) <= 2e-5
+
+
 def test_gemm_batched():
     B, M, Nn, K = 3, 120, 784, 384
     a, w = _rand(B, M, K, seed=8), _rand(B, Nn, K, seed=9, scale=0.1)
