@@ -79,6 +79,16 @@ int sm_gemm_f32_tile(const sm_gemm_args* args, int bm, int bn, void* stream);
 /* the tile sm_gemm_f32 would launch for this shape (host-side heuristic, no GPU work) */
 int sm_gemm_f32_pick_tile(const sm_gemm_args* args, int* bm, int* bn);
 
+/* ---- fp32-grade GEMM on the f16 matrix cores (split operands) -----------------------------------------------------
+ * F16X2 format of a row of K floats (K % 8 == 0): per group of 8 consecutive k, 16 B of hi = f16(x) followed by 16 B
+ * of lo = f16((x - hi) * 2048).  Same bytes and strides as the fp32 row (4 B / element).  x*y is evaluated as
+ * hi*hi + 2^-11 (hi*lo + lo*hi): three v_mfma_f32_32x32x16_f16 per 16-deep step instead of eight fp32 MFMAs, 22
+ * significant bits kept (through the whole network as close to fp64 as the fp32 reference is). */
+int sm_split_f16x2(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t K, void* stream);
+/* same contract as sm_gemm_f32_tile, but A, A_alt and W hold F16X2 data; out_f16x2 != 0 writes C in F16X2 too
+ * (BIAS / GELU / RELU epilogues, N % 8 == 0) so it can feed the next GEMM without a conversion pass */
+int sm_gemm_f16x2_tile(const sm_gemm_args* args, int out_f16x2, int bm, int bn, void* stream);
+
 /* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
  * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */
 int sm_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float* y, int64_t ldy,

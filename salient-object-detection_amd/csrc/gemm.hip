@@ -75,7 +75,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD, each
+    // with a private 4 MiB L2).  Give every XCD a CONTIGUOUS range of logical tiles (m-tile major, n-tile minor) so all
+    // n-tiles of an A row-panel run on one XCD and re-read it from that L2 instead of the Infinity Cache.
+    int tile_id = blockIdx.x;
+    const int ntn = (g.N + BN - 1) / BN;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int n0 = (tile_id % ntn) * BN, m0 = (tile_id / ntn) * BM;
     const int M = g.M, N = g.N;
     // split-K: blockIdx.z is the K-slice (batch == 1); otherwise it is the batch index
     const int split = g.split_k > 1 ? g.split_k : 1;
@@ -214,7 +223,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(sm_gemm_args g) {
 
 template <int BM, int BN, int NST>
 static int launch_gemm(const sm_gemm_args& g, hipStream_t st) {
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.split_k > 1 ? g.split_k : g.batch);
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : g.batch);
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {

@@ -1,0 +1,325 @@
+// fp32-grade GEMM on the f16 matrix cores: C = epilogue(A W^T + bias) with BOTH operands in the "F16X2" split format.
+//
+// Why: the 1e-4 logit gate rules out bf16/f16 operands (7e-2 off), and the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32)
+// is 1/16 of the f16 rate.  Splitting every fp32 value x into two halves, hi = f16(x) and lo = f16((x - hi) * 2^11),
+// keeps 22 significant bits; x*y ~= hi_x*hi_y + 2^-11 (hi_x*lo_y + lo_x*hi_y) needs THREE f16 MFMAs with two fp32
+// accumulators (main, cross) and drops only the 2^-22 lo*lo term.  Simulated through the whole network this is as
+// close to the fp64 truth as the fp32 reference itself (calib: 1.26e-5 vs 1.57e-5; soft: 6.0e-5 vs 7.9e-5), at
+// 3 x 32 cycles per 32x32x16 block instead of 8 x 64: 5.3x the fp32-MFMA rate (833 TFLOP/s equivalent at spec).
+//
+// F16X2 layout of a row of K floats (K % 8 == 0): for every group of 8 consecutive k, 16 bytes of hi halves followed
+// by 16 bytes of lo halves.  A row therefore occupies exactly the bytes of the fp32 row (4 B / element), a 32-k tile
+// of a row is one 128-B line made of eight 16-B chunks, and the LDS-DMA ring / XOR swizzle of gemm.hip carry over
+// unchanged.  Producers write this format directly (LayerNorm, attention, the GELU/ReLU epilogues, im2col, ...).
+//
+// MFMA orientation: the WEIGHT fragment is the A operand and the ACTIVATION fragment the B operand, so a lane ends
+// up with ONE output row m and four consecutive output columns n per register quad: 16-B fp32 stores (or 8-B F16X2
+// half-chunks) instead of 4-B scattered ones.
+#include "common.h"
+#include <type_traits>
+#include <stdlib.h>
+
+namespace sm {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HBK = 32;  // k per pipeline stage (two 16-deep MFMA steps)
+
+__device__ __forceinline__ void dma16h(const void* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_off)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_h() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// hi/lo halves of 4 consecutive values packed for the F16X2 layout.  The hi conversion goes through inline asm so
+// that the value stored and the value subtracted are ONE v_cvt_f16_f32 result: left to itself hipcc emitted a packed
+// round-toward-zero convert for the stored vector and a round-to-nearest one for the subtraction inside the GELU
+// epilogue (lo then had the wrong sign whenever the two roundings differed: 1 f16 ulp errors on 15 % of elements).
+__device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        _Float16 h;
+        float hf;
+        asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(x[i]));
+        asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(h));
+        hi[i] = h;
+        lo[i] = (_Float16)((x[i] - hf) * 2048.0f);
+    }
+}
+
+// store 4 consecutive outputs (columns n..n+3, n % 4 == 0) of row m
+template <int EPI, bool OUT_F16X2>
+__device__ __forceinline__ void store4(const sm_gemm_args& g, float* C, int64_t bz, int m, int n, float (&val)[4]) {
+    if constexpr (EPI == SM_EPI_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[i] = 0.5f * val[i] * (1.0f + erff(val[i] * 0.70710678118654752440f));
+    } else if constexpr (EPI == SM_EPI_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
+    } else if constexpr (EPI == SM_EPI_RESIDUAL) {
+        const float4 r = *reinterpret_cast<const float4*>((g.R + bz * g.strideR) + (int64_t)m * g.ldr + n);
+        val[0] = r.x + val[0]; val[1] = r.y + val[1]; val[2] = r.z + val[2]; val[3] = r.w + val[3];
+    } else if constexpr (EPI == SM_EPI_SIGMOID2) {
+        float4 sg;
+        sg.x = 1.0f / (1.0f + expf(-val[0])); sg.y = 1.0f / (1.0f + expf(-val[1]));
+        sg.z = 1.0f / (1.0f + expf(-val[2])); sg.w = 1.0f / (1.0f + expf(-val[3]));
+        *reinterpret_cast<float4*>((g.C2 + bz * g.strideC) + (int64_t)m * g.ldc + n) = sg;
+    } else if constexpr (EPI == SM_EPI_PATCH) {
+        const int img = m / g.patch_n, p = m - img * g.patch_n;
+        const float4 r = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
+        val[0] += r.x; val[1] += r.y; val[2] += r.z; val[3] += r.w;
+        m = img * (g.patch_n + 1) + 1 + p;
+    }
+    if constexpr (OUT_F16X2) {
+        // row m, group n/8: hi chunk at +0, lo chunk at +16 B; this lane owns elements (n%8)..(n%8)+3 of each
+        f16x4 hi, lo;
+        split4(val, hi, lo);
+        char* row = reinterpret_cast<char*>(C) + ((int64_t)m * g.ldc + (n & ~7)) * 4 + (n & 7) * 2;
+        *reinterpret_cast<f16x4*>(row) = hi;
+        *reinterpret_cast<f16x4*>(row + 16) = lo;
+    } else {
+        *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = make_float4(val[0], val[1], val[2], val[3]);
+    }
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_INST = BM / 32, W_INST = BN / 32;
+    constexpr int NI = A_INST + W_INST;
+    constexpr int STAGE = (BM + BN) * 128;  // bytes per stage (128 B per row per 32-k tile)
+    extern __shared__ __attribute__((aligned(16))) char smemh[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD, each
+    // with a private 4 MiB L2).  Give every XCD a CONTIGUOUS range of logical tiles (m-tile major, n-tile minor) so all
+    // n-tiles of an A row-panel run on one XCD and re-read it from that L2 instead of the Infinity Cache.
+    int tile_id = blockIdx.x;
+    const int ntn = (g.N + BN - 1) / BN;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int n0 = (tile_id % ntn) * BN, m0 = (tile_id / ntn) * BM;
+    const int M = g.M, N = g.N;
+    const int split = g.split_k > 1 ? g.split_k : 1;
+    const int64_t bz = split > 1 ? 0 : (int64_t)blockIdx.z;
+    const int nk = g.K / HBK / split;
+    const int k_begin = split > 1 ? (int)blockIdx.z * nk * HBK : 0;
+    // operands are F16X2: same element count / strides as the fp32 tensors they mirror (4 B per element)
+    const char* A = reinterpret_cast<const char*>(((g.alt_from_n > 0 && n0 >= g.alt_from_n) ? g.A_alt : g.A) + bz * g.strideA + k_begin);
+    const char* W = reinterpret_cast<const char*>(g.W + bz * g.strideW + k_begin);
+
+    const char* a_src[A_INST];
+    const char* w_src[W_INST];
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = (wave * A_INST + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        a_src[i] = A + ((int64_t)gm * g.lda) * 4 + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_INST; ++i) {
+        const int row = (wave * W_INST + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        int gn = n0 + row;
+        gn = gn < N ? gn : N - 1;
+        w_src[i] = W + ((int64_t)gn * g.ldw) * 4 + c * 16;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smemh;
+    auto issue = [&](int kt, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + wave * A_INST * 1024);
+        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + BM * 128 + wave * W_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) dma16h(a_src[i] + kt * 128, sa + i * 1024);
+#pragma unroll
+        for (int i = 0; i < W_INST; ++i) dma16h(w_src[i] + kt * 128, sw + i * 1024);
+    };
+
+    // fragment byte offsets inside a 128-B row: k16-step s, lane half h -> k-group 2s+h -> chunks 2(2s+h) [hi], +1 [lo]
+    const int swz = (r >> 1) & 7;
+    int off_hi[2], off_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        off_hi[s] = ((2 * (2 * s + h)) ^ swz) * 16;
+        off_lo[s] = ((2 * (2 * s + h) + 1) ^ swz) * 16;
+    }
+    const int a_row = (wm * (BM / 2) + r) * 128;
+    const int w_row = BM * 128 + (wn * (BN / 2) + r) * 128;
+
+    f32x16 acc[TM][TN], crs[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { acc[i][j][v] = 0.f; crs[i][j][v] = 0.f; }
+
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt_h<(NST - 2) * NI>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int nt = kt + NST - 1;
+            issue(nt < nk ? nt : nk - 1, nt % NST);
+        }
+        const char* st = smemh + (kt % NST) * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_hi[s]);
+                al[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_lo[s]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_hi[s]);
+                wl[j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_lo[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // D[n][m]: weights are the MFMA A operand (rows = n), activations the B operand (cols = m)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+                    crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], crs[i][j], 0, 0, 0);
+                    crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], crs[i][j], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_vmcnt_h<0>();
+
+    float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : bz) * g.strideC;
+    const bool out_split = g.patch_n < 0;  // out-format flag travels in the sign of patch_n for non-PATCH epilogues
+    auto run = [&](auto epi_tag, auto fmt_tag) {
+        constexpr int EPI = decltype(epi_tag)::value;
+        constexpr bool F = decltype(fmt_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 32 + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * h;
+                    if (n >= N) continue;
+                    float val[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = g.bias ? g.bias[n + e] : 0.f;
+                        val[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + b;
+                    }
+                    store4<EPI, F>(g, C, bz, m, n, val);
+                }
+            }
+        }
+    };
+    using T = std::true_type;
+    using Fa = std::false_type;
+    switch (g.epilogue) {
+        case SM_EPI_GELU: out_split ? run(std::integral_constant<int, SM_EPI_GELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_GELU>{}, Fa{}); break;
+        case SM_EPI_RELU: out_split ? run(std::integral_constant<int, SM_EPI_RELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_RELU>{}, Fa{}); break;
+        case SM_EPI_RESIDUAL: run(std::integral_constant<int, SM_EPI_RESIDUAL>{}, Fa{}); break;
+        case SM_EPI_SIGMOID2: run(std::integral_constant<int, SM_EPI_SIGMOID2>{}, Fa{}); break;
+        case SM_EPI_PATCH: run(std::integral_constant<int, SM_EPI_PATCH>{}, Fa{}); break;
+        default: out_split ? run(std::integral_constant<int, SM_EPI_BIAS>{}, T{}) : run(std::integral_constant<int, SM_EPI_BIAS>{}, Fa{}); break;
+    }
+}
+
+// fp32 (rows, K) -> F16X2, one thread per group of 8
+__global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                          int64_t ldd, int K, int64_t total_groups) {
+    const int gpr = K / 8;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total_groups; t += (int64_t)gridDim.x * 256) {
+        const int64_t row = t / gpr;
+        const int gidx = (int)(t - row * gpr);
+        const float4 a = *reinterpret_cast<const float4*>(src + row * lds_ + gidx * 8);
+        const float4 b = *reinterpret_cast<const float4*>(src + row * lds_ + gidx * 8 + 4);
+        const float x0[4] = {a.x, a.y, a.z, a.w}, x1[4] = {b.x, b.y, b.z, b.w};
+        f16x4 h0, l0, h1, l1;
+        split4(x0, h0, l0);
+        split4(x1, h1, l1);
+        char* out = reinterpret_cast<char*>(dst + row * ldd + gidx * 8);
+        *reinterpret_cast<f16x4*>(out) = h0; *reinterpret_cast<f16x4*>(out + 8) = h1;
+        *reinterpret_cast<f16x4*>(out + 16) = l0; *reinterpret_cast<f16x4*>(out + 24) = l1;
+    }
+}
+
+template <int BM, int BN, int NST>
+static int launch_gemm_h(const sm_gemm_args& g, hipStream_t st) {
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : g.batch);
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, BN, NST>), grid, dim3(256), lds, st, g);
+    return check_launch("sm_gemm_f16x2");
+}
+
+}  // namespace sm
+
+extern "C" int sm_split_f16x2(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t K,
+                              void* stream) {
+    SM_REQUIRE(src && dst && rows > 0 && K > 0 && K % 8 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= K &&
+                   ld_dst >= K,
+               "sm_split_f16x2: bad arguments (K %% 8 == 0, strides %% 4 == 0)");
+    const int64_t groups = rows * (K / 8);
+    int64_t grid = (groups + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sm::split_f16x2_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst,
+                       K, groups);
+    return sm::check_launch("sm_split_f16x2");
+}
+
+extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, int bn, void* stream) {
+    SM_REQUIRE(g && g->A && g->W && g->C, "sm_gemm_f16x2: null pointer");
+    SM_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0 && g->batch > 0 && g->K % sm::HBK == 0, "sm_gemm_f16x2: bad shape");
+    SM_REQUIRE(g->N % 4 == 0 && g->ldc % 4 == 0 && ((uintptr_t)g->C % 16 == 0), "sm_gemm_f16x2: N, ldc must be multiples of 4");
+    SM_REQUIRE(g->lda % 8 == 0 && g->ldw % 8 == 0 && ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->W % 16 == 0),
+               "sm_gemm_f16x2: lda/ldw must be multiples of 8, pointers 16-B aligned");
+    SM_REQUIRE(g->epilogue >= 0 && g->epilogue <= SM_EPI_PATCH, "sm_gemm_f16x2: bad epilogue");
+    if (out_f16x2)
+        SM_REQUIRE(g->N % 8 == 0 && g->ldc % 8 == 0 && (g->epilogue == SM_EPI_BIAS || g->epilogue == SM_EPI_GELU ||
+                                                      g->epilogue == SM_EPI_RELU) && !(g->split_k > 1),
+                   "sm_gemm_f16x2: F16X2 output needs N %% 8 == 0 and a BIAS/GELU/RELU epilogue");
+    if (g->epilogue == SM_EPI_RESIDUAL) SM_REQUIRE(g->R && g->ldr % 4 == 0, "sm_gemm_f16x2: residual needs R, ldr %% 4 == 0");
+    if (g->epilogue == SM_EPI_SIGMOID2) SM_REQUIRE(g->C2, "sm_gemm_f16x2: SIGMOID2 needs C2");
+    if (g->epilogue == SM_EPI_PATCH) SM_REQUIRE(g->R && g->patch_n > 0 && g->batch == 1, "sm_gemm_f16x2: PATCH needs R/patch_n");
+    if (g->alt_from_n > 0) SM_REQUIRE(g->A_alt && g->alt_from_n % 128 == 0, "sm_gemm_f16x2: bad A_alt");
+    if (g->split_k > 1)
+        SM_REQUIRE(g->batch == 1 && g->epilogue == SM_EPI_BIAS && !g->bias && (g->K / sm::HBK) % g->split_k == 0,
+                   "sm_gemm_f16x2: bad split_k");
+    sm_gemm_args a = *g;
+    if (out_f16x2) a.patch_n = -1;
+    hipStream_t st = (hipStream_t)stream;
+    const char* env = getenv("SM_F16X2_NST");  // tuning knob (pipeline depth); default per tile below
+    const int nst = env ? atoi(env) : 0;
+    if (bm == 128 && bn == 128) return nst == 2 ? sm::launch_gemm_h<128, 128, 2>(a, st) : nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : sm::launch_gemm_h<128, 128, 4>(a, st);
+    if (bm == 128 && bn == 64) return nst == 2 ? sm::launch_gemm_h<128, 64, 2>(a, st) : nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : sm::launch_gemm_h<128, 64, 4>(a, st);
+    if (bm == 64 && bn == 64) return nst == 3 ? sm::launch_gemm_h<64, 64, 3>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 6 ? sm::launch_gemm_h<64, 64, 6>(a, st) : sm::launch_gemm_h<64, 64, 4>(a, st);
+    sm::set_error("sm_gemm_f16x2_tile: unsupported tile %dx%d", bm, bn);
+    return SM_EINVAL;
+}

@@ -97,6 +97,8 @@ SYMBOLS = {
     "sm_gemm_f32": (C.c_int, [C.POINTER(GemmArgs), fp]),
     "sm_gemm_f32_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, fp]),
     "sm_gemm_f32_pick_tile": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sm_split_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int64, C.c_int64, C.c_int32, fp]),
+    "sm_gemm_f16x2_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, C.c_int, fp]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),
     "sm_layernorm_rows_f32": (C.c_int, [C.POINTER(LnArgs), fp]),
     "sm_broadcast_rows_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, fp]),

@@ -70,6 +70,37 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return res
 
 
+def split_f16x2(x: torch.Tensor) -> torch.Tensor:
+    """fp32 (..., K) -> F16X2 (same shape / dtype container: 4 B per element, hi/lo f16 halves per group of 8)."""
+    _dev(x)
+    x2 = x.reshape(-1, x.shape[-1])
+    assert x2.stride(1) == 1
+    out = torch.empty((x2.shape[0], x2.shape[1]), device=x.device, dtype=torch.float32)
+    N.check(N.load().sm_split_f16x2(x2.data_ptr(), x2.stride(0), out.data_ptr(), out.stride(0), x2.shape[0], x2.shape[1],
+                                    _stream()), "sm_split_f16x2")
+    return out.view(x.shape)
+
+
+def gemm_f16x2(a_split: torch.Tensor, w_split: torch.Tensor, bias=None, epilogue: int = N.EPI_BIAS, residual=None,
+               tile=(128, 128), out=None, out_f16x2: bool = False, split_k: int = 1):
+    """C = epilogue(A W^T + bias) with A, W in F16X2 format (see split_f16x2); 2-D operands only (test / tuning)."""
+    _dev(a_split, w_split, bias, residual)
+    M, K = a_split.shape
+    Nn = w_split.shape[0]
+    c = out if out is not None else torch.empty((max(1, split_k), M, Nn), device=a_split.device, dtype=torch.float32)
+    c3 = c if c.dim() == 3 else c.unsqueeze(0)
+    g = N.GemmArgs()
+    g.A, g.W, g.bias, g.C = a_split.data_ptr(), w_split.data_ptr(), _ptr(bias), c3.data_ptr()
+    g.strideC = c3.stride(0)
+    g.M, g.N, g.K = M, Nn, K
+    g.lda, g.ldw, g.ldc = a_split.stride(0), w_split.stride(0), c3.stride(1)
+    g.batch, g.epilogue, g.split_k = 1, epilogue, split_k if split_k > 1 else 0
+    if residual is not None:
+        g.R, g.ldr = residual.data_ptr(), residual.stride(0)
+    N.check(N.load().sm_gemm_f16x2_tile(g, 1 if out_f16x2 else 0, tile[0], tile[1], _stream()), "sm_gemm_f16x2_tile")
+    return c if (out is not None or split_k > 1) else c[0]
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
               add: Optional[torch.Tensor] = None, in_map=(0, 0, 0), out_map=(0, 0, 0), rows: Optional[int] = None,
               out_rows: Optional[int] = None):
