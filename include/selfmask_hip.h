@@ -88,6 +88,8 @@ int sm_split_f16x2(const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
 /* same contract as sm_gemm_f32_tile, but A, A_alt and W hold F16X2 data; out_f16x2 != 0 writes C in F16X2 too
  * (BIAS / GELU / RELU epilogues, N % 8 == 0) so it can feed the next GEMM without a conversion pass */
 int sm_gemm_f16x2_tile(const sm_gemm_args* args, int out_f16x2, int bm, int bn, void* stream);
+/* tile / pipeline depth chosen per shape */
+int sm_gemm_f16x2(const sm_gemm_args* args, int out_f16x2, void* stream);
 
 /* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
  * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */
@@ -104,7 +106,7 @@ typedef struct sm_row_map { int32_t group, stride, offset; } sm_row_map;
 typedef struct sm_ln_args {
     const float* x;  int64_t ldx;  sm_row_map in_map;   /* with n_partials > 0: slice 0 of a split-K GEMM output    */
     const float *gamma, *beta;
-    float* y;        int64_t ldy;  sm_row_map out_map;
+    float* y;        int64_t ldy;  sm_row_map out_map;  /* y may be NULL when only ys is wanted                   */
     float* y2;       int64_t ldy2;          /* NULL = none; indexed by the logical row r */
     const float* add; int32_t add_rows;      /* (add_rows,384), row stride 384 */
     int32_t rows;
@@ -115,6 +117,9 @@ typedef struct sm_ln_args {
     int64_t partial_stride;      /* elements between slices */
     const float* pre_bias;       /* (384) */
     const float* residual;       /* (rows,384), row stride ldx */
+    /* F16X2 outputs for the split-operand GEMM (sm_gemm_f16x2): */
+    float* ys;                   /* NULL or F16X2 copy of y, same row map / stride as y (y itself may then be NULL)  */
+    int32_t y2_f16x2;            /* != 0: y2 is written in F16X2 instead of fp32                                     */
 } sm_ln_args;
 int sm_layernorm_rows_f32(const sm_ln_args* args, void* stream);
 
@@ -130,12 +135,15 @@ typedef struct sm_attn_args {
     int64_t sQb, sQr, sKb, sKr, sVb, sVr, sOb, sOr;
     int32_t batch, heads, n_q, n_k;
     float scale;
+    int32_t out_f16x2; /* != 0: O is written in the F16X2 split format (it only feeds the next projection GEMM) */
 } sm_attn_args;
 int sm_attention_f32(const sm_attn_args* args, void* stream);
 
 /* im2col of non-overlapping PxP patches with zero padding to a multiple of P (make_input_divisible,
  * vision_transformer.py:260-267; PatchEmbed conv :182-188): img (B,3,H,W) -> cols (B*gh*gw, 3*P*P), k=(c,i,j). */
 int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream);
+/* same, cols written in the F16X2 split format */
+int sm_im2col_patches_f16x2(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream);
 
 /* tokens[b,0,:] = cls + pos[0]   (vision_transformer.py:276-280) */
 int sm_cls_rows_f32(const float* cls, const float* pos, float* tokens, int32_t B, int32_t N, void* stream);
@@ -149,6 +157,9 @@ int sm_pos_embed_bicubic_f32(const float* pos_in, int32_t g0, float* pos_out, in
  * up (B, 2gh*2gw, 384). */
 int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
                              void* stream);
+/* same, up written in the F16X2 split format (it is the W operand of the mask GEMM) */
+int sm_upsample2x_tokens_f16x2(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
+                               void* stream);
 
 /* objectness = sigmoid(h . w3 + b3) for each row of h (rows,384): last layer of MLP + sigmoid (maskformer.py:231-239) */
 int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows, void* stream);
@@ -237,6 +248,9 @@ typedef struct sm_weights {
     const float* dec_kv_w; /* packed by the host from the state_dict: rows [384:1152) of every decoder layer's      */
     const float* dec_kv_b; /*   multihead_attn.in_proj_{weight,bias}, concatenated -> (L*768, 384) / (L*768): the   */
                            /*   cross-attention K/V of ALL layers is one GEMM over the encoder memory               */
+    int32_t gemm_mode;     /* 0: exact-fp32 MFMA GEMMs; 1: split-operand f16 GEMMs - every GEMM weight pointer above
+                              (patch_w, qkv/proj/fc1/fc2, decoder in/out projections, linear1/2, dec_kv_w, ffn0/1)
+                              then holds the F16X2 copy of the tensor (sm_split_f16x2), biases / norms stay fp32   */
     int32_t patch;         /* 8 or 16 */
     int32_t pos_grid;      /* g0: trained grid side (224/patch) */
     int32_t n_queries;

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f32_kernel(sm_attn_args 
                 float4 w;
                 w.x = o[db][4 * g + 0] * inv; w.y = o[db][4 * g + 1] * inv;
                 w.z = o[db][4 * g + 2] * inv; w.w = o[db][4 * g + 3] * inv;
-                *reinterpret_cast<float4*>(Op + db * 32 + 8 * g + 4 * h) = w;
+                if (a.out_f16x2) {
+                    const float wv[4] = {w.x, w.y, w.z, w.w};
+                    store_f16x2_4(a.O + b * a.sOb + (int64_t)(q0 + r) * a.sOr, head * SM_HEAD_DIM + db * 32 + 8 * g + 4 * h, wv);
+                } else {
+                    *reinterpret_cast<float4*>(Op + db * 32 + 8 * g + 4 * h) = w;
+                }
             }
         }
     }
@@ -193,6 +198,7 @@ extern "C" int sm_attention_f32(const sm_attn_args* a, void* stream) {
     SM_REQUIRE(a->sQr % 4 == 0 && a->sKr % 4 == 0 && a->sVr % 4 == 0 && a->sOr % 4 == 0 && a->sQb % 4 == 0 &&
                    a->sKb % 4 == 0 && a->sVb % 4 == 0 && a->sOb % 4 == 0,
                "sm_attention_f32: strides must be multiples of 4 floats (16-B accesses)");
+    if (a->out_f16x2) SM_REQUIRE(a->sOr % 8 == 0 && a->sOb % 8 == 0, "sm_attention_f32: F16X2 output needs strides %% 8 == 0");
     SM_REQUIRE(((uintptr_t)a->Q | (uintptr_t)a->K | (uintptr_t)a->V | (uintptr_t)a->O) % 16 == 0,
                "sm_attention_f32: pointers must be 16-B aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -45,6 +45,50 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ---- F16X2 split format (see gemm_f16x2.hip): hi = f16(x), lo = f16((x - hi) * 2^11) ---------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// The hi conversion goes through inline asm so that the value stored and the value subtracted are ONE v_cvt_f16_f32
+// result: left to itself hipcc emitted a packed round-toward-zero convert for a stored vector and a round-to-nearest
+// one for the subtraction (lo then had the wrong sign whenever the two roundings differed).
+__device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
+    float hf;
+    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(x));
+    asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(hi));
+    lo = (_Float16)((x - hf) * 2048.0f);
+}
+__device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        _Float16 h, l;
+        split1(x[i], h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+// byte offset of element k of an F16X2 row: hi half; the lo half lives 16 bytes further
+__device__ __forceinline__ int64_t f16x2_off(int64_t k) { return (k & ~(int64_t)7) * 4 + (k & 7) * 2; }
+// store 4 consecutive elements k..k+3 (k % 4 == 0) of an F16X2 row
+__device__ __forceinline__ void store_f16x2_4(void* row, int64_t k, const float (&x)[4]) {
+    f16x4 hi, lo;
+    split4(x, hi, lo);
+    char* p = reinterpret_cast<char*>(row) + f16x2_off(k);
+    *reinterpret_cast<f16x4*>(p) = hi;
+    *reinterpret_cast<f16x4*>(p + 16) = lo;
+}
+// store 2 consecutive elements k, k+1 (k even)
+__device__ __forceinline__ void store_f16x2_2(void* row, int64_t k, float x0, float x1) {
+    f16x2 hi, lo;
+    _Float16 h, l;
+    split1(x0, h, l); hi[0] = h; lo[0] = l;
+    split1(x1, h, l); hi[1] = h; lo[1] = l;
+    char* p = reinterpret_cast<char*>(row) + f16x2_off(k);
+    *reinterpret_cast<f16x2*>(p) = hi;
+    *reinterpret_cast<f16x2*>(p + 16) = lo;
+}
+
 // row of a 32x32 MFMA accumulator held in register v by lane-half h  (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 

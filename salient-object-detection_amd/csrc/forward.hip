@@ -1,6 +1,12 @@
 // MaskFormer.forward (maskformer.py:164-251; return_intermediate=True, use_binary_classifier=True) as one
 // stream-ordered sequence of the kernels of this library.  No allocation, no synchronisation: the caller owns the
 // workspace and the stream, so the whole forward can be captured into a hipGraph.
+//
+// Two GEMM back ends behind sm_weights.gemm_mode:
+//   0  exact-fp32 MFMA (gemm.hip): every buffer fp32;
+//   1  split-operand f16 MFMA (gemm_f16x2.hip, fp32-grade, ~2.2x faster): every tensor that only feeds a GEMM is
+//      produced directly in the F16X2 format by its producer (LayerNorm, attention, GELU/ReLU epilogues, im2col,
+//      up-sample); tensors that are also residuals / outputs exist in fp32 as well.  "(S)" marks them below.
 #include "common.h"
 
 namespace sm {
@@ -21,7 +27,8 @@ static Shape make_shape(const sm_weights* w, int B, int H, int W) {
 
 // workspace carve-up (floats, every region 256-B aligned)
 struct Ws {
-    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *KV, *UP, *TGT, *TGTQ, *T2, *QK, *Vd, *Qc, *AOd, *HIDd, *PART, *QD, *LOG, *O1, *O2;
+    float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *TOKs, *KV, *UP, *TGT, *TGTs, *TGTQ, *T2, *QK, *Qc, *AOd, *HIDd, *PART, *QD,
+        *QDs, *LOG, *O1, *O2;
     size_t total;
 };
 
@@ -36,51 +43,73 @@ static Ws carve(const Shape& s, float* base) {
     const size_t D = SM_EMBED;
     w.pos = take((size_t)s.N * D);
     w.X = take(s.M * D);
-    w.Xn = take(s.M * D);
+    w.Xn = take(s.M * D);               // (S)
     w.QKV = take(s.M * 3 * D);
-    w.AO = take(s.M * D);
-    // HID doubles as the im2col buffer (consumed by the patch GEMM before fc1 first writes HID)
+    w.AO = take(s.M * D);               // (S)
+    // HID (S) doubles as the im2col buffer (S) (consumed by the patch GEMM before fc1 first writes HID)
     size_t hid = s.M * SM_MLP, cols = (size_t)s.Mp * 3 * s.P * s.P;
     w.HID = take(hid > cols ? hid : cols);
     w.TOK = take(s.Mp * D);
-    w.KV = take(s.Mp * 2 * D * s.L);   // cross-attention K|V of ALL decoder layers: (B*n, L*768)
-    w.UP = take(s.Mp * 4 * D);
+    w.TOKs = take(s.Mp * D);            // F16X2 copy of TOK (A operand of the all-layer K/V GEMM)
+    w.KV = take(s.Mp * 2 * D * s.L);    // cross-attention K|V of ALL decoder layers: (B*n, L*768)
+    w.UP = take(s.Mp * 4 * D);          // (S)
     w.TGT = take(s.Md * D);
-    w.TGTQ = take(s.Md * D);
+    w.TGTs = take(s.Md * D);            // F16X2 copy of TGT
+    w.TGTQ = take(s.Md * D);            // (S) tgt + query_pos
     w.T2 = take(s.Md * D);
-    w.QK = take(s.Md * 2 * D);
-    w.Vd = take(s.Md * D);
+    w.QK = take(s.Md * 3 * D);
     w.Qc = take(s.Md * D);
-    w.AOd = take(s.Md * D);
-    w.HIDd = take(s.Md * SM_MLP);
+    w.AOd = take(s.Md * D);             // (S)
+    w.HIDd = take(s.Md * SM_MLP);       // (S)
     w.PART = take(s.Md * D * 4);        // split-K partials of linear2
     w.QD = take(s.Mo * D);
+    w.QDs = take(s.Mo * D);             // F16X2 copy of QD
     w.LOG = take(s.Mo * 4 * s.n);
-    w.O1 = take(s.Mo * D);
+    w.O1 = take(s.Mo * D);              // (S)
     w.O2 = take(s.Mo * D);
     w.total = off * sizeof(float);
     return w;
 }
 
-static int linear(const float* A, int lda, const float* W, const float* b, float* C, int ldc, int64_t M, int N, int K,
-                  int epi, const float* R, int ldr, hipStream_t st) {
+struct Ctx {
+    bool S;  // split-operand GEMM mode
+    hipStream_t st;
+};
+
+// C = epilogue(A W^T + b); in split mode A and W are F16X2 and `out_s` asks for an F16X2 C
+static int linear(const Ctx& c, const float* A, int lda, const float* W, const float* b, float* C, int ldc, int64_t M, int N,
+                  int K, int epi, const float* R, int ldr, bool out_s = false) {
     sm_gemm_args g = {};
     g.A = A; g.W = W; g.bias = b; g.C = C; g.R = R;
     g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldr = ldr;
     g.batch = 1; g.epilogue = epi;
-    return sm_gemm_f32(&g, st);
+    return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
+}
+static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s = false) {
+    return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
 }
 
-static int ln(const float* x, const float* gw, const float* gb, float* y, int64_t rows, float eps, hipStream_t st,
-              sm_row_map in_map = {0, 0, 0}, sm_row_map out_map = {0, 0, 0}, float* y2 = nullptr,
-              const float* add = nullptr, int add_rows = 0, int n_partials = 0, int64_t partial_stride = 0,
-              const float* pre_bias = nullptr, const float* residual = nullptr) {
+struct LnOpt {
+    sm_row_map in_map = {0, 0, 0}, out_map = {0, 0, 0};
+    float* ys = nullptr;        // F16X2 copy of y
+    float* y2 = nullptr;        // y + add (fp32, or F16X2 when y2_s)
+    bool y2_s = false;
+    const float* add = nullptr;
+    int add_rows = 0;
+    int n_partials = 0;
+    int64_t partial_stride = 0;
+    const float* pre_bias = nullptr;
+    const float* residual = nullptr;
+};
+static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, float* y, int64_t rows, float eps,
+              const LnOpt& o = LnOpt()) {
     sm_ln_args a = {};
-    a.x = x; a.ldx = SM_EMBED; a.in_map = in_map; a.gamma = gw; a.beta = gb; a.y = y; a.ldy = SM_EMBED;
-    a.out_map = out_map; a.y2 = y2; a.ldy2 = SM_EMBED; a.add = add; a.add_rows = add_rows;
+    a.x = x; a.ldx = SM_EMBED; a.in_map = o.in_map; a.gamma = gw; a.beta = gb; a.y = y; a.ldy = SM_EMBED;
+    a.out_map = o.out_map; a.y2 = o.y2; a.ldy2 = SM_EMBED; a.add = o.add; a.add_rows = o.add_rows;
     a.rows = (int)rows; a.eps = eps;
-    a.n_partials = n_partials; a.partial_stride = partial_stride; a.pre_bias = pre_bias; a.residual = residual;
-    return sm_layernorm_rows_f32(&a, st);
+    a.n_partials = o.n_partials; a.partial_stride = o.partial_stride; a.pre_bias = o.pre_bias; a.residual = o.residual;
+    a.ys = o.ys; a.y2_f16x2 = o.y2_s ? 1 : 0;
+    return sm_layernorm_rows_f32(&a, c.st);
 }
 
 #define TRY(x)                \
@@ -93,7 +122,8 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     const Shape s = make_shape(w, io->B, io->H, io->W);
     Ws ws = carve(s, wsbase);
     const int D = SM_EMBED;
-    const sm_row_map id = {0, 0, 0};
+    const Ctx c = {w->gemm_mode == 1, st};
+    const bool S = c.S;
 
     // ---- tokens: patch embedding + cls + position (vision_transformer.py:269-281) ----------------------------
     const float* pos = w->pos_embed;
@@ -102,110 +132,142 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         pos = ws.pos;
     }
     float* cols = ws.HID;
-    TRY(sm_im2col_patches_f32(io->x, cols, s.B, s.H, s.W, s.P, st));
+    TRY(S ? sm_im2col_patches_f16x2(io->x, cols, s.B, s.H, s.W, s.P, st)
+          : sm_im2col_patches_f32(io->x, cols, s.B, s.H, s.W, s.P, st));
     TRY(sm_cls_rows_f32(w->cls_token, pos, ws.X, s.B, s.N, st));
     {
         sm_gemm_args g = {};
         g.A = cols; g.W = w->patch_w; g.bias = w->patch_b; g.C = ws.X; g.R = pos;
         g.M = (int)s.Mp; g.N = D; g.K = 3 * s.P * s.P; g.lda = g.K; g.ldw = g.K; g.ldc = D; g.ldr = D;
         g.batch = 1; g.epilogue = SM_EPI_PATCH; g.patch_n = s.n;
-        TRY(sm_gemm_f32(&g, st));
+        TRY(gemm(c, g));
     }
 
     // ---- 12 pre-norm blocks (vision_transformer.py:164-170) -----------------------------------------------------
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
-        TRY(ln(ws.X, e.norm1_w, e.norm1_b, ws.Xn, s.M, 1e-6f, st));
-        TRY(linear(ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, st));
+        LnOpt xs;
+        xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
+        TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0));
         sm_attn_args a = {};
         a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
         a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
         a.sOb = (int64_t)s.N * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f; a.out_f16x2 = S;
         TRY(sm_attention_f32(&a, st));
-        TRY(linear(ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D, st));
-        TRY(ln(ws.X, e.norm2_w, e.norm2_b, ws.Xn, s.M, 1e-6f, st));
-        TRY(linear(ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, st));
-        TRY(linear(ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D, st));
+        TRY(linear(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
+        TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
+        TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D));
     }
     // final norm on the last layer only (the other 11 per-layer norms of :299 are dead work when
     // lateral_connection=False), dropping the cls row on the way (maskformer.py:107-108,177)
     float* tok = io->patch_tokens ? io->patch_tokens : ws.TOK;
     {
-        const sm_row_map drop_cls = {s.n, s.N, 1};
-        TRY(ln(ws.X, w->enc_norm_w, w->enc_norm_b, tok, s.Mp, 1e-6f, st, drop_cls, id));
+        LnOpt o;
+        o.in_map = {s.n, s.N, 1};
+        o.ys = S ? ws.TOKs : nullptr;
+        TRY(ln(c, ws.X, w->enc_norm_w, w->enc_norm_b, tok, s.Mp, 1e-6f, o));
     }
     if (io->encoder_only) return SM_OK;
+    const float* tok_a = S ? ws.TOKs : tok;  // GEMM-operand view of the tokens
 
     // ---- 6 post-norm decoder layers (transformer_decoder.py:260-297, :112-150) ----------------------------------
     float* QD = io->queries ? io->queries : ws.QD;
-    if (hipMemsetAsync(ws.TGT, 0, s.Md * D * sizeof(float), st) != hipSuccess) {
+    const float* qpos = w->query_embed;
+    // tgt = 0 (F16X2 zeros are zero bytes too); tgt + query_pos = query_pos broadcast over the batch
+    if (hipMemsetAsync(ws.TGT, 0, s.Md * D * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(ws.TGTs, 0, s.Md * D * sizeof(float), st) != hipSuccess) {
         set_error("sm_maskformer_forward: hipMemsetAsync failed");
         return SM_ELAUNCH;
     }
-    const float* qpos = w->query_embed;
-    TRY(sm_broadcast_rows_f32(qpos, ws.TGTQ, s.nq, s.B, st));  // tgt + query_pos with tgt = 0
+    if (S) {
+        TRY(sm_broadcast_rows_f32(qpos, ws.T2, s.nq, s.B, st));
+        TRY(sm_split_f16x2(ws.T2, D, ws.TGTQ, D, s.Md, D, st));
+    } else {
+        TRY(sm_broadcast_rows_f32(qpos, ws.TGTQ, s.nq, s.B, st));
+    }
     // cross-attention keys/values of every layer depend only on the encoder memory: one large GEMM
     // (B*n x 384) x (384 x L*768) instead of L small ones on the critical chain
     const int KVW = s.L * 2 * D;
-    TRY(linear(tok, D, w->dec_kv_w, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0, st));
+    TRY(linear(c, tok_a, D, w->dec_kv_w, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0));
     for (int l = 0; l < s.L; ++l) {
         const sm_dec_layer& d = w->dec[l];
+        const float* tgt_a = S ? ws.TGTs : ws.TGT;  // GEMM-operand view of tgt (TGT / T2 swap roles every layer)
         // self-attention: q = k = tgt + query_pos, v = tgt  ->  ONE launch: columns [0,768) read TGTQ, [768,1152) TGT
         {
             sm_gemm_args g = {};
-            g.A = ws.TGTQ; g.A_alt = ws.TGT; g.alt_from_n = 2 * D; g.W = d.sa_in_w; g.bias = d.sa_in_b; g.C = ws.QK;
+            g.A = ws.TGTQ; g.A_alt = tgt_a; g.alt_from_n = 2 * D; g.W = d.sa_in_w; g.bias = d.sa_in_b; g.C = ws.QK;
             g.M = (int)s.Md; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * D; g.batch = 1; g.epilogue = SM_EPI_BIAS;
-            TRY(sm_gemm_f32(&g, st));
+            TRY(gemm(c, g));
         }
         sm_attn_args a = {};
         a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.QK + 2 * D; a.O = ws.AOd;
         a.sQb = a.sKb = a.sVb = (int64_t)s.nq * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f; a.out_f16x2 = S;
         TRY(sm_attention_f32(&a, st));
-        TRY(linear(ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
-        TRY(ln(ws.T2, d.norm1_w, d.norm1_b, ws.TGT, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq));
+        TRY(linear(c, ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
+        {
+            LnOpt o;  // norm1 -> tgt (fp32: residual of the next block) + tgt + query_pos (cross-attention query operand)
+            o.y2 = ws.TGTQ; o.y2_s = S; o.add = qpos; o.add_rows = s.nq;
+            TRY(ln(c, ws.T2, d.norm1_w, d.norm1_b, ws.TGT, s.Md, 1e-5f, o));
+        }
         // cross-attention: q = tgt + query_pos, k = v = memory (pos = None)
-        TRY(linear(ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, st));
+        TRY(linear(c, ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0));
         a = {};
         a.Q = ws.Qc; a.K = ws.KV + (int64_t)l * 2 * D; a.V = a.K + D; a.O = ws.AOd;
         a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * KVW; a.sKr = a.sVr = KVW;
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f; a.out_f16x2 = S;
         TRY(sm_attention_f32(&a, st));
-        TRY(linear(ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D, st));
-        TRY(ln(ws.T2, d.norm2_w, d.norm2_b, ws.TGT, s.Md, 1e-5f, st));
+        TRY(linear(c, ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
+        {
+            LnOpt o;  // norm2 -> tgt (residual of the FFN) (+ F16X2 copy: operand of linear1)
+            o.ys = S ? ws.TGTs : nullptr;
+            TRY(ln(c, ws.T2, d.norm2_w, d.norm2_b, ws.TGT, s.Md, 1e-5f, o));
+        }
         // FFN: linear2 (K = 1536, only M/64 x 6 tiles) is split 4-way along K; norm3 sums the slices + bias + residual
-        TRY(linear(ws.TGT, D, d.lin1_w, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, st));
+        TRY(linear(c, tgt_a, D, d.lin1_w, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, S));
         {
             sm_gemm_args g = {};
             g.A = ws.HIDd; g.W = d.lin2_w; g.C = ws.PART; g.M = (int)s.Md; g.N = D; g.K = SM_MLP; g.lda = SM_MLP;
             g.ldw = SM_MLP; g.ldc = D; g.batch = 1; g.epilogue = SM_EPI_BIAS; g.split_k = 4; g.strideC = s.Md * D;
-            TRY(sm_gemm_f32(&g, st));
+            TRY(gemm(c, g));
         }
-        TRY(ln(ws.PART, d.norm3_w, d.norm3_b, ws.T2, s.Md, 1e-5f, st, id, id, ws.TGTQ, qpos, s.nq, 4, s.Md * D, d.lin2_b,
-               ws.TGT));
-        { float* t = ws.TGT; ws.TGT = ws.T2; ws.T2 = t; }  // norm3 wrote the new tgt
-        // shared final norm on every layer's output, scattered into (B, L, nq, 384)
-        const sm_row_map stack = {s.nq, s.L * s.nq, l * s.nq};
-        TRY(ln(ws.TGT, w->dec_norm_w, w->dec_norm_b, QD, s.Md, 1e-5f, st, id, stack));
+        {
+            LnOpt o;  // norm3(sum of slices + bias + tgt) -> new tgt (fp32 + F16X2) and tgt + query_pos
+            o.ys = S ? ws.TGTs : nullptr;
+            o.y2 = ws.TGTQ; o.y2_s = S; o.add = qpos; o.add_rows = s.nq;
+            o.n_partials = 4; o.partial_stride = s.Md * D; o.pre_bias = d.lin2_b; o.residual = ws.TGT;
+            TRY(ln(c, ws.PART, d.norm3_w, d.norm3_b, ws.T2, s.Md, 1e-5f, o));
+        }
+        { float* t = ws.TGT; ws.TGT = ws.T2; ws.T2 = t; }  // norm3 wrote the new tgt into T2
+        {
+            LnOpt o;  // shared final norm on every layer's output, scattered into (B, L, nq, 384) (+ F16X2 copy)
+            o.out_map = {s.nq, s.L * s.nq, l * s.nq};
+            o.ys = S ? ws.QDs : nullptr;
+            TRY(ln(c, ws.TGT, w->dec_norm_w, w->dec_norm_b, QD, s.Md, 1e-5f, o));
+        }
     }
+    const float* qd_a = S ? ws.QDs : QD;
 
     // ---- heads --------------------------------------------------------------------------------------------------
     TRY(sm_query_mean_f32(QD, io->features, s.B, s.L, s.nq, st));
-    TRY(sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
+    TRY(S ? sm_upsample2x_tokens_f16x2(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st)
+          : sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
     {
         // mask_pred[b] = sigmoid(Q[b] (L*nq x 384) . up[b]^T (384 x 4n))   (maskformer.py:223)
         sm_gemm_args g = {};
-        g.A = QD; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;
+        g.A = qd_a; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;
         g.M = s.L * s.nq; g.N = 4 * s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = 4 * s.n;
         g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)4 * s.n * D; g.strideC = (int64_t)s.L * s.nq * 4 * s.n;
         g.batch = s.B; g.epilogue = SM_EPI_SIGMOID2;
-        TRY(sm_gemm_f32(&g, st));
+        TRY(gemm(c, g));
     }
-    TRY(linear(QD, D, w->ffn0_w, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, st));
-    TRY(linear(ws.O1, D, w->ffn1_w, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, st));
+    TRY(linear(c, qd_a, D, w->ffn0_w, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
+    TRY(linear(c, ws.O1, D, w->ffn1_w, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0));
     TRY(sm_rowdot_sigmoid_f32(ws.O2, w->ffn2_w, w->ffn2_b, io->objectness, (int)s.Mo, st));
     return SM_OK;
 }
@@ -213,11 +275,16 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
 static int validate(const sm_weights* w, const sm_forward_io* io) {
     SM_REQUIRE(w && io, "sm_maskformer_forward: null arguments");
     SM_REQUIRE(w->patch == 8 || w->patch == 16, "sm_maskformer_forward: patch=%d (8 or 16)", w->patch);
+    SM_REQUIRE(w->gemm_mode == 0 || w->gemm_mode == 1, "sm_maskformer_forward: gemm_mode=%d (0 or 1)", w->gemm_mode);
     SM_REQUIRE(w->n_dec_layers >= 1 && w->n_dec_layers <= SM_MAX_DEC_LAYERS, "sm_maskformer_forward: n_dec_layers=%d",
                w->n_dec_layers);
     SM_REQUIRE(w->n_queries >= 1 && w->pos_grid >= 1, "sm_maskformer_forward: bad n_queries/pos_grid");
     SM_REQUIRE(w->dec_kv_w && w->dec_kv_b, "sm_maskformer_forward: dec_kv_w/dec_kv_b (packed cross-attention K/V) missing");
     SM_REQUIRE(io->x && io->B > 0 && io->H > 0 && io->W > 0, "sm_maskformer_forward: bad input shape");
+    if (w->gemm_mode == 1) {
+        const int gh = (io->H + w->patch - 1) / w->patch, gw = (io->W + w->patch - 1) / w->patch;
+        SM_REQUIRE((4 * gh * gw) % 4 == 0, "sm_maskformer_forward: mask width must be a multiple of 4");
+    }
     if (!io->encoder_only)
         SM_REQUIRE(io->mask_pred && io->objectness && io->features, "sm_maskformer_forward: null output");
     else

@@ -21,9 +21,6 @@
 
 namespace sm {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
 constexpr int HBK = 32;  // k per pipeline stage (two 16-deep MFMA steps)
 
 __device__ __forceinline__ void dma16h(const void* gsrc, unsigned lds_off) {
@@ -37,22 +34,6 @@ __device__ __forceinline__ void dma16h(const void* gsrc, unsigned lds_off) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt_h() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// hi/lo halves of 4 consecutive values packed for the F16X2 layout.  The hi conversion goes through inline asm so
-// that the value stored and the value subtracted are ONE v_cvt_f16_f32 result: left to itself hipcc emitted a packed
-// round-toward-zero convert for the stored vector and a round-to-nearest one for the subtraction inside the GELU
-// epilogue (lo then had the wrong sign whenever the two roundings differed: 1 f16 ulp errors on 15 % of elements).
-__device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        _Float16 h;
-        float hf;
-        asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(h) : "v"(x[i]));
-        asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(h));
-        hi[i] = h;
-        lo[i] = (_Float16)((x[i] - hf) * 2048.0f);
-    }
 }
 
 // store 4 consecutive outputs (columns n..n+3, n % 4 == 0) of row m
@@ -80,11 +61,7 @@ __device__ __forceinline__ void store4(const sm_gemm_args& g, float* C, int64_t 
     }
     if constexpr (OUT_F16X2) {
         // row m, group n/8: hi chunk at +0, lo chunk at +16 B; this lane owns elements (n%8)..(n%8)+3 of each
-        f16x4 hi, lo;
-        split4(val, hi, lo);
-        char* row = reinterpret_cast<char*>(C) + ((int64_t)m * g.ldc + (n & ~7)) * 4 + (n & 7) * 2;
-        *reinterpret_cast<f16x4*>(row) = hi;
-        *reinterpret_cast<f16x4*>(row + 16) = lo;
+        store_f16x2_4(C + (int64_t)m * g.ldc, n, val);
     } else {
         *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = make_float4(val[0], val[1], val[2], val[3]);
     }
@@ -255,12 +232,8 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
         const float4 a = *reinterpret_cast<const float4*>(src + row * lds_ + gidx * 8);
         const float4 b = *reinterpret_cast<const float4*>(src + row * lds_ + gidx * 8 + 4);
         const float x0[4] = {a.x, a.y, a.z, a.w}, x1[4] = {b.x, b.y, b.z, b.w};
-        f16x4 h0, l0, h1, l1;
-        split4(x0, h0, l0);
-        split4(x1, h1, l1);
-        char* out = reinterpret_cast<char*>(dst + row * ldd + gidx * 8);
-        *reinterpret_cast<f16x4*>(out) = h0; *reinterpret_cast<f16x4*>(out + 8) = h1;
-        *reinterpret_cast<f16x4*>(out + 16) = l0; *reinterpret_cast<f16x4*>(out + 24) = l1;
+        store_f16x2_4(dst + row * ldd, gidx * 8, x0);
+        store_f16x2_4(dst + row * ldd, gidx * 8 + 4, x1);
     }
 }
 
@@ -315,11 +288,21 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     sm_gemm_args a = *g;
     if (out_f16x2) a.patch_n = -1;
     hipStream_t st = (hipStream_t)stream;
-    const char* env = getenv("SM_F16X2_NST");  // tuning knob (pipeline depth); default per tile below
+    // Pipeline depth: this kernel is bound by bytes in flight per CU (L2 -> LDS latency ~1.7 us under load), so the
+    // depths below keep 48 KiB of LDS per workgroup = three workgroups per CU (scripts/gemm_f16x2_sweep.py).
+    const char* env = getenv("SM_F16X2_NST");  // tuning knob
     const int nst = env ? atoi(env) : 0;
-    if (bm == 128 && bn == 128) return nst == 2 ? sm::launch_gemm_h<128, 128, 2>(a, st) : nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : sm::launch_gemm_h<128, 128, 4>(a, st);
-    if (bm == 128 && bn == 64) return nst == 2 ? sm::launch_gemm_h<128, 64, 2>(a, st) : nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : sm::launch_gemm_h<128, 64, 4>(a, st);
-    if (bm == 64 && bn == 64) return nst == 3 ? sm::launch_gemm_h<64, 64, 3>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 6 ? sm::launch_gemm_h<64, 64, 6>(a, st) : sm::launch_gemm_h<64, 64, 4>(a, st);
+    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2>(a, st);
+    if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2>(a, st);
+    if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : sm::launch_gemm_h<64, 64, 3>(a, st);
     sm::set_error("sm_gemm_f16x2_tile: unsupported tile %dx%d", bm, bn);
     return SM_EINVAL;
+}
+
+extern "C" int sm_gemm_f16x2(const sm_gemm_args* g, int out_f16x2, void* stream) {
+    SM_REQUIRE(g, "sm_gemm_f16x2: null pointer");
+    // measured on MI355X (B=64 ViT-S/16 shapes): wide outputs (N >= 768) 128x64, everything else 64x64
+    const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * (g->split_k > 1 ? g->split_k : g->batch);
+    if (g->N >= 768 && wg128 >= 768) return sm_gemm_f16x2_tile(g, out_f16x2, 128, 64, stream);
+    return sm_gemm_f16x2_tile(g, out_f16x2, 64, 64, stream);
 }

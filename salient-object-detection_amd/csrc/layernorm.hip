@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
         q += v[i].x * v[i].x + v[i].y * v[i].y;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 384.0f) + a.eps);
-    float* yr = a.y + map_row(row, a.out_map) * a.ldy;
+    const int64_t orow = map_row(row, a.out_map);
+    float* yr = a.y ? a.y + orow * a.ldy : nullptr;
+    float* ysr = a.ys ? a.ys + orow * a.ldy : nullptr;
     float* y2r = a.y2 ? a.y2 + (int64_t)row * a.ldy2 : nullptr;
     const float* ar = a.y2 ? a.add + (int64_t)(row % a.add_rows) * SM_EMBED : nullptr;
 #pragma unroll
@@ -54,12 +56,14 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
         float2 o;
         o.x = v[i].x * rstd * gm.x + bt.x;
         o.y = v[i].y * rstd * gm.y + bt.y;
-        *reinterpret_cast<float2*>(yr + i * 128 + lane * 2) = o;
+        if (yr) *reinterpret_cast<float2*>(yr + i * 128 + lane * 2) = o;
+        if (ysr) store_f16x2_2(ysr, i * 128 + lane * 2, o.x, o.y);
         if (y2r) {
             const float2 ad = *reinterpret_cast<const float2*>(ar + i * 128 + lane * 2);
             o.x += ad.x;
             o.y += ad.y;
-            *reinterpret_cast<float2*>(y2r + i * 128 + lane * 2) = o;
+            if (a.y2_f16x2) store_f16x2_2(y2r, i * 128 + lane * 2, o.x, o.y);
+            else *reinterpret_cast<float2*>(y2r + i * 128 + lane * 2) = o;
         }
     }
 }
@@ -74,7 +78,8 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __rest
 }  // namespace sm
 
 extern "C" int sm_layernorm_rows_f32(const sm_ln_args* a, void* stream) {
-    SM_REQUIRE(a && a->x && a->gamma && a->beta && a->y, "sm_layernorm_f32: null pointer");
+    SM_REQUIRE(a && a->x && a->gamma && a->beta && (a->y || a->ys), "sm_layernorm_f32: null pointer");
+    if (a->ys || a->y2_f16x2) SM_REQUIRE(a->ldy % 8 == 0 && a->ldy2 % 8 == 0, "sm_layernorm_f32: F16X2 outputs need ld %% 8 == 0");
     SM_REQUIRE(a->rows >= 0 && a->ldx >= SM_EMBED && a->ldy >= SM_EMBED && a->ldx % 2 == 0 && a->ldy % 2 == 0,
                "sm_layernorm_f32: bad rows/strides");
     SM_REQUIRE(a->in_map.group >= 0 && a->out_map.group >= 0, "sm_layernorm_f32: bad row map");

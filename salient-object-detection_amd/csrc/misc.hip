@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 // ---- im2col: cols[(b,gy,gx)][(c,i,j)] = img[b][c][gy*P+i][gx*P+j], zero beyond H/W ------------------------------
 // one thread per 4 consecutive j (16 B of one image row); consecutive threads walk k fastest so the cols rows are
 // written as full contiguous lines; image reads are P*4-byte runs.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ cols, int B,
                                                      int H, int W, int P, int gh, int gw, int64_t total4) {
     const int K = 3 * P * P, K4 = K / 4;
@@ -39,7 +40,12 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
                 if (x + 3 < W) v.w = src[3];
             }
         }
-        *reinterpret_cast<float4*>(cols + m * K + k) = v;
+        if constexpr (SPLIT) {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            store_f16x2_4(cols + m * K, k, vv);
+        } else {
+            *reinterpret_cast<float4*>(cols + m * K + k) = v;
+        }
     }
 }
 
@@ -87,6 +93,7 @@ __global__ __launch_bounds__(128) void pos_bicubic_kernel(const float* __restric
 }
 
 // ---- bilinear x2, align_corners=False, channels-last: up[b][(oy,ox)][c] ------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ tok, int64_t strideb,
                                                          float* __restrict__ up, int gh, int gw, int64_t total4) {
     const int oh = 2 * gh, ow = 2 * gw, C4 = SM_EMBED / 4;
@@ -110,7 +117,12 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
         o.y = ly0 * (lx0 * p00.y + lx1 * p01.y) + ly1 * (lx0 * p10.y + lx1 * p11.y);
         o.z = ly0 * (lx0 * p00.z + lx1 * p01.z) + ly1 * (lx0 * p10.z + lx1 * p11.z);
         o.w = ly0 * (lx0 * p00.w + lx1 * p01.w) + ly1 * (lx0 * p10.w + lx1 * p11.w);
-        *reinterpret_cast<float4*>(up + px * SM_EMBED + c) = o;
+        if constexpr (SPLIT) {
+            const float vv[4] = {o.x, o.y, o.z, o.w};
+            store_f16x2_4(up + px * SM_EMBED, c, vv);
+        } else {
+            *reinterpret_cast<float4*>(up + px * SM_EMBED + c) = o;
+        }
     }
 }
 
@@ -153,16 +165,25 @@ static inline int grid_for(int64_t work, int per_block = 256) {
 extern "C" int sm_version(void) { return 100; }
 extern "C" const char* sm_last_error(void) { return sm::g_err; }
 
-extern "C" int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P,
-                                     void* stream) {
+static int im2col_impl(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream, bool split) {
     SM_REQUIRE(img && cols, "sm_im2col_patches_f32: null pointer");
     SM_REQUIRE(B > 0 && H > 0 && W > 0 && (P == 8 || P == 16), "sm_im2col_patches_f32: bad shape B=%d H=%d W=%d P=%d", B,
                H, W, P);
     const int gh = (H + P - 1) / P, gw = (W + P - 1) / P;
     const int64_t total4 = (int64_t)B * gh * gw * (3 * P * P / 4);
-    hipLaunchKernelGGL(sm::im2col_kernel, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, img, cols, B, H,
-                       W, P, gh, gw, total4);
+    if (split)
+        hipLaunchKernelGGL(sm::im2col_kernel<true>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, img, cols,
+                           B, H, W, P, gh, gw, total4);
+    else
+        hipLaunchKernelGGL(sm::im2col_kernel<false>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, img, cols,
+                           B, H, W, P, gh, gw, total4);
     return sm::check_launch("sm_im2col_patches_f32");
+}
+extern "C" int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream) {
+    return im2col_impl(img, cols, B, H, W, P, stream, false);
+}
+extern "C" int sm_im2col_patches_f16x2(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream) {
+    return im2col_impl(img, cols, B, H, W, P, stream, true);
 }
 
 extern "C" int sm_cls_rows_f32(const float* cls, const float* pos, float* tokens, int32_t B, int32_t N, void* stream) {
@@ -179,13 +200,25 @@ extern "C" int sm_pos_embed_bicubic_f32(const float* pos_in, int32_t g0, float* 
     return sm::check_launch("sm_pos_embed_bicubic_f32");
 }
 
-extern "C" int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
-                                        void* stream) {
+static int upsample_impl(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, void* stream,
+                         bool split) {
     SM_REQUIRE(tok && up && B > 0 && gh > 0 && gw > 0 && strideb % 4 == 0, "sm_upsample2x_tokens_f32: bad arguments");
     const int64_t total4 = (int64_t)B * 4 * gh * gw * (SM_EMBED / 4);
-    hipLaunchKernelGGL(sm::upsample2x_kernel, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, tok, strideb,
-                       up, gh, gw, total4);
+    if (split)
+        hipLaunchKernelGGL(sm::upsample2x_kernel<true>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, tok,
+                           strideb, up, gh, gw, total4);
+    else
+        hipLaunchKernelGGL(sm::upsample2x_kernel<false>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, tok,
+                           strideb, up, gh, gw, total4);
     return sm::check_launch("sm_upsample2x_tokens_f32");
+}
+extern "C" int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
+                                        void* stream) {
+    return upsample_impl(tok, strideb, up, B, gh, gw, stream, false);
+}
+extern "C" int sm_upsample2x_tokens_f16x2(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
+                                          void* stream) {
+    return upsample_impl(tok, strideb, up, B, gh, gw, stream, true);
 }
 
 extern "C" int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows,

@@ -31,7 +31,7 @@ class LnArgs(C.Structure):
     _fields_ = [("x", fp), ("ldx", C.c_int64), ("in_map", RowMap), ("gamma", fp), ("beta", fp),
                 ("y", fp), ("ldy", C.c_int64), ("out_map", RowMap), ("y2", fp), ("ldy2", C.c_int64),
                 ("add", fp), ("add_rows", C.c_int32), ("rows", C.c_int32), ("eps", C.c_float), ("n_partials", C.c_int32),
-                ("partial_stride", C.c_int64), ("pre_bias", fp), ("residual", fp)]
+                ("partial_stride", C.c_int64), ("pre_bias", fp), ("residual", fp), ("ys", fp), ("y2_f16x2", C.c_int32)]
 
 
 class AttnArgs(C.Structure):
@@ -39,7 +39,7 @@ class AttnArgs(C.Structure):
                 ("sQb", C.c_int64), ("sQr", C.c_int64), ("sKb", C.c_int64), ("sKr", C.c_int64),
                 ("sVb", C.c_int64), ("sVr", C.c_int64), ("sOb", C.c_int64), ("sOr", C.c_int64),
                 ("batch", C.c_int32), ("heads", C.c_int32), ("n_q", C.c_int32), ("n_k", C.c_int32),
-                ("scale", C.c_float)]
+                ("scale", C.c_float), ("out_f16x2", C.c_int32)]
 
 
 ENC_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
@@ -62,7 +62,7 @@ class Weights(C.Structure):
                 ("enc", EncLayer * ENC_DEPTH), ("enc_norm_w", fp), ("enc_norm_b", fp),
                 ("dec", DecLayer * MAX_DEC_LAYERS), ("dec_norm_w", fp), ("dec_norm_b", fp),
                 ("ffn0_w", fp), ("ffn0_b", fp), ("ffn1_w", fp), ("ffn1_b", fp), ("ffn2_w", fp), ("ffn2_b", fp),
-                ("dec_kv_w", fp), ("dec_kv_b", fp), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
+                ("dec_kv_w", fp), ("dec_kv_b", fp), ("gemm_mode", C.c_int32), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
                 ("n_dec_layers", C.c_int32)]
 
 
@@ -99,6 +99,9 @@ SYMBOLS = {
     "sm_gemm_f32_pick_tile": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sm_split_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int64, C.c_int64, C.c_int32, fp]),
     "sm_gemm_f16x2_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, C.c_int, fp]),
+    "sm_gemm_f16x2": (C.c_int, [C.POINTER(GemmArgs), C.c_int, fp]),
+    "sm_im2col_patches_f16x2": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_upsample2x_tokens_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),
     "sm_layernorm_rows_f32": (C.c_int, [C.POINTER(LnArgs), fp]),
     "sm_broadcast_rows_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, fp]),

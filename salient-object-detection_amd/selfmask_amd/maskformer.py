@@ -113,8 +113,13 @@ class MaskFormer(nn.Module):
             lateral_connection: bool = False,
             scale_factor: int = 2,
             abs_2d_pe_init: bool = False,
-            use_binary_classifier: bool = False
+            use_binary_classifier: bool = False,
+            *,
+            gemm_mode: Optional[str] = None,
     ):
+        """Same arguments as the reference.  ``gemm_mode`` (extra, keyword-only) picks the GEMM back end:
+        "f16x2" (default; split-operand f16 matrix cores, fp32-grade results) or "fp32" (exact fp32 MFMA).
+        The environment variable SM_GEMM_MODE overrides the default."""
         super().__init__()
         if arch != "vit_small":
             raise NotImplementedError(f"arch={arch!r}: only the DINO ViT-S encoder is on the MI355X hot path "
@@ -145,6 +150,10 @@ class MaskFormer(nn.Module):
         self.return_intermediate = return_intermediate
         self.n_queries = n_queries
         self.n_decoder_layers = n_decoder_layers
+        import os
+        self.gemm_mode = gemm_mode or os.environ.get("SM_GEMM_MODE", "f16x2")
+        if self.gemm_mode not in ("f16x2", "fp32"):
+            raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'f16x2' or 'fp32'")
         self._table = None       # (Weights struct, key) cache
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
         self._workspace = {}     # (device, B, H, W) -> uint8 tensor
@@ -165,7 +174,8 @@ class MaskFormer(nn.Module):
         self._packed = None
 
     def _weights(self) -> N.Weights:
-        key = (self.query_embed.data_ptr(), self.ffn.layers[2].bias.data_ptr(), self.encoder.pos_embed.data_ptr())
+        key = (self.query_embed.data_ptr(), self.ffn.layers[2].bias.data_ptr(), self.encoder.pos_embed.data_ptr(),
+               self.gemm_mode)
         if self._table is not None and self._table[1] == key:
             return self._table[0]
         for n_, p in self.named_parameters():
@@ -174,45 +184,57 @@ class MaskFormer(nn.Module):
                                    f"(got {p.device}, {p.dtype}); the product path has no CPU fallback")
         w = N.Weights()
         e = self.encoder
+        split = self.gemm_mode == "f16x2"
+        packed = {}
+        d = N.EMBED
+        # cross-attention K/V projections of all layers packed into one (L*768, 384) weight: rows [384:1152) of each
+        # multihead_attn.in_proj_weight (transformer_decoder.py:283-289 with key = value = memory)
+        packed["dec_kv_w"] = torch.cat([lay.multihead_attn.in_proj_weight.detach()[d:] for lay in self.decoder.layers]).contiguous()
+        packed["dec_kv_b"] = torch.cat([lay.multihead_attn.in_proj_bias.detach()[d:] for lay in self.decoder.layers]).contiguous()
+
+        def gw(name: str, t: torch.Tensor) -> int:
+            """pointer of a GEMM weight: the tensor itself (fp32 mode) or its F16X2 copy (split mode)"""
+            t2 = t.detach().reshape(t.shape[0], -1)
+            if not split:
+                return t2.data_ptr()
+            from . import ops
+            packed["s:" + name] = ops.split_f16x2(t2.contiguous())
+            return packed["s:" + name].data_ptr()
+
         w.query_embed = self.query_embed.data_ptr()
         w.cls_token = e.cls_token.data_ptr()
         w.pos_embed = e.pos_embed.data_ptr()
-        w.patch_w = e.patch_embed.proj.weight.data_ptr()
+        w.patch_w = gw("patch_w", e.patch_embed.proj.weight)
         w.patch_b = e.patch_embed.proj.bias.data_ptr()
         for i, blk in enumerate(e.blocks):
             L = w.enc[i]
             L.norm1_w, L.norm1_b = blk.norm1.weight.data_ptr(), blk.norm1.bias.data_ptr()
-            L.qkv_w, L.qkv_b = blk.attn.qkv.weight.data_ptr(), blk.attn.qkv.bias.data_ptr()
-            L.proj_w, L.proj_b = blk.attn.proj.weight.data_ptr(), blk.attn.proj.bias.data_ptr()
+            L.qkv_w, L.qkv_b = gw(f"enc{i}.qkv", blk.attn.qkv.weight), blk.attn.qkv.bias.data_ptr()
+            L.proj_w, L.proj_b = gw(f"enc{i}.proj", blk.attn.proj.weight), blk.attn.proj.bias.data_ptr()
             L.norm2_w, L.norm2_b = blk.norm2.weight.data_ptr(), blk.norm2.bias.data_ptr()
-            L.fc1_w, L.fc1_b = blk.mlp.fc1.weight.data_ptr(), blk.mlp.fc1.bias.data_ptr()
-            L.fc2_w, L.fc2_b = blk.mlp.fc2.weight.data_ptr(), blk.mlp.fc2.bias.data_ptr()
+            L.fc1_w, L.fc1_b = gw(f"enc{i}.fc1", blk.mlp.fc1.weight), blk.mlp.fc1.bias.data_ptr()
+            L.fc2_w, L.fc2_b = gw(f"enc{i}.fc2", blk.mlp.fc2.weight), blk.mlp.fc2.bias.data_ptr()
         w.enc_norm_w, w.enc_norm_b = e.norm.weight.data_ptr(), e.norm.bias.data_ptr()
         for j, lay in enumerate(self.decoder.layers):
             L = w.dec[j]
-            L.sa_in_w, L.sa_in_b = lay.self_attn.in_proj_weight.data_ptr(), lay.self_attn.in_proj_bias.data_ptr()
-            L.sa_out_w, L.sa_out_b = lay.self_attn.out_proj.weight.data_ptr(), lay.self_attn.out_proj.bias.data_ptr()
-            L.ca_in_w, L.ca_in_b = lay.multihead_attn.in_proj_weight.data_ptr(), lay.multihead_attn.in_proj_bias.data_ptr()
-            L.ca_out_w = lay.multihead_attn.out_proj.weight.data_ptr()
+            L.sa_in_w, L.sa_in_b = gw(f"dec{j}.sa_in", lay.self_attn.in_proj_weight), lay.self_attn.in_proj_bias.data_ptr()
+            L.sa_out_w, L.sa_out_b = gw(f"dec{j}.sa_out", lay.self_attn.out_proj.weight), lay.self_attn.out_proj.bias.data_ptr()
+            L.ca_in_w, L.ca_in_b = gw(f"dec{j}.ca_in", lay.multihead_attn.in_proj_weight), lay.multihead_attn.in_proj_bias.data_ptr()
+            L.ca_out_w = gw(f"dec{j}.ca_out", lay.multihead_attn.out_proj.weight)
             L.ca_out_b = lay.multihead_attn.out_proj.bias.data_ptr()
-            L.lin1_w, L.lin1_b = lay.linear1.weight.data_ptr(), lay.linear1.bias.data_ptr()
-            L.lin2_w, L.lin2_b = lay.linear2.weight.data_ptr(), lay.linear2.bias.data_ptr()
+            L.lin1_w, L.lin1_b = gw(f"dec{j}.lin1", lay.linear1.weight), lay.linear1.bias.data_ptr()
+            L.lin2_w, L.lin2_b = gw(f"dec{j}.lin2", lay.linear2.weight), lay.linear2.bias.data_ptr()
             L.norm1_w, L.norm1_b = lay.norm1.weight.data_ptr(), lay.norm1.bias.data_ptr()
             L.norm2_w, L.norm2_b = lay.norm2.weight.data_ptr(), lay.norm2.bias.data_ptr()
             L.norm3_w, L.norm3_b = lay.norm3.weight.data_ptr(), lay.norm3.bias.data_ptr()
         w.dec_norm_w, w.dec_norm_b = self.decoder.norm.weight.data_ptr(), self.decoder.norm.bias.data_ptr()
         f = self.ffn.layers
-        w.ffn0_w, w.ffn0_b = f[0].weight.data_ptr(), f[0].bias.data_ptr()
-        w.ffn1_w, w.ffn1_b = f[1].weight.data_ptr(), f[1].bias.data_ptr()
+        w.ffn0_w, w.ffn0_b = gw("ffn0", f[0].weight), f[0].bias.data_ptr()
+        w.ffn1_w, w.ffn1_b = gw("ffn1", f[1].weight), f[1].bias.data_ptr()
         w.ffn2_w, w.ffn2_b = f[2].weight.data_ptr(), f[2].bias.data_ptr()
-        # cross-attention K/V projections of all layers packed into one (L*768, 384) weight: rows [384:1152) of each
-        # multihead_attn.in_proj_weight (transformer_decoder.py:283-289 with key = value = memory)
-        d = N.EMBED
-        self._packed = {
-            "dec_kv_w": torch.cat([lay.multihead_attn.in_proj_weight.detach()[d:] for lay in self.decoder.layers]).contiguous(),
-            "dec_kv_b": torch.cat([lay.multihead_attn.in_proj_bias.detach()[d:] for lay in self.decoder.layers]).contiguous(),
-        }
-        w.dec_kv_w, w.dec_kv_b = self._packed["dec_kv_w"].data_ptr(), self._packed["dec_kv_b"].data_ptr()
+        w.dec_kv_w, w.dec_kv_b = gw("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
+        w.gemm_mode = 1 if split else 0
+        self._packed = packed
         w.patch = e.patch_size
         w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))
         w.n_queries = self.n_queries

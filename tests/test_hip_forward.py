@@ -27,18 +27,22 @@ def _tol(scale):
     return ABS_TOL * max(1.0, scale / 16.0)
 
 
-def _model(patch, wseed, style):
+MODES = ["f16x2", "fp32"]  # split-operand f16 matrix cores (default) / exact fp32 MFMA
+
+
+def _model(patch, wseed, style, mode="f16x2"):
     m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True,
-                   use_binary_classifier=True)
+                   use_binary_classifier=True, gemm_mode=mode)
     m.load_state_dict(synthetic_state_dict(wseed, style, patch_size=patch), strict=True)
     return m.to(DEV)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("fp", CASES, ids=[os.path.basename(c)[8:-4] for c in CASES])
-def test_forward_matches_reference_vectors(fp):
+def test_forward_matches_reference_vectors(fp, mode):
     g = np.load(fp)
     patch, B, Hh, Ww, wseed, xseed, _ = [int(v) for v in g["meta"]]
-    m = _model(patch, wseed, str(g["style"]))
+    m = _model(patch, wseed, str(g["style"]), mode)
     x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww))).to(DEV)
     out = m(x, return_logits=True)
     scale = float(g["logit_absmax"])
@@ -47,7 +51,7 @@ def test_forward_matches_reference_vectors(fp):
     d32 = np.abs(logits - g["logits_last"]).max()
     d64 = np.abs(logits - g["logits_last_f64"]).max()
     ref64 = float(g["f32_vs_f64_maxabs"])
-    print(f"\n{os.path.basename(fp)}: |logit|max={scale:.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e} tol={tol:.1e}")
+    print(f"\n[{mode}] {os.path.basename(fp)}: |logit|max={scale:.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e} tol={tol:.1e}")
     assert d32 <= tol
     assert d64 <= max(2.0 * ref64, 0.5 * tol)  # as close to the fp64 truth as the fp32 reference is (x2 slack)
     assert out["mask_pred"].shape == (B, 6, 20, 2 * int(g["grid"][0]), 2 * int(g["grid"][1]))
@@ -67,12 +71,13 @@ def test_forward_matches_reference_vectors(fp):
         assert np.abs(out["patch_tokens"][0].cpu().numpy() - g["patch_tokens_b0"]).max() <= 5e-5
 
 
-def test_forward_vs_oracle_batch8_and_fp64_truth():
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_vs_oracle_batch8_and_fp64_truth(mode):
     """Larger seeded batch through the oracle on this box's CPU (fp32 + fp64), strict 1e-4 on a calib checkpoint."""
     patch, B = 16, 8
     sd = synthetic_state_dict(11, "calib", patch_size=patch)
     x = torch.from_numpy(synthetic_images(4321, (B, 3, 224, 224)))
-    m = _model(patch, 11, "calib")
+    m = _model(patch, 11, "calib", mode)
     out = m(x.to(DEV), return_logits=True)
     o32 = O.forward(x, sd, patch)
     o64 = O.forward(x.double(), O.cast_state(sd, torch.float64), patch)
@@ -80,7 +85,7 @@ def test_forward_vs_oracle_batch8_and_fp64_truth():
     d32 = (lg - o32["mask_logits"]).abs().max().item()
     d64 = (lg.double() - o64["mask_logits"]).abs().max().item()
     r64 = (o32["mask_logits"].double() - o64["mask_logits"]).abs().max().item()
-    print(f"\nB=8 calib: |logit|max={o32['mask_logits'].abs().max():.1f} hip-oracle32={d32:.2e} hip-truth64={d64:.2e} "
+    print(f"\n[{mode}] B=8 calib: |logit|max={o32['mask_logits'].abs().max():.1f} hip-oracle32={d32:.2e} hip-truth64={d64:.2e} "
           f"oracle32-truth64={r64:.2e}")
     assert d32 <= ABS_TOL
     assert d64 <= max(2 * r64, 0.5 * ABS_TOL)
