@@ -27,6 +27,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD, 256 CUs @ 2.4 GHz
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (v_mfma_f32_32x32x16_f16); the split GEMM issues 3 MFMA flops per
+                               # algorithmic flop, so its fp32-equivalent roof is 833 TFLOP/s
 HBM_PEAK_GBS = 8000.0
 
 
@@ -60,32 +62,46 @@ def forward_gemm_launches(B, P, S, L=6, nq=20):
     ]
 
 
-def time_gemm_kernels(B, P, S, iters=3):
-    """Live per-kernel timing of the GEMM instantiations (the kernels that hold >80 % of the forward): for each
-    kernel name (= workgroup tile) replay exactly the launch mix one forward issues, bracketed by HIP events on
-    the stream the library launches on (torch's current stream).  Returns {kernel: dict} sorted by time."""
+def time_gemm_kernels(B, P, S, mode, iters=3):
+    """Live per-kernel timing of the GEMM instantiations (the kernels that hold most of the forward): for each
+    kernel name (= back end + workgroup tile) replay exactly the launch mix one forward issues, bracketed by HIP events
+    on the stream the library launches on (torch's current stream).  Returns {kernel: dict} sorted by time."""
     import ctypes
     from selfmask_amd import ops, _native as Nn
     lib = Nn.load()
     dev = "cuda"
+    split_mode = mode == "f16x2"
     groups = {}
     for name, M, N, K, epi, batch, cnt, split in forward_gemm_launches(B, P, S):
         ga = Nn.GemmArgs()
         ga.M, ga.N, ga.K, ga.batch, ga.split_k = M, N, K, batch, split
-        bm, bn = ctypes.c_int(), ctypes.c_int()
-        Nn.check(lib.sm_gemm_f32_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn)))
+        bm, bn, nst = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        if split_mode:
+            Nn.check(lib.sm_gemm_f16x2_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nst)))
+            kname = f"gemm_f16x2_kernel<{bm.value}, {bn.value}, {nst.value}>"
+        else:
+            Nn.check(lib.sm_gemm_f32_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn)))
+            nst_f32 = {(128, 128): 2, (128, 64): 3, (64, 64): 4}[(bm.value, bn.value)]
+            kname = f"gemm_f32_kernel<{bm.value}, {bn.value}, {nst_f32}>"
         a = torch.randn(batch, M, K, device=dev)
         w = torch.randn(batch, N, K, device=dev) * 0.03
+        if split_mode:  # operands in the F16X2 split format, as the forward's producers write them
+            a, w = ops.split_f16x2(a), ops.split_f16x2(w)
         bias = torch.zeros(N, device=dev) if split == 1 else None
         c = torch.empty(max(batch, split), M, N, device=dev)
         r = torch.randn(batch, M, N, device=dev) if epi == Nn.EPI_RESIDUAL else None
-        groups.setdefault((bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch, split))
+        groups.setdefault((kname, bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch, split, batch))
     out = {}
-    for (bm, bn), items in groups.items():
+    for (kname, bm, bn), items in groups.items():
         def run_mix():
-            for name, a, w, bias, c, r, epi, cnt, fl, split in items:
+            for name, a, w, bias, c, r, epi, cnt, fl, split, batch in items:
                 for _ in range(cnt):
-                    ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn), split_k=split)
+                    if split_mode:
+                        for bi in range(batch):  # the python test wrapper is 2-D; batched launches are replayed per image
+                            ops.gemm_f16x2(a[bi], w[bi], bias, epilogue=epi, residual=None if r is None else r[bi],
+                                           tile=(bm, bn), out=c if split > 1 else c[bi], split_k=split)
+                    else:
+                        ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn), split_k=split)
         run_mix()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -94,11 +110,10 @@ def time_gemm_kernels(B, P, S, iters=3):
             run_mix()
         e1.record()
         torch.cuda.synchronize()
-        launches = sum(i[7] for i in items)
+        launches = sum(i[7] * (i[10] if split_mode else 1) for i in items)
         flops = sum(i[7] * i[8] for i in items)
         total_s = e0.elapsed_time(e1) * 1e-3 / iters
-        nst = {(128, 128): 2, (128, 64): 3, (64, 64): 4}[(bm, bn)]
-        out[f"gemm_f32_kernel<{bm}, {bn}, {nst}>"] = {
+        out[kname] = {
             "launches_per_forward": launches, "avg_launch_us": total_s / launches * 1e6,
             "flops_per_launch": flops / launches, "total_ms_per_forward": total_s * 1e3,
             "achieved_tflops": flops / total_s / 1e12, "mix": [i[0] for i in items]}
@@ -138,6 +153,7 @@ def main():
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-mode", default=None, choices=["f16x2", "fp32"], help="GEMM back end (default f16x2)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,7 +171,7 @@ def main():
     from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images
     P, S, B = a.patch, a.size, a.batch
     model = MaskFormer(n_queries=20, patch_size=P, n_decoder_layers=6, return_intermediate=True,
-                       use_binary_classifier=True)
+                       use_binary_classifier=True, gemm_mode=a.gemm_mode)
     model.load_state_dict(synthetic_state_dict(0, "soft", patch_size=P), strict=True)
     model = model.to(dev)
     # every rank owns a different shard of the (synthetic) image list: rank-strided seeds
@@ -206,26 +222,30 @@ def main():
     if rank == 0:
         value = world * a.steps * B / dt
         flops_img = forward_flops_per_image(P, S)
-        kern = time_gemm_kernels(B, P, S)
+        kern = time_gemm_kernels(B, P, S, model.gemm_mode)
         dom_name, dom = next(iter(kern.items()))
         ach = dom["achieved_tflops"]
+        peak = F32_MFMA_PEAK_TFLOPS if model.gemm_mode == "fp32" else F16_MFMA_PEAK_TFLOPS
         res = {
             "metric": "images/sec (224^2, nq=20)", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if model.gemm_mode == "fp32" else "f32 (GEMM operands split into two f16 halves, f16 MFMA, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
                                    f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
-                       "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20,
+                       "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20, "gemm_mode": model.gemm_mode,
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
             "roofline": {"bound": "mfma", "kernel": dom_name, "launch_mix": dom["mix"],
-                         "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": None,
+                         "mfma_issued_tflops": round(ach * (3.0 if model.gemm_mode == "f16x2" else 1.0), 2),
                          "avg_launch_us": round(dom["avg_launch_us"], 2),
                          "launches_per_forward": dom["launches_per_forward"],
                          "flops_per_launch": dom["flops_per_launch"]},
             "roofline_other_kernels": {k: {"achieved": round(v["achieved_tflops"], 2),
-                                           "frac": round(v["achieved_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                                           "frac": round(v["achieved_tflops"] / peak, 4),
                                            "avg_launch_us": round(v["avg_launch_us"], 2),
                                            "launches_per_forward": v["launches_per_forward"]}
                                        for k, v in list(kern.items())[1:]},

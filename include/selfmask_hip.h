@@ -90,6 +90,7 @@ int sm_split_f16x2(const float* src, int64_t ld_src, float* dst, int64_t ld_dst,
 int sm_gemm_f16x2_tile(const sm_gemm_args* args, int out_f16x2, int bm, int bn, void* stream);
 /* tile / pipeline depth chosen per shape */
 int sm_gemm_f16x2(const sm_gemm_args* args, int out_f16x2, void* stream);
+int sm_gemm_f16x2_pick_tile(const sm_gemm_args* args, int* bm, int* bn, int* nst);
 
 /* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
  * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */

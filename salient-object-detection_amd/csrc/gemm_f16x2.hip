@@ -299,10 +299,19 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     return SM_EINVAL;
 }
 
-extern "C" int sm_gemm_f16x2(const sm_gemm_args* g, int out_f16x2, void* stream) {
-    SM_REQUIRE(g, "sm_gemm_f16x2: null pointer");
-    // measured on MI355X (B=64 ViT-S/16 shapes): wide outputs (N >= 768) 128x64, everything else 64x64
+extern "C" int sm_gemm_f16x2_pick_tile(const sm_gemm_args* g, int* bm, int* bn, int* nst) {
+    SM_REQUIRE(g && bm && bn && nst, "sm_gemm_f16x2_pick_tile: null pointer");
+    // measured on MI355X (B=64 ViT-S/16 shapes): wide outputs (N >= 768) 128x64 (2 stages), everything else 64x64 (3
+    // stages); both are 48 KiB of LDS per workgroup = three workgroups per CU
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * (g->split_k > 1 ? g->split_k : g->batch);
-    if (g->N >= 768 && wg128 >= 768) return sm_gemm_f16x2_tile(g, out_f16x2, 128, 64, stream);
-    return sm_gemm_f16x2_tile(g, out_f16x2, 64, 64, stream);
+    if (g->N >= 768 && wg128 >= 768) { *bm = 128; *bn = 64; *nst = 2; }
+    else { *bm = 64; *bn = 64; *nst = 3; }
+    return SM_OK;
+}
+
+extern "C" int sm_gemm_f16x2(const sm_gemm_args* g, int out_f16x2, void* stream) {
+    int bm, bn, nst;
+    int rc = sm_gemm_f16x2_pick_tile(g, &bm, &bn, &nst);
+    if (rc) return rc;
+    return sm_gemm_f16x2_tile(g, out_f16x2, bm, bn, stream);
 }

@@ -100,6 +100,7 @@ SYMBOLS = {
     "sm_split_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int64, C.c_int64, C.c_int32, fp]),
     "sm_gemm_f16x2_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, C.c_int, fp]),
     "sm_gemm_f16x2": (C.c_int, [C.POINTER(GemmArgs), C.c_int, fp]),
+    "sm_gemm_f16x2_pick_tile": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sm_im2col_patches_f16x2": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_upsample2x_tokens_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),
