@@ -186,10 +186,10 @@ typedef struct sm_eval_args {
                                     mask, each in the order iou, pixel_acc, f_score, f_max, f_mean, mae, s_measure
                                     (evaluator.pyc@L276 header order); 14 = picked query, 15 = upper-bound query      */
     float* ious;                 /* out [B][nq] per-query IoU against the GT, or NULL                                 */
-    void* workspace;             /* sm_evaluate_workspace_bytes(B, nq), 256-B aligned                                 */
+    void* workspace;             /* sm_evaluate_workspace_bytes(B, nq, mh, mw, max_pixels), 256-B aligned             */
     size_t workspace_bytes;
     int32_t B, nq, mh, mw;       /* nq <= 32                                                                         */
-    int32_t max_pixels;          /* largest H*W among the batch's ground truths (<= 1024*1024): sizes the launch grid */
+    int32_t max_pixels;          /* largest H*W among the batch's ground truths (<= 2048*2048): sizes the launch grid */
     float scale;                 /* > 0: reference mode F.interpolate(scale_factor=scale)[..., :H, :W]
                                     (evaluator.pyc@L209-211: 4 for ViT-S/8); 0: resize to (H, W) (batched mode)       */
 } sm_eval_args;
@@ -197,7 +197,7 @@ typedef struct sm_eval_args {
 /* Per image: bilinear up-sample of the nq query masks (align_corners=False), upper-bound query = arg-max IoU vs GT
  * (evaluator.pyc@L101-134,216), pick = arg-max objectness (@L219-221), then compute_iou / FMeasure (f_measure,
  * f_max over 255 thresholds, f_mean) / compute_mae / compute_pixel_accuracy / SMeasure (metrics/ *.py) for both. */
-size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq);
+size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq, int32_t mh, int32_t mw, int32_t max_pixels);
 int sm_evaluate_masks_f32(const sm_eval_args* args, void* stream);
 
 /* ---- bilateral-solver refinement ---------------------------------------------------- */

@@ -72,51 +72,145 @@ __device__ __forceinline__ void split_idx(int idx, int W, float inv_w, int& y, i
     if (x < 0) { --y; x += W; } else if (x >= W) { ++y; x -= W; }
 }
 
-// K1: one workgroup per (pixel chunk, image): every thread up-samples ALL queries at its pixels (index math and the
-// GT byte are shared by the nq queries), integer counts go to global memory with integer atomics (deterministic).
-__global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, QueryStats* qs, GtStats* gs) {
+constexpr int EV_QS = 32;  // query stride of the transposed mask copy (floats): one 128-B line per low-res pixel
+
+// K0: maskT[b][p][q] = mask_pred[b][q][p] (q padded to 32) so the nq queries of one bilinear tap are one cache line
+__global__ __launch_bounds__(256) void eval_transpose_kernel(sm_eval_args a, float* __restrict__ maskT) {
+    const int b = blockIdx.y, plane = a.mh * a.mw;
+    const float* __restrict__ m0 = a.mask_pred + (int64_t)b * a.mask_stride_b;
+    float* out = maskT + (int64_t)b * plane * EV_QS;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < plane * EV_QS; t += gridDim.x * 256) {
+        const int p = t / EV_QS, q = t - p * EV_QS;
+        out[t] = q < a.nq ? m0[(int64_t)q * plane + p] : 0.f;
+    }
+}
+
+// K1: one workgroup per (pixel chunk, image): every thread up-samples ALL queries at its pixels - index math, the GT
+// byte and the four tap addresses are shared by the nq queries.  The low-res rows the chunk touches (a 2048-pixel
+// chunk spans ~7 image rows = 2-3 low-res rows) are staged in LDS first: per-lane global loads of the taps cost a full
+// texture-addresser pass each even when 10-14 neighbouring lanes want the same address (measured: 320 us for the
+// batch, TA-bound); ds_read_b128 from LDS is an order of magnitude cheaper.  Integer counts go to global memory with
+// integer atomics (deterministic).
+constexpr int EV_LDS_ROWS = 8;  // low-res rows staged per chunk (falls back to global loads if the chunk needs more)
+
+__global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, const float* __restrict__ maskT,
+                                                                QueryStats* qpart, GtStats* gpart, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) float taps[];  // [rows][mw][EV_QS]
+    __shared__ unsigned red_u[EV_THREADS / 64][2 * EV_MAXQ];
+    __shared__ unsigned long long red_g[EV_THREADS / 64][3];
     const int b = blockIdx.y;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W;
     const int base = blockIdx.x * EV_CHUNK;
-    if (base >= npx) return;
+    QueryStats* qslot = qpart + ((int64_t)b * nchunk + blockIdx.x) * a.nq;  // per-chunk partials: no atomics (thousands
+    GtStats* gslot = gpart + (int64_t)b * nchunk + blockIdx.x;              // of adds on two cache lines serialise in L2)
+    if (base >= npx) {
+        if (threadIdx.x < a.nq) { QueryStats z; z.inter = 0; z.uni = 0; qslot[threadIdx.x] = z; }
+        if (threadIdx.x == 0) { GtStats z; z.sum_g = 0; z.sum_gx = 0; z.sum_gy = 0; *gslot = z; }
+        return;
+    }
     const unsigned char* __restrict__ gt = a.gt + im.gt_off;
-    const float* __restrict__ m0 = a.mask_pred + (int64_t)b * a.mask_stride_b;
+    const float* __restrict__ mt = maskT + (int64_t)b * a.mh * a.mw * EV_QS;
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
     const float inv_w = 1.0f / (float)im.W;
-    const int plane = a.mh * a.mw;
+    const int nq4 = (a.nq + 3) >> 2;
+    // low-res rows touched by this chunk
+    const int last = min(base + EV_CHUNK, npx) - 1;
+    const int r_lo = up_index(base / im.W, sy, a.mh).i0, r_hi = up_index(last / im.W, sy, a.mh).i1;
+    const bool staged = (r_hi - r_lo + 1) <= EV_LDS_ROWS;
+    if (staged) {
+        const int n4 = (r_hi - r_lo + 1) * a.mw * (EV_QS / 4);
+        const float4* src = reinterpret_cast<const float4*>(mt + (int64_t)r_lo * a.mw * EV_QS);
+        for (int t = threadIdx.x; t < n4; t += EV_THREADS) reinterpret_cast<float4*>(taps)[t] = src[t];
+    }
+    __syncthreads();
     unsigned inter[EV_MAXQ], uni[EV_MAXQ];
 #pragma unroll
     for (int q = 0; q < EV_MAXQ; ++q) { inter[q] = 0; uni[q] = 0; }
     unsigned long long sg = 0, sgx = 0, sgy = 0;
-    for (int k = 0; k < EV_PPT; ++k) {
-        const int idx = base + k * EV_THREADS + threadIdx.x;
-        if (idx >= npx) break;
-        int y, x;
-        split_idx(idx, im.W, inv_w, y, x);
-        const UpIdx uy = up_index(y, sy, a.mh), ux = up_index(x, sx, a.mw);
-        const unsigned g = gt[idx] != 0;
-        if (g) { sg += 1; sgx += (unsigned)x; sgy += (unsigned)y; }
+    // one body, two call sites, so each keeps its pointer's address space (ds_read for the staged copy, global
+    // loads for the fallback): never select between an LDS and a global pointer at run time
+    auto body = [&](const float* tb, int row0) {
+        for (int k = 0; k < EV_PPT; ++k) {
+            const int idx = base + k * EV_THREADS + threadIdx.x;
+            if (idx >= npx) break;
+            int y, x;
+            split_idx(idx, im.W, inv_w, y, x);
+            const UpIdx uy = up_index(y, sy, a.mh), ux = up_index(x, sx, a.mw);
+            const unsigned g = gt[idx] != 0;
+            if (g) { sg += 1; sgx += (unsigned)x; sgy += (unsigned)y; }
+            const float4* t00 = reinterpret_cast<const float4*>(tb + ((uy.i0 - row0) * a.mw + ux.i0) * EV_QS);
+            const float4* t01 = reinterpret_cast<const float4*>(tb + ((uy.i0 - row0) * a.mw + ux.i1) * EV_QS);
+            const float4* t10 = reinterpret_cast<const float4*>(tb + ((uy.i1 - row0) * a.mw + ux.i0) * EV_QS);
+            const float4* t11 = reinterpret_cast<const float4*>(tb + ((uy.i1 - row0) * a.mw + ux.i1) * EV_QS);
 #pragma unroll
-        for (int q = 0; q < EV_MAXQ; ++q) {
-            if (q < a.nq) {
-                const unsigned bin = up_sample(m0 + q * plane, a.mw, uy, ux) > 0.5f;
-                inter[q] += bin & g;
-                uni[q] += bin | g;
+            for (int q4 = 0; q4 < EV_MAXQ / 4; ++q4) {
+                if (q4 < nq4) {
+                    const float4 p00 = t00[q4], p01 = t01[q4], p10 = t10[q4], p11 = t11[q4];
+                    const float v00[4] = {p00.x, p00.y, p00.z, p00.w}, v01[4] = {p01.x, p01.y, p01.z, p01.w};
+                    const float v10[4] = {p10.x, p10.y, p10.z, p10.w}, v11[4] = {p11.x, p11.y, p11.z, p11.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float top = __builtin_fmaf(v00[e], ux.l0, v01[e] * ux.l1);
+                        const float bot = __builtin_fmaf(v10[e], ux.l0, v11[e] * ux.l1);
+                        const unsigned bin = __builtin_fmaf(top, uy.l0, bot * uy.l1) > 0.5f;
+                        inter[q4 * 4 + e] += bin & g;
+                        uni[q4 * 4 + e] += bin | g;
+                    }
+                }
             }
         }
-    }
-    const int lane = threadIdx.x & 63;
+    };
+    if (staged) body(taps, r_lo);
+    else body(mt, 0);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < EV_MAXQ; ++q) {
         if (q < a.nq) {
             const unsigned i = wave_total(inter[q]), u = wave_total(uni[q]);
-            if (lane == 0) { atomicAdd(&qs[b * a.nq + q].inter, i); atomicAdd(&qs[b * a.nq + q].uni, u); }
+            if (lane == 0) { red_u[wv][2 * q] = i; red_u[wv][2 * q + 1] = u; }
         }
     }
     sg = wave_total(sg); sgx = wave_total(sgx); sgy = wave_total(sgy);
-    if (lane == 0) { atomicAdd(&gs[b].sum_g, sg); atomicAdd(&gs[b].sum_gx, sgx); atomicAdd(&gs[b].sum_gy, sgy); }
+    if (lane == 0) { red_g[wv][0] = sg; red_g[wv][1] = sgx; red_g[wv][2] = sgy; }
+    __syncthreads();
+    if (threadIdx.x < a.nq) {
+        const int q = threadIdx.x;
+        QueryStats o;
+        o.inter = red_u[0][2 * q] + red_u[1][2 * q] + red_u[2][2 * q] + red_u[3][2 * q];
+        o.uni = red_u[0][2 * q + 1] + red_u[1][2 * q + 1] + red_u[2][2 * q + 1] + red_u[3][2 * q + 1];
+        qslot[q] = o;
+    }
+    if (threadIdx.x == 0) {
+        GtStats o;
+        o.sum_g = red_g[0][0] + red_g[1][0] + red_g[2][0] + red_g[3][0];
+        o.sum_gx = red_g[0][1] + red_g[1][1] + red_g[2][1] + red_g[3][1];
+        o.sum_gy = red_g[0][2] + red_g[1][2] + red_g[2][2] + red_g[3][2];
+        *gslot = o;
+    }
+}
+
+// K1b: sum the per-chunk partials of an image (one thread per query)
+__global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
+                                                               QueryStats* qs, GtStats* gs, int nchunk) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    if (t < a.nq) {
+        QueryStats o; o.inter = 0; o.uni = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const QueryStats p = qpart[((int64_t)b * nchunk + c) * a.nq + t];
+            o.inter += p.inter; o.uni += p.uni;
+        }
+        qs[b * a.nq + t] = o;
+    }
+    if (t == 63) {
+        GtStats o; o.sum_g = 0; o.sum_gx = 0; o.sum_gy = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            const GtStats p = gpart[(int64_t)b * nchunk + c];
+            o.sum_g += p.sum_g; o.sum_gx += p.sum_gx; o.sum_gy += p.sum_gy;
+        }
+        gs[b] = o;
+    }
 }
 
 // selection (evaluator.pyc@L216-221): which = 0 arg-max objectness, which = 1 arg-max IoU (first maximum)
@@ -217,6 +311,9 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     double* slot = part + ((int64_t)(b * 2 + which) * nchunk + c) * EV_NACC;
     if (base >= npx) {
         if (tid < EV_NACC && tid > 0) slot[tid] = 0.0;
+        MetricCounts* mz = cnt + ((int64_t)(b * 2 + which) * nchunk + c);
+        if (tid < 6) (&mz->tp5)[tid] = 0;
+        mz->hist[0][tid] = 0; mz->hist[1][tid] = 0;
         return;
     }
     if (tid == 0) {
@@ -247,20 +344,31 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     //      20,21 = bg {sum (1-p), sum (1-p)^2}
     for (int k = 0; k < EV_PPT; ++k) {
         const int idx = base + k * EV_THREADS + tid;
-        if (idx >= npx) break;
-        int y, x;
-        split_idx(idx, im.W, inv_w, y, x);
-        const float p = up_sample(m, a.mw, up_index(y, sy, a.mh), up_index(x, sx, a.mw));
-        const unsigned g = gt[idx] != 0, b5 = p > 0.5f, ba = p > thr_adapt;
-        tp5 += b5 & g; np5 += b5; ng += g; eq5 += (b5 == g); tpa += ba & g; npa += ba;
+        const bool valid = idx < npx;
+        if (__ballot(valid) == 0) break;  // wave-uniform exit: the ballots below need every lane here
+        int y = 0, x = 0;
+        float p = 0.f;
+        unsigned g = 0;
+        if (valid) {
+            split_idx(idx, im.W, inv_w, y, x);
+            p = up_sample(m, a.mw, up_index(y, sy, a.mh), up_index(x, sx, a.mw));
+            g = gt[idx] != 0;
+        }
+        const unsigned b5 = valid && p > 0.5f, ba = valid && p > thr_adapt;
+        g = valid ? g : 0;
+        tp5 += b5 & g; np5 += b5; ng += g; eq5 += (valid && b5 == g); tpa += ba & g; npa += ba;
         const float gf = (float)g;
-        acc[1] += (double)fabsf(p - gf);
+        if (valid) acc[1] += (double)fabsf(p - gf);
         // number of thresholds strictly below p: start from floor(p*255) and correct (the table is ascending, ~k/255)
         int lo = (int)(p * 255.0f);
         lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
         while (lo > 0 && !(thr[lo - 1] < p)) --lo;
         while (lo < 255 && thr[lo] < p) ++lo;
-        atomicAdd(&hist[g][lo], 1u);
+        // LDS histogram split by GT.  (Tried and rejected, measured on the B=64 bench: ballot-counting the saturated bins
+        // 0/255 is neutral, peeling one distinct key per round with ballots is 1.5x SLOWER - bilinear ramps put ~50
+        // distinct bins into a 64-pixel wave.)
+        if (valid) atomicAdd(&hist[g][lo], 1u);
+        if (!valid) continue;
         const double pd = (double)p, gd = (double)gf;
         const int quad = (y >= Y ? 2 : 0) + (x >= X ? 1 : 0);
 #pragma unroll
@@ -277,31 +385,68 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     }
     tp5 = wave_total(tp5); np5 = wave_total(np5); ng = wave_total(ng); eq5 = wave_total(eq5);
     tpa = wave_total(tpa); npa = wave_total(npa);
-    MetricCounts* mc = cnt + (b * 2 + which);
-    if (lane == 0) {
-        atomicAdd(&mc->tp5, tp5); atomicAdd(&mc->np5, np5); atomicAdd(&mc->ng, ng); atomicAdd(&mc->eq5, eq5);
-        atomicAdd(&mc->tpa, tpa); atomicAdd(&mc->npa, npa);
-    }
+    __shared__ unsigned redc[EV_THREADS / 64][6];
+    if (lane == 0) { redc[wv][0] = tp5; redc[wv][1] = np5; redc[wv][2] = ng; redc[wv][3] = eq5; redc[wv][4] = tpa; redc[wv][5] = npa; }
     __syncthreads();
+    // per-chunk partial counts + histogram, plain stores (K4 sums them): no same-line atomic storms
+    MetricCounts* mc = cnt + ((int64_t)(b * 2 + which) * nchunk + c);
     if (tid > 0 && tid < EV_NACC) slot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (hist[0][tid]) atomicAdd(&mc->hist[0][tid], hist[0][tid]);
-    if (hist[1][tid]) atomicAdd(&mc->hist[1][tid], hist[1][tid]);
+    if (tid < 6) (&mc->tp5)[tid] = redc[0][tid] + redc[1][tid] + redc[2][tid] + redc[3][tid];
+    mc->hist[0][tid] = hist[0][tid];
+    mc->hist[1][tid] = hist[1][tid];
 }
 
-// K4: finalise the 7 metrics of (image, which) with the reference's fp32 operation order
-__global__ __launch_bounds__(64) void eval_finalize_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs,
-                                                           const double* part, const MetricCounts* cnt, int nchunk) {
-    const int which = blockIdx.x, b = blockIdx.y;
-    if (threadIdx.x != 0) return;
+// K4: finalise the 7 metrics of (image, which) with the reference's fp32 operation order; 256 threads: fixed-order
+// partial sums, suffix sums of the histogram and the 255 F-measures in parallel, the scalar tail on thread 0
+__global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs,
+                                                            const double* part, const MetricCounts* cnt, int nchunk) {
+    __shared__ double accs[EV_NACC];
+    __shared__ unsigned s_tp[257], s_np[257];
+    __shared__ float s_f[256];
+    const int which = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W;
-    const MetricCounts& mc = cnt[b * 2 + which];
+    const MetricCounts* mcp = cnt + (int64_t)(b * 2 + which) * nchunk;
+    __shared__ unsigned h0[256], h1[256], cts[6];
+    {
+        unsigned s0 = 0, s1 = 0;
+        for (int c = 0; c < nchunk; ++c) { s0 += mcp[c].hist[0][tid]; s1 += mcp[c].hist[1][tid]; }
+        h0[tid] = s0; h1[tid] = s1;
+        if (tid < 6) {
+            unsigned v = 0;
+            for (int c = 0; c < nchunk; ++c) v += (&mcp[c].tp5)[tid];
+            cts[tid] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < EV_NACC) {
+        const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC + tid;
+        double sacc = 0.0;
+        for (int c = 0; c < nchunk; ++c) sacc += p0[(int64_t)c * EV_NACC];  // chunk order: deterministic
+        accs[tid] = sacc;
+    }
+    // suffix sums: s_tp[k] = sum_{b > k} hist1[b], s_np[k] = sum_{b > k} (hist0 + hist1)[b]   (k = tid)
+    s_tp[tid] = tid < 255 ? h1[tid + 1] : 0u;
+    s_np[tid] = tid < 255 ? h0[tid + 1] + h1[tid + 1] : 0u;
+    if (tid == 0) { s_tp[256] = 0; s_np[256] = 0; }
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const unsigned t1 = tid + o < 256 ? s_tp[tid + o] : 0u, t2 = tid + o < 256 ? s_np[tid + o] : 0u;
+        __syncthreads();
+        s_tp[tid] += t1; s_np[tid] += t2;
+        __syncthreads();
+    }
+    const unsigned ng = cts[2];
+    s_f[tid] = tid < 255 ? f_measure_from_counts(s_tp[tid], s_np[tid], ng) : -INFINITY;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) s_f[tid] = fmaxf(s_f[tid], s_f[tid + o]);
+        __syncthreads();
+    }
+    if (tid != 0) return;
     double acc[EV_NACC];
-    for (int k = 0; k < EV_NACC; ++k) acc[k] = 0.0;
-    const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
-    for (int c = 0; c < nchunk; ++c)
-        for (int k = 0; k < EV_NACC; ++k) acc[k] += p0[(int64_t)c * EV_NACC + k];
-    const unsigned tp5 = mc.tp5, np5 = mc.np5, ng = mc.ng, eq5 = mc.eq5, tpa = mc.tpa, npa = mc.npa;
+    for (int k = 0; k < EV_NACC; ++k) acc[k] = accs[k];
+    const unsigned tp5 = cts[0], np5 = cts[1], eq5 = cts[3], tpa = cts[4], npa = cts[5];
     const GtStats g0 = gs[b];
     const int X = (int)rintf(SM_DIV((float)g0.sum_gx, (float)g0.sum_g)), Y = (int)rintf(SM_DIV((float)g0.sum_gy, (float)g0.sum_g));
     const int q = select_query(a, qs, b, which, false);
@@ -311,15 +456,7 @@ __global__ __launch_bounds__(64) void eval_finalize_kernel(sm_eval_args a, const
     row[0] = SM_DIV((float)tp5, SM_ADD((float)(np5 + ng - tp5), 1e-7f));   // iou.py:28-31
     row[1] = SM_DIV((float)eq5, N);                                             // pixel_acc.py:14
     row[2] = f_measure_from_counts(tp5, np5, ng);                                  // f_measure.py:44-50
-    {   // F-max over the 255 thresholds: pixels above threshold k are those in bins > k (suffix sums)
-        unsigned tp = 0, np = 0;
-        float best = -INFINITY;
-        for (int k = 254; k >= 0; --k) {
-            tp += mc.hist[1][k + 1]; np += mc.hist[0][k + 1] + mc.hist[1][k + 1];
-            best = fmaxf(best, f_measure_from_counts(tp, np, ng));
-        }
-        row[3] = best;
-    }
+    row[3] = s_f[0];                                                               // f_measure.py:52-69
     row[4] = f_measure_from_counts(tpa, npa, ng);                                  // f_measure.py:71-81
     row[5] = (float)(acc[1] / (double)npx);                                        // mae.py:9
     {   // S-measure (s_measure.py:105-124)
@@ -350,30 +487,30 @@ __global__ __launch_bounds__(64) void eval_finalize_kernel(sm_eval_args a, const
     a.rows[(int64_t)b * 16 + 14 + which] = (float)q;
 }
 
-struct EvalWs { QueryStats* qs; GtStats* gs; MetricCounts* cnt; double* part; size_t zero_bytes, total; };
+struct EvalWs { QueryStats *qs, *qpart; GtStats *gs, *gpart; MetricCounts* cnt; double* part; float* maskT; size_t total; };
 
-static EvalWs carve_eval(int B, int nq, int nchunk, char* base) {
+static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
     EvalWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
-    // the first three regions are accumulated with atomics: zeroed by ONE memset node ahead of the launches
     w.qs = (QueryStats*)take((size_t)B * nq * sizeof(QueryStats));
     w.gs = (GtStats*)take((size_t)B * sizeof(GtStats));
-    w.cnt = (MetricCounts*)take((size_t)B * 2 * sizeof(MetricCounts));
-    w.zero_bytes = off;
+    w.qpart = (QueryStats*)take((size_t)B * nchunk * nq * sizeof(QueryStats));
+    w.gpart = (GtStats*)take((size_t)B * nchunk * sizeof(GtStats));
+    w.cnt = (MetricCounts*)take((size_t)B * 2 * nchunk * sizeof(MetricCounts));
     w.part = (double*)take((size_t)B * 2 * nchunk * EV_NACC * sizeof(double));
+    w.maskT = (float*)take((size_t)B * plane * EV_QS * sizeof(float));
     w.total = off;
     return w;
 }
 
 }  // namespace sm
 
-// workspace is sized for the largest supported ground truth (1024 x 1024 pixels per image)
-static const int SM_EVAL_MAX_PIXELS = 1 << 20;
+static const int SM_EVAL_MAX_PIXELS = 1 << 22;
 
-extern "C" size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq) {
-    if (B <= 0 || nq <= 0 || nq > sm::EV_MAXQ) return 0;
-    return sm::carve_eval(B, nq, SM_EVAL_MAX_PIXELS / sm::EV_CHUNK, nullptr).total;
+extern "C" size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq, int32_t mh, int32_t mw, int32_t max_pixels) {
+    if (B <= 0 || nq <= 0 || nq > sm::EV_MAXQ || mh <= 0 || mw <= 0 || max_pixels <= 0 || max_pixels > SM_EVAL_MAX_PIXELS) return 0;
+    return sm::carve_eval(B, nq, (max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK, mh * mw, nullptr).total;
 }
 
 extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
@@ -381,21 +518,22 @@ extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
                "sm_evaluate_masks_f32: null pointer");
     SM_REQUIRE(a->B > 0 && a->nq > 0 && a->nq <= sm::EV_MAXQ && a->mh > 0 && a->mw > 0 && a->scale >= 0.f,
                "sm_evaluate_masks_f32: bad shape (nq <= %d)", sm::EV_MAXQ);
+    SM_REQUIRE(a->mw <= 128, "sm_evaluate_masks_f32: mask width %d > 128 (LDS tap staging)", a->mw);
     SM_REQUIRE(a->max_pixels > 0 && a->max_pixels <= SM_EVAL_MAX_PIXELS,
                "sm_evaluate_masks_f32: max_pixels=%d (largest H*W of the batch, <= %d)", a->max_pixels, SM_EVAL_MAX_PIXELS);
-    SM_REQUIRE(a->workspace_bytes >= sm_evaluate_workspace_bytes(a->B, a->nq) && ((uintptr_t)a->workspace % 256) == 0,
+    SM_REQUIRE(a->workspace_bytes >= sm_evaluate_workspace_bytes(a->B, a->nq, a->mh, a->mw, a->max_pixels) &&
+                   ((uintptr_t)a->workspace % 256) == 0,
                "sm_evaluate_masks_f32: workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = (a->max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK;
-    const sm::EvalWs w = sm::carve_eval(a->B, a->nq, SM_EVAL_MAX_PIXELS / sm::EV_CHUNK, (char*)a->workspace);
-    if (hipMemsetAsync(a->workspace, 0, w.zero_bytes, st) != hipSuccess) {
-        sm::set_error("sm_evaluate_masks_f32: hipMemsetAsync failed");
-        return SM_ELAUNCH;
-    }
-    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.gs);
+    const sm::EvalWs w = sm::carve_eval(a->B, a->nq, nchunk, a->mh * a->mw, (char*)a->workspace);
+    hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B), dim3(256), 0, st, *a, w.maskT);
+    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B), dim3(sm::EV_THREADS),
+                       (size_t)sm::EV_LDS_ROWS * a->mw * sm::EV_QS * sizeof(float), st, *a, w.maskT, w.qpart, w.gpart, nchunk);
+    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(64), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, nchunk);
     hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.part, nchunk);
     hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.gs, w.part,
                        w.cnt, nchunk);
-    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.qs, w.gs, w.part, w.cnt, nchunk);
+    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(256), 0, st, *a, w.qs, w.gs, w.part, w.cnt, nchunk);
     return sm::check_launch("sm_evaluate_masks_f32");
 }

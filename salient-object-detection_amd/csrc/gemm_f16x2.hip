@@ -148,14 +148,16 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
 
+    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only builds: 2 = no MFMA, 3 = no DMA in the loop
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt_h<(NST - 2) * NI>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (ablate != 3) {
             const int nt = kt + NST - 1;
             issue(nt < nk ? nt : nk - 1, nt % NST);
         }
+        if (ablate == 2) continue;
         const char* st = smemh + (kt % NST) * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -287,6 +289,7 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
                    "sm_gemm_f16x2: bad split_k");
     sm_gemm_args a = *g;
     if (out_f16x2) a.patch_n = -1;
+    if (const char* ab = getenv("SM_F16X2_ABLATE")) a.patch_n = -atoi(ab);  // timing-only (wrong results)
     hipStream_t st = (hipStream_t)stream;
     // Pipeline depth: this kernel is bound by bytes in flight per CU (L2 -> LDS latency ~1.7 us under load), so the
     // depths below keep 48 KiB of LDS per workgroup = three workgroups per CU (scripts/gemm_f16x2_sweep.py).

@@ -113,7 +113,7 @@ SYMBOLS = {
     "sm_upsample2x_tokens_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
-    "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "sm_bilateral_solver_f64": (C.c_int, [C.POINTER(BilateralArgs), fp]),

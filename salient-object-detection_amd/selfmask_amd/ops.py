@@ -234,7 +234,10 @@ def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, 
     rows = torch.empty((B, 16), device=dev, dtype=torch.float32)
     ious = torch.empty((B, nq), device=dev, dtype=torch.float32) if return_ious else None
     lib = N.load()
-    wsb = lib.sm_evaluate_workspace_bytes(B, nq)
+    max_pixels = max(h * w for (h, w) in gb.shapes)
+    wsb = lib.sm_evaluate_workspace_bytes(B, nq, mh, mw, max_pixels)
+    if wsb == 0:
+        raise ValueError("unsupported evaluate_masks shape")
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     a = N.EvalArgs()
     a.mask_pred, a.mask_stride_b = mask_pred_last.data_ptr(), mask_pred_last.stride(0)
@@ -242,6 +245,6 @@ def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, 
     a.gt, a.images, a.thresholds = gb.gt_all.data_ptr(), gb.images.data_ptr(), f_max_thresholds(dev).data_ptr()
     a.rows, a.ious, a.workspace, a.workspace_bytes = rows.data_ptr(), _ptr(ious), ws.data_ptr(), wsb
     a.B, a.nq, a.mh, a.mw, a.scale = B, nq, mh, mw, float(scale)
-    a.max_pixels = max(h * w for (h, w) in gb.shapes)
+    a.max_pixels = max_pixels
     N.check(lib.sm_evaluate_masks_f32(a, _stream()), "sm_evaluate_masks_f32")
     return (rows, ious) if return_ious else rows
