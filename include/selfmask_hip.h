@@ -139,6 +139,10 @@ typedef struct sm_attn_args {
     int32_t out_f16x2; /* != 0: O is written in the F16X2 split format (it only feeds the next projection GEMM) */
 } sm_attn_args;
 int sm_attention_f32(const sm_attn_args* args, void* stream);
+/* Same operation with Q, K and V given in the F16X2 split format (as sm_gemm_f16x2 writes them with out_f16x2 = 1):
+ * three f16 MFMAs per product (hi*hi, hi*lo, lo*hi), probabilities split in registers - fp32-grade results at several
+ * times the fp32 MFMA rate. Strides/pointers in float units, multiples of 8 (one F16X2 group), 32-B aligned. */
+int sm_attention_f16x2(const sm_attn_args* args, void* stream);
 
 /* im2col of non-overlapping PxP patches with zero padding to a multiple of P (make_input_divisible,
  * vision_transformer.py:260-267; PatchEmbed conv :182-188): img (B,3,H,W) -> cols (B*gh*gw, 3*P*P), k=(c,i,j). */

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libselfmask_hip.so")
-SOURCES = ["gemm.hip", "gemm_f16x2.hip", "layernorm.hip", "attention.hip", "misc.hip", "eval.hip", "bilateral.hip", "forward.hip"]
+SOURCES = ["gemm.hip", "gemm_f16x2.hip", "layernorm.hip", "attention.hip", "attention_f16x2.hip", "misc.hip", "eval.hip", "bilateral.hip", "forward.hip"]
 
 
 def _hipcc() -> str:

@@ -89,6 +89,30 @@ __device__ __forceinline__ void store_f16x2_2(void* row, int64_t k, float x0, fl
     *reinterpret_cast<f16x2*>(p + 16) = lo;
 }
 
+// Lanes l and l^32 each hold elements 4h..4h+3 (h = l >> 5) of two consecutive 8-element groups: x of group G, y of
+// group G+1 (the 32x32 accumulator layout).  One v_permlane32_swap per register later lane h owns ALL of group G+h
+// (x = elements 0..3, y = elements 4..7), so an F16X2 group leaves as one contiguous 32-B store instead of four 8-B ones.
+__device__ __forceinline__ void pair_groups(float (&x)[4], float (&y)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[e]), __float_as_uint(y[e]), false, false);
+        x[e] = __uint_as_float(sw[0]);
+        y[e] = __uint_as_float(sw[1]);
+    }
+}
+// store the 8 elements k..k+7 (k % 8 == 0) of an F16X2 row: x = elements 0..3, y = elements 4..7
+__device__ __forceinline__ void store_f16x2_8(void* row, int64_t k, const float (&x)[4], const float (&y)[4]) {
+    f16x4 h0, l0, h1, l1;
+    split4(x, h0, l0);
+    split4(y, h1, l1);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = h0[e]; hi[4 + e] = h1[e]; lo[e] = l0[e]; lo[4 + e] = l1[e]; }
+    char* p = reinterpret_cast<char*>(row) + k * 4;
+    *reinterpret_cast<f16x8*>(p) = hi;
+    *reinterpret_cast<f16x8*>(p + 16) = lo;
+}
+
 // row of a 32x32 MFMA accumulator held in register v by lane-half h  (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 

@@ -88,6 +88,11 @@ static int linear(const Ctx& c, const float* A, int lda, const float* W, const f
 static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s = false) {
     return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
 }
+// in split mode Q, K and V are F16X2 (written so by the projection GEMMs) and the f16 matrix cores do the work
+static int attn(const Ctx& c, sm_attn_args& a) {
+    a.out_f16x2 = c.S;
+    return c.S ? sm_attention_f16x2(&a, c.st) : sm_attention_f32(&a, c.st);
+}
 
 struct LnOpt {
     sm_row_map in_map = {0, 0, 0}, out_map = {0, 0, 0};
@@ -149,13 +154,13 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         LnOpt xs;
         xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
         TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
-        TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0));
+        TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
         sm_attn_args a = {};
         a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
         a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
         a.sOb = (int64_t)s.N * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f; a.out_f16x2 = S;
-        TRY(sm_attention_f32(&a, st));
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
+        TRY(attn(c, a));
         TRY(linear(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
         TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
@@ -191,7 +196,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // cross-attention keys/values of every layer depend only on the encoder memory: one large GEMM
     // (B*n x 384) x (384 x L*768) instead of L small ones on the critical chain
     const int KVW = s.L * 2 * D;
-    TRY(linear(c, tok_a, D, w->dec_kv_w, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0));
+    TRY(linear(c, tok_a, D, w->dec_kv_w, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0, S));
     for (int l = 0; l < s.L; ++l) {
         const sm_dec_layer& d = w->dec[l];
         const float* tgt_a = S ? ws.TGTs : ws.TGT;  // GEMM-operand view of tgt (TGT / T2 swap roles every layer)
@@ -200,14 +205,14 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
             sm_gemm_args g = {};
             g.A = ws.TGTQ; g.A_alt = tgt_a; g.alt_from_n = 2 * D; g.W = d.sa_in_w; g.bias = d.sa_in_b; g.C = ws.QK;
             g.M = (int)s.Md; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * D; g.batch = 1; g.epilogue = SM_EPI_BIAS;
-            TRY(gemm(c, g));
+            TRY(gemm(c, g, S));
         }
         sm_attn_args a = {};
         a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.QK + 2 * D; a.O = ws.AOd;
         a.sQb = a.sKb = a.sVb = (int64_t)s.nq * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f; a.out_f16x2 = S;
-        TRY(sm_attention_f32(&a, st));
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
+        TRY(attn(c, a));
         TRY(linear(c, ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
         {
             LnOpt o;  // norm1 -> tgt (fp32: residual of the next block) + tgt + query_pos (cross-attention query operand)
@@ -215,13 +220,13 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
             TRY(ln(c, ws.T2, d.norm1_w, d.norm1_b, ws.TGT, s.Md, 1e-5f, o));
         }
         // cross-attention: q = tgt + query_pos, k = v = memory (pos = None)
-        TRY(linear(c, ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0));
+        TRY(linear(c, ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, S));
         a = {};
         a.Q = ws.Qc; a.K = ws.KV + (int64_t)l * 2 * D; a.V = a.K + D; a.O = ws.AOd;
         a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * KVW; a.sKr = a.sVr = KVW;
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f; a.out_f16x2 = S;
-        TRY(sm_attention_f32(&a, st));
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
+        TRY(attn(c, a));
         TRY(linear(c, ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
         {
             LnOpt o;  // norm2 -> tgt (residual of the FFN) (+ F16X2 copy: operand of linear1)

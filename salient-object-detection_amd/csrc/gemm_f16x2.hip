@@ -197,17 +197,41 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
             if (m >= M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                if constexpr (F) {
+                    // F16X2 output: lanes l / l^32 trade halves so each writes one whole 32-B group (N % 8 == 0)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * h;
-                    if (n >= N) continue;
-                    float val[4];
+                    for (int q = 0; q < 4; q += 2) {
+                        float x[4], y[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float b = g.bias ? g.bias[n + e] : 0.f;
-                        val[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + b;
+                        for (int e = 0; e < 4; ++e) {
+                            const int nx = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * h + e, ny = nx + 8;
+                            x[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
+                            y[e] = (acc[i][j][4 * q + 4 + e] + crs[i][j][4 * q + 4 + e] * (1.0f / 2048.0f)) + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
+                            if constexpr (EPI == SM_EPI_GELU) {
+                                x[e] = 0.5f * x[e] * (1.0f + erff(x[e] * 0.70710678118654752440f));
+                                y[e] = 0.5f * y[e] * (1.0f + erff(y[e] * 0.70710678118654752440f));
+                            } else if constexpr (EPI == SM_EPI_RELU) {
+                                x[e] = fmaxf(x[e], 0.f);
+                                y[e] = fmaxf(y[e], 0.f);
+                            }
+                        }
+                        pair_groups(x, y);
+                        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * (q + h);
+                        if (n < N) store_f16x2_8(C + (int64_t)m * g.ldc, n, x, y);
                     }
-                    store4<EPI, F>(g, C, bz, m, n, val);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * h;
+                        if (n >= N) continue;
+                        float val[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float b = g.bias ? g.bias[n + e] : 0.f;
+                            val[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + b;
+                        }
+                        store4<EPI, false>(g, C, bz, m, n, val);
+                    }
                 }
             }
         }

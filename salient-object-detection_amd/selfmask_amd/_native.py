@@ -107,6 +107,7 @@ SYMBOLS = {
     "sm_layernorm_rows_f32": (C.c_int, [C.POINTER(LnArgs), fp]),
     "sm_broadcast_rows_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_attention_f32": (C.c_int, [C.POINTER(AttnArgs), fp]),
+    "sm_attention_f16x2": (C.c_int, [C.POINTER(AttnArgs), fp]),
     "sm_im2col_patches_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_cls_rows_f32": (C.c_int, [fp, fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_pos_embed_bicubic_f32": (C.c_int, [fp, C.c_int32, fp, C.c_int32, C.c_int32, fp]),

@@ -125,11 +125,15 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return (y, y2) if add is not None else y
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 0.125) -> torch.Tensor:
-    """q (B,Nq,H,64), k/v (B,Nk,H,64) views (last two dims contiguous) -> (B,Nq,H*64)."""
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 0.125, split: bool = False) -> torch.Tensor:
+    """q (B,Nq,H,64), k/v (B,Nk,H,64) views (last two dims contiguous) -> (B,Nq,H*64).
+    split=True: the operands are first converted to F16X2 rows and sm_attention_f16x2 (f16 matrix cores) runs."""
     _dev(q, k, v)
     B, nq, H, dh = q.shape
     nk = k.shape[1]
+    if split:  # F16X2 images of the (B, N, H*64) rows; the (B,N,H,64) view keeps float-unit strides
+        q, k, v = (split_f16x2(t.reshape(t.shape[0], t.shape[1], H * dh).contiguous()).view(t.shape[0], t.shape[1], H, dh)
+                   for t in (q, k, v))
     assert dh == 64 and q.stride(3) == 1 and q.stride(2) == 64 and k.stride(2) == 64 and v.stride(2) == 64
     o = torch.empty((B, nq, H * dh), device=q.device, dtype=torch.float32)
     a = N.AttnArgs()
@@ -137,7 +141,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 
     a.sQb, a.sQr, a.sKb, a.sKr, a.sVb, a.sVr = q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1)
     a.sOb, a.sOr = o.stride(0), o.stride(1)
     a.batch, a.heads, a.n_q, a.n_k, a.scale = B, H, nq, nk, scale
-    N.check(N.load().sm_attention_f32(a, _stream()), "sm_attention_f32")
+    if split:
+        N.check(N.load().sm_attention_f16x2(a, _stream()), "sm_attention_f16x2")
+    else:
+        N.check(N.load().sm_attention_f32(a, _stream()), "sm_attention_f32")
     return o
 
 

@@ -151,24 +151,26 @@ def _attn_ref(q, k, v, scale):
 
 @pytest.mark.parametrize("B,nq,nk", [(2, 197, 197), (1, 785, 785), (1, 577, 577), (3, 20, 20), (3, 20, 196), (2, 20, 784),
                                       (1, 1, 1), (1, 33, 225)])
-def test_attention_shapes(B, nq, nk):
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_shapes(B, nq, nk, split):
     qkv = _rand(B, max(nq, nk), 3, 6, 64, seed=30, scale=1.5).to(DEV)
     q, k, v = qkv[:, :nq, 0], qkv[:, :nk, 1], qkv[:, :nk, 2]  # strided views like the packed qkv buffer
-    o = ops.attention(q, k, v, 0.125)
+    o = ops.attention(q, k, v, 0.125, split=split)
     ref = _attn_ref(q.cpu(), k.cpu(), v.cpu(), 0.125)
     ref32 = F.scaled_dot_product_attention(q.cpu().transpose(1, 2), k.cpu().transpose(1, 2), v.cpu().transpose(1, 2),
                                            scale=0.125).transpose(1, 2).reshape(B, nq, -1)
     assert _maxerr(o, ref) <= max(1e-5, 3 * _maxerr(ref32, ref))
 
 
-def test_attention_online_softmax_rescale_branch():
+@pytest.mark.parametrize("split", [False, True])
+def test_attention_online_softmax_rescale_branch(split):
     """Force the running-max rescale between 224-key chunks: the global max sits in the LAST chunk (rule: a rare
     data-dependent branch needs an input that takes it)."""
     B, n = 1, 500
     q, k, v = _rand(B, n, 6, 64, seed=31), _rand(B, n, 6, 64, seed=32), _rand(B, n, 6, 64, seed=33)
     k[:, 470] = q[:, 5] * 4.0  # spike: key 470 (third chunk) dominates query 5
     k[:, 3] = q[:, 100] * 3.0  # and a first-chunk spike for another row
-    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0.125)
+    o = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), 0.125, split=split)
     assert _maxerr(o, _attn_ref(q, k, v, 0.125)) <= 5e-6
 
 
