@@ -41,7 +41,7 @@ template <int EPI, bool OUT_F16X2>
 __device__ __forceinline__ void store4(const sm_gemm_args& g, float* C, int64_t bz, int m, int n, float (&val)[4]) {
     if constexpr (EPI == SM_EPI_GELU) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) val[i] = 0.5f * val[i] * (1.0f + erff(val[i] * 0.70710678118654752440f));
+        for (int i = 0; i < 4; ++i) val[i] = 0.5f * val[i] * (1.0f + fast_erff(val[i] * 0.70710678118654752440f));
     } else if constexpr (EPI == SM_EPI_RELU) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
@@ -67,17 +67,22 @@ __device__ __forceinline__ void store4(const sm_gemm_args& g, float* C, int64_t 
     }
 }
 
-template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int A_INST = BM / 32, W_INST = BN / 32;
+// NWM x NWN waves per workgroup, each owning a (BM/NWM) x (BN/NWN) block of the tile as TM x TN 32x32 accumulators.
+// The kernel is fed from L2 at a roughly fixed rate per CU (~50 GB/s measured), so what a tile shape buys is MACs per
+// byte staged: BM*BN/(BM+BN) - 43 for 128x64, 85 for 256x128.
+template <int BM, int BN, int NST, int NWM, int NWN, int MINB>
+__global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gemm_args g) {
+    constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_INST = BM / 8 / NW, W_INST = BN / 8 / NW;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) per wave and stage
+    static_assert(A_INST * 8 * NW == BM && W_INST * 8 * NW == BN && TM * 32 * NWM == BM && TN * 32 * NWN == BN, "tile split");
     constexpr int NI = A_INST + W_INST;
     constexpr int STAGE = (BM + BN) * 128;  // bytes per stage (128 B per row per 32-k tile)
     extern __shared__ __attribute__((aligned(16))) char smemh[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int r = lane & 31, h = lane >> 5;
     // XCD-aware tile order (1-D grid): workgroups are dealt round-robin over the 8 XCDs (id % 8 labels the XCD, each
     // with a private 4 MiB L2).  Give every XCD a CONTIGUOUS range of logical tiles (m-tile major, n-tile minor) so all
@@ -134,8 +139,8 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
         off_hi[s] = ((2 * (2 * s + h)) ^ swz) * 16;
         off_lo[s] = ((2 * (2 * s + h) + 1) ^ swz) * 16;
     }
-    const int a_row = (wm * (BM / 2) + r) * 128;
-    const int w_row = BM * 128 + (wn * (BN / 2) + r) * 128;
+    const int a_row = (wm * WTM + r) * 128;
+    const int w_row = BM * 128 + (wn * WTN + r) * 128;
 
     f32x16 acc[TM][TN], crs[TM][TN];
 #pragma unroll
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
 
-    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only builds: 2 = no MFMA, 3 = no DMA in the loop
+    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only runs: 2 = no MFMA, 3 = no DMA in the loop, 4 = no epilogue
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt_h<(NST - 2) * NI>();
         __builtin_amdgcn_s_barrier();
@@ -159,32 +164,38 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
         }
         if (ablate == 2) continue;
         const char* st = smemh + (kt % NST) * STAGE;
+        // all fragment reads of the stage are issued up front: the second 16-k step's reads land under the first
+        // step's MFMAs (LDS returns in order, so the compiler waits with a counted lgkmcnt for the first half only)
+        f16x8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_hi[s]);
-                al[i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_lo[s]);
+                ah[s][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_hi[s]);
+                al[s][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_lo[s]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                wh[j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_hi[s]);
-                wl[j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_lo[s]);
+                wh[s][j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_hi[s]);
+                wl[s][j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_lo[s]);
             }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     // D[n][m]: weights are the MFMA A operand (rows = n), activations the B operand (cols = m)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
-                    crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], crs[i][j], 0, 0, 0);
-                    crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], crs[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], ah[s][i], acc[i][j], 0, 0, 0);
+                    crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], al[s][i], crs[i][j], 0, 0, 0);
+                    crs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s][j], ah[s][i], crs[i][j], 0, 0, 0);
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     wait_vmcnt_h<0>();
+    if (ablate == 4) return;  // timing-only: no epilogue
 
     float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : bz) * g.strideC;
     const bool out_split = g.patch_n < 0;  // out-format flag travels in the sign of patch_n for non-PATCH epilogues
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
         constexpr bool F = decltype(fmt_tag)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 32 + r;
+            const int m = m0 + wm * WTM + i * 32 + r;
             if (m >= M) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -204,25 +215,25 @@ __global__ __launch_bounds__(256) void gemm_f16x2_kernel(sm_gemm_args g) {
                         float x[4], y[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const int nx = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * h + e, ny = nx + 8;
+                            const int nx = n0 + wn * WTN + j * 32 + 8 * q + 4 * h + e, ny = nx + 8;
                             x[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
                             y[e] = (acc[i][j][4 * q + 4 + e] + crs[i][j][4 * q + 4 + e] * (1.0f / 2048.0f)) + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
                             if constexpr (EPI == SM_EPI_GELU) {
-                                x[e] = 0.5f * x[e] * (1.0f + erff(x[e] * 0.70710678118654752440f));
-                                y[e] = 0.5f * y[e] * (1.0f + erff(y[e] * 0.70710678118654752440f));
+                                x[e] = 0.5f * x[e] * (1.0f + fast_erff(x[e] * 0.70710678118654752440f));
+                                y[e] = 0.5f * y[e] * (1.0f + fast_erff(y[e] * 0.70710678118654752440f));
                             } else if constexpr (EPI == SM_EPI_RELU) {
                                 x[e] = fmaxf(x[e], 0.f);
                                 y[e] = fmaxf(y[e], 0.f);
                             }
                         }
                         pair_groups(x, y);
-                        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * (q + h);
+                        const int n = n0 + wn * WTN + j * 32 + 8 * (q + h);
                         if (n < N) store_f16x2_8(C + (int64_t)m * g.ldc, n, x, y);
                     }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * h;
+                        const int n = n0 + wn * WTN + j * 32 + 8 * q + 4 * h;
                         if (n >= N) continue;
                         float val[4];
 #pragma unroll
@@ -263,18 +274,18 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
     }
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int NWM = 2, int NWN = 2, int MINB = 1>
 static int launch_gemm_h(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : g.batch);
     constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, BN, NST>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB>), grid, dim3(NWM * NWN * 64), lds, st, g);
     return check_launch("sm_gemm_f16x2");
 }
 
@@ -315,23 +326,27 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     if (out_f16x2) a.patch_n = -1;
     if (const char* ab = getenv("SM_F16X2_ABLATE")) a.patch_n = -atoi(ab);  // timing-only (wrong results)
     hipStream_t st = (hipStream_t)stream;
-    // Pipeline depth: this kernel is bound by bytes in flight per CU (L2 -> LDS latency ~1.7 us under load), so the
-    // depths below keep 48 KiB of LDS per workgroup = three workgroups per CU (scripts/gemm_f16x2_sweep.py).
+    // Occupancy is what this kernel lives on (scripts/gemm_f16x2_ablate.py): the DMA stream, the MFMA stream and the
+    // epilogue of one workgroup only overlap with those of OTHER workgroups on the CU, so the default shapes are the
+    // ones that fit three workgroups per CU - 48 KiB of LDS and, via __launch_bounds__(256, 3), <= 168 registers
+    // (left alone hipcc spends 109 VGPR + 64 AGPR on the 128x64 tile = two per CU, and the kernel is 25 % slower).
     const char* env = getenv("SM_F16X2_NST");  // tuning knob
     const int nst = env ? atoi(env) : 0;
-    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2>(a, st);
-    if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2>(a, st);
-    if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : sm::launch_gemm_h<64, 64, 3>(a, st);
+    if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
+    if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
+    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2>(a, st);
+    if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2, 2, 2, 3>(a, st);
+    if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 2 ? sm::launch_gemm_h<64, 64, 2, 2, 2, 5>(a, st) : sm::launch_gemm_h<64, 64, 3, 2, 2, 3>(a, st);
     sm::set_error("sm_gemm_f16x2_tile: unsupported tile %dx%d", bm, bn);
     return SM_EINVAL;
 }
 
 extern "C" int sm_gemm_f16x2_pick_tile(const sm_gemm_args* g, int* bm, int* bn, int* nst) {
     SM_REQUIRE(g && bm && bn && nst, "sm_gemm_f16x2_pick_tile: null pointer");
-    // measured on MI355X (B=64 ViT-S/16 shapes): wide outputs (N >= 768) 128x64 (2 stages), everything else 64x64 (3
-    // stages); both are 48 KiB of LDS per workgroup = three workgroups per CU
+    // measured on MI355X (B=64 ViT-S/16 shapes): 128x64 (2 stages) wherever it still yields >= 512 workgroups,
+    // 64x64 (3 stages) for the small decoder GEMMs; both are 48 KiB of LDS = three workgroups per CU
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * (g->split_k > 1 ? g->split_k : g->batch);
-    if (g->N >= 768 && wg128 >= 768) { *bm = 128; *bn = 64; *nst = 2; }
+    if (wg128 >= 512) { *bm = 128; *bn = 64; *nst = 2; }
     else { *bm = 64; *bn = 64; *nst = 3; }
     return SM_OK;
 }

@@ -28,7 +28,7 @@ for name, m, n, k, epi in shapes:
     if r is not None: ref = ref + r.double()
     c32 = ops.gemm(a, w, b, epilogue=epi, residual=r.clone() if r is not None else None)
     line = f"{name:9s} M={m} N={n} K={k} | fp32-mfma err {(c32.double()-ref).abs().max().item():.2e}"
-    for tile in [(128, 128), (128, 64), (64, 64)]:
+    for tile in [(256, 128), (256, 64), (128, 128), (128, 64), (64, 64)]:
         c = ops.gemm_f16x2(a_s, w_s, b, epilogue=epi, residual=r, tile=tile)
         err = (c.double() - ref).abs().max().item()
         c_out = torch.empty(m, n, device="cuda")
