@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .base_structure import BaseStructure
 from .datasets import get_dataset
+from .streams import DEFAULT_STREAMS, StreamRing
 from .distributed import HEADER, KEYS, SingleComm, TorchDistComm, average_rows, gather_rows, shard_indices
 
 
@@ -31,7 +32,7 @@ class Evaluator(BaseStructure):
     @torch.no_grad()
     def __call__(self, dataset_name: str, dir_ckpt: str, img_size: Optional[int] = None, scale_factor: int = 2,
                  batch_size: int = 1, device: torch.device = torch.device("cuda:0"), cost_type: str = "iou",
-                 comm=None) -> dict:
+                 comm=None, streams: int = DEFAULT_STREAMS) -> dict:
         assert cost_type == "iou", "the upper bound is chosen by IoU (evaluator.pyc@L216); other costs are unused"
         if not getattr(self.model, "use_binary_classifier", True):
             raise RuntimeError("the evaluator dereferences objectness unconditionally (evaluator.pyc@L219): "
@@ -49,15 +50,18 @@ class Evaluator(BaseStructure):
         if img_size is None and batch_size != 1:
             raise ValueError("native-resolution evaluation runs at batch_size=1 (images differ in size)")
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
+        ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
         for s in range(0, len(mine), batch_size):
             items = [dataset[i] for i in mine[s:s + batch_size]]
             x = torch.stack([it["x"] for it in items])
-            out = self._forward({"x": x}, device=device)
-            mask_pred, obj = out["mask_pred"], out.get("objectness")
-            if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
-                mask_pred, obj = mask_pred[:, -1], obj[:, -1]
-            gts = [it["m"].squeeze().to(device) for it in items]
-            rows_local[s:s + len(items)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gts, scale=scale)
+            with ring.next():
+                out = self._forward({"x": x}, device=device)
+                mask_pred, obj = out["mask_pred"], out.get("objectness")
+                if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
+                    mask_pred, obj = mask_pred[:, -1], obj[:, -1]
+                gts = [it["m"].squeeze().to(device) for it in items]
+                rows_local[s:s + len(items)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gts, scale=scale)
+        ring.join()
         if self.debug:
             n_total = len(mine) * comm.world_size
             mine = list(range(comm.rank, n_total, comm.world_size))

@@ -156,7 +156,7 @@ class MaskFormer(nn.Module):
             raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'f16x2' or 'fp32'")
         self._table = None       # (Weights struct, key) cache
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
-        self._workspace = {}     # (device, B, H, W) -> uint8 tensor
+        self._workspace = {}     # (device, B, H, W, stream) -> uint8 tensor
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_packed())
         self.eval()
 
@@ -244,13 +244,14 @@ class MaskFormer(nn.Module):
 
     def _get_workspace(self, w: N.Weights, x: torch.Tensor) -> torch.Tensor:
         B, _, H, W = x.shape
-        k = (x.device, B, H, W)
+        # one workspace per (shape, stream): batches in flight on different streams must not share scratch
+        k = (x.device, B, H, W, torch.cuda.current_stream().cuda_stream)
         ws = self._workspace.get(k)
         if ws is None:
             nbytes = N.load().sm_forward_workspace_bytes(w, B, H, W)
             if nbytes == 0:
                 raise RuntimeError("sm_forward_workspace_bytes returned 0 (bad shape)")
-            if len(self._workspace) > 4:  # keep a few shapes resident, not an unbounded set
+            if len(self._workspace) > 8:  # keep a few shapes resident, not an unbounded set
                 self._workspace.clear()
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
             self._workspace[k] = ws
