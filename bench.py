@@ -43,22 +43,22 @@ def forward_flops_per_image(P, S, L=6, nq=20):
 
 
 def forward_gemm_launches(B, P, S, L=6, nq=20):
-    """Every sm_gemm_f32 launch of one MaskFormer.forward:
-    (name, M, N, K, epilogue, batch, launches per forward, split_k)."""
+    """Every GEMM launch of one MaskFormer.forward:
+    (name, M, N, K, epilogue, batch, launches per forward, split_k, F16X2 output in split mode)."""
     from selfmask_amd import _native as Nn
     g = S // P
     n, N = g * g, g * g + 1
     M, Mp, Md, Mo = B * N, B * n, B * nq, B * nq * L
     return [
-        ("patch_embed", Mp, 384, 3 * P * P, Nn.EPI_BIAS, 1, 1, 1),
-        ("enc.qkv", M, 1152, 384, Nn.EPI_BIAS, 1, 12, 1), ("enc.proj", M, 384, 384, Nn.EPI_RESIDUAL, 1, 12, 1),
-        ("enc.fc1", M, 1536, 384, Nn.EPI_GELU, 1, 12, 1), ("enc.fc2", M, 384, 1536, Nn.EPI_RESIDUAL, 1, 12, 1),
-        ("dec.ca_kv_all_layers", Mp, L * 768, 384, Nn.EPI_BIAS, 1, 1, 1),
-        ("dec.sa_qkv", Md, 1152, 384, Nn.EPI_BIAS, 1, L, 1), ("dec.sa_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1),
-        ("dec.ca_q", Md, 384, 384, Nn.EPI_BIAS, 1, L, 1), ("dec.ca_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1),
-        ("dec.lin1", Md, 1536, 384, Nn.EPI_RELU, 1, L, 1), ("dec.lin2_splitk4", Md, 384, 1536, Nn.EPI_BIAS, 1, L, 4),
-        ("mask_einsum", L * nq, 4 * n, 384, Nn.EPI_BIAS, B, 1, 1),
-        ("obj.ffn0", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1), ("obj.ffn1", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1),
+        ("patch_embed", Mp, 384, 3 * P * P, Nn.EPI_BIAS, 1, 1, 1, False),
+        ("enc.qkv", M, 1152, 384, Nn.EPI_BIAS, 1, 12, 1, True), ("enc.proj", M, 384, 384, Nn.EPI_RESIDUAL, 1, 12, 1, False),
+        ("enc.fc1", M, 1536, 384, Nn.EPI_GELU, 1, 12, 1, True), ("enc.fc2", M, 384, 1536, Nn.EPI_RESIDUAL, 1, 12, 1, False),
+        ("dec.ca_kv_all_layers", Mp, L * 768, 384, Nn.EPI_BIAS, 1, 1, 1, True),
+        ("dec.sa_qkv", Md, 1152, 384, Nn.EPI_BIAS, 1, L, 1, True), ("dec.sa_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1, False),
+        ("dec.ca_q", Md, 384, 384, Nn.EPI_BIAS, 1, L, 1, True), ("dec.ca_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1, False),
+        ("dec.lin1", Md, 1536, 384, Nn.EPI_RELU, 1, L, 1, True), ("dec.lin2_splitk4", Md, 384, 1536, Nn.EPI_BIAS, 1, L, 4, False),
+        ("mask_einsum", L * nq, 4 * n, 384, Nn.EPI_BIAS, B, 1, 1, False),
+        ("obj.ffn0", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1, True), ("obj.ffn1", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1, True),
     ]
 
 
@@ -72,13 +72,13 @@ def time_gemm_kernels(B, P, S, mode, iters=3):
     dev = "cuda"
     split_mode = mode == "f16x2"
     groups = {}
-    for name, M, N, K, epi, batch, cnt, split in forward_gemm_launches(B, P, S):
+    for name, M, N, K, epi, batch, cnt, split, osplit in forward_gemm_launches(B, P, S):
         ga = Nn.GemmArgs()
         ga.M, ga.N, ga.K, ga.batch, ga.split_k = M, N, K, batch, split
         bm, bn, nst = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         if split_mode:
             Nn.check(lib.sm_gemm_f16x2_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nst)))
-            kname = f"gemm_f16x2_kernel<{bm.value}, {bn.value}, {nst.value}>"
+            kname = f"gemm_f16x2_kernel<{bm.value}, {bn.value}, {nst.value}, 2, 2, 3>"  # 2x2 waves, 3 workgroups/CU
         else:
             Nn.check(lib.sm_gemm_f32_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn)))
             nst_f32 = {(128, 128): 2, (128, 64): 3, (64, 64): 4}[(bm.value, bn.value)]
@@ -90,16 +90,17 @@ def time_gemm_kernels(B, P, S, mode, iters=3):
         bias = torch.zeros(N, device=dev) if split == 1 else None
         c = torch.empty(max(batch, split), M, N, device=dev)
         r = torch.randn(batch, M, N, device=dev) if epi == Nn.EPI_RESIDUAL else None
-        groups.setdefault((kname, bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch, split, batch))
+        groups.setdefault((kname, bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch, split, osplit))
     out = {}
     for (kname, bm, bn), items in groups.items():
         def run_mix():
-            for name, a, w, bias, c, r, epi, cnt, fl, split, batch in items:
+            for name, a, w, bias, c, r, epi, cnt, fl, split, osplit in items:
                 for _ in range(cnt):
                     if split_mode:
-                        for bi in range(batch):  # the python test wrapper is 2-D; batched launches are replayed per image
-                            ops.gemm_f16x2(a[bi], w[bi], bias, epilogue=epi, residual=None if r is None else r[bi],
-                                           tile=(bm, bn), out=c if split > 1 else c[bi], split_k=split)
+                        batched = a.shape[0] > 1
+                        ops.gemm_f16x2(a if batched else a[0], w if batched else w[0], bias, epilogue=epi,
+                                       residual=None if r is None else (r if batched else r[0]), tile=(bm, bn),
+                                       out=c if (split > 1 or batched) else c[0], split_k=split, out_f16x2=osplit)
                     else:
                         ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn), split_k=split)
         run_mix()
@@ -110,7 +111,7 @@ def time_gemm_kernels(B, P, S, mode, iters=3):
             run_mix()
         e1.record()
         torch.cuda.synchronize()
-        launches = sum(i[7] * (i[10] if split_mode else 1) for i in items)
+        launches = sum(i[7] for i in items)
         flops = sum(i[7] * i[8] for i in items)
         total_s = e0.elapsed_time(e1) * 1e-3 / iters
         out[kname] = {
@@ -156,6 +157,7 @@ def main():
                     help="batches in flight per GPU: step k runs on HIP stream k %% streams (own workspace), so one "
                          "batch's latency-bound decoder / metrics kernels fill CUs beside another's encoder GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="diagnostic: skip the evaluator kernels (not the metric)")
     ap.add_argument("--gemm-mode", default=None, choices=["f16x2", "fp32"], help="GEMM back end (default f16x2)")
     a = ap.parse_args()
 
@@ -196,6 +198,8 @@ def main():
         # one evaluator iteration over a batch (evaluator.pyc@L193-228, batched mode): forward, last decoder
         # layer, up-sample to each GT's size, upper-bound + arg-max-objectness query, 7 metrics x 2 -> 16 floats/image
         out = model(x)
+        if a.forward_only:
+            return out["objectness"][:, -1, :16, 0]
         return ops.evaluate_masks(out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0], gt_batch, scale=0.0)
 
     from selfmask_amd.streams import StreamRing

@@ -10,39 +10,81 @@
 //   O^T = V^T P^T  : V stays row-major [key][d] in LDS exactly as the GEMM wrote it; the transposed A operand comes
 //                    from ds_read_b64_tr_b16 (4 keys x 16 dims per 16-lane group, delivered column-major), whose
 //                    4-row blocks match the permuted k order above.
-// K/V rows are staged raw (the 256-B head slice of each F16X2 row) with a 272-B row stride (conflict-free b128 reads).
+//
+// Staging: K and V rows travel as raw 256-B head slices of the F16X2 rows, 64 keys per chunk, by LDS-DMA into a
+// two-deep ring (2 x 32 KiB = two workgroups per CU): the DMA of chunk c+1 flies under the MFMAs of chunk c and costs
+// neither registers nor ds_writes.  An LDS-DMA writes 64 consecutive 16-B pieces, so rows cannot be padded; instead
+// piece p of row r sits at slot p ^ swz(r), swz a bit permutation of r & 15 chosen so that both the b128 key reads
+// (16 rows, one piece index) and the transposed value reads (4 consecutive rows x 4 alternate pieces) hit 64 banks.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace sm {
 
-constexpr int HAT_KCH = 128;   // keys per LDS chunk (2 x 128 x 272 B = 68 KiB: two workgroups per CU)
-constexpr int HAT_LD = 272;    // bytes per staged row
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int HAT_CH = 64;                  // keys per ring slot
+constexpr int HAT_TENSOR = HAT_CH * 256;    // bytes of K (or V) per slot
+constexpr int HAT_SLOT = 2 * HAT_TENSOR;
 
 __device__ __forceinline__ f16x4 tr_read4(unsigned addr) {
     f16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
     return v;
 }
+// slot permutation of row r: bits (r0, r1, r2, r3) -> XOR mask bits (0, 3, 1, 2)
+__device__ __forceinline__ int hat_swz(int r) { return (r & 1) | ((r & 2) << 2) | ((r & 4) >> 1) | ((r & 8) >> 1); }
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_args a, int kc_rows) {
+__global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_args a, int groups, int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smema[];
-    char* Ks = smema;
-    char* Vs = smema + kc_rows * HAT_LD;
-    const unsigned vs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)Vs;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smema;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int head = blockIdx.y;
-    const int64_t b = blockIdx.z;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs (id % 8), so the `groups` workgroups that
+    // share one (batch, head)'s keys and values get ids 8 apart - same XCD, dispatched together - and the second one
+    // finds K/V in that XCD's L2 instead of fetching them again from HBM
+    int qg, pair;
+    {
+        const int id = blockIdx.x, pairs = a.heads * a.batch;
+        if ((pairs & 7) == 0) {
+            const int t = id >> 3;
+            qg = t % groups;
+            pair = (t / groups) * 8 + (id & 7);
+        } else {
+            qg = id % groups;
+            pair = id / groups;
+        }
+    }
+    const int head = pair % a.heads;
+    const int64_t b = pair / a.heads;
+    const int q0 = (qg * NW + wave) * 32;
+    const bool active = q0 < a.n_q;  // waves past the last query block only help with staging
 
     const char* Qp = reinterpret_cast<const char*>(a.Q + b * a.sQb + head * SM_HEAD_DIM);
     const char* Kp = reinterpret_cast<const char*>(a.K + b * a.sKb + head * SM_HEAD_DIM);
     const char* Vp = reinterpret_cast<const char*>(a.V + b * a.sVb + head * SM_HEAD_DIM);
+
+    // ring fill: 32 one-KiB pieces per chunk (16 of K, 16 of V; a piece = 4 rows), dealt round-robin over the waves
+    const int n_k = a.n_k;
+    const int srow = lane >> 4;                       // row of the piece this lane fetches
+    auto issue = [&](int chunk, int slot) {
+#pragma unroll
+        for (int j = 0; j < (32 + NW - 1) / NW; ++j) {
+            const int i = wave + NW * j;
+            if (i < 32) {
+                const int g = i & 15, row = 4 * g + srow;
+                int key = chunk * HAT_CH + row;
+                key = key < n_k ? key : n_k - 1;      // tail rows repeat the last key (finite data; masked below)
+                const int piece = (lane & 15) ^ hat_swz(row);
+                const char* src = (i < 16 ? Kp + (int64_t)key * a.sKr * 4 : Vp + (int64_t)key * a.sVr * 4) + piece * 16;
+                lds_dma16(src, __builtin_amdgcn_readfirstlane(lds0 + slot * HAT_SLOT + (i >> 4) * HAT_TENSOR + g * 1024));
+            }
+        }
+    };
+    const int nch = (n_k + HAT_CH - 1) / HAT_CH;
+    issue(0, 0);
 
     // Q fragments (B operand of S^T = K Q^T): lane (r,h), 16-dim step t -> k-group 2t+h: hi chunk, lo chunk
     int qrow = q0 + r;
@@ -61,116 +103,128 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
     for (int v = 0; v < 16; ++v) { om[0][v] = 0.f; om[1][v] = 0.f; oc[0][v] = 0.f; oc[1][v] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    // per-lane pieces of the transposed V reads: 16-lane group g16 = (column block cb, key half = h); lane 4q+p of a
-    // group supplies row q, columns 4p..4p+3 and receives column (lane & 15)
+    // key fragment offsets inside a row (A operand of S^T): pieces 2(2t+h) [hi] and +1 [lo], permuted by the row
+    const int ksw = hat_swz(r & 15);
+    int k_hi[4], k_lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        k_hi[t] = ((2 * (2 * t + h)) ^ ksw) * 16;
+        k_lo[t] = ((2 * (2 * t + h) + 1) ^ ksw) * 16;
+    }
+    // transposed V reads: 16-lane group = (column block cb, key half h); lane 4q+p of a group supplies row q, columns
+    // 4p..4p+3 and receives column (lane & 15).  Rows 16u + 4h + q and + 8; pieces 2(4db + 2cb + (p>>1)) [hi], +1 [lo]
     const int cb = (lane >> 4) & 1, li = lane & 15, trq = li >> 2, trp = li & 3;
+    const int vrow = 4 * h + trq;
+    const int vswA = hat_swz(vrow), vswB = hat_swz(vrow + 8);
+    const int vpiece = 4 * cb + 2 * (trp >> 1), vsub = (trp & 1) * 8;
 
-    for (int c0 = 0; c0 < a.n_k; c0 += HAT_KCH) {
-        const int ck = min(HAT_KCH, a.n_k - c0);
-        const int nb = (ck + 31) >> 5;
-        __syncthreads();
-        for (int c = tid; c < nb * 32 * 16; c += NW * 64) {  // 16 chunks of 16 B per row and tensor
-            const int row = c >> 4, ch = (c & 15) * 16;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (row < ck) {
-                kv = *reinterpret_cast<const float4*>(Kp + (int64_t)(c0 + row) * a.sKr * 4 + ch);
-                vv = *reinterpret_cast<const float4*>(Vp + (int64_t)(c0 + row) * a.sVr * 4 + ch);
+    for (int c = 0; c < nch; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // chunk c has landed for every wave, and every wave is done with chunk c-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nch && (ablate != 2)) issue(c + 1, (c + 1) & 1);
+        if (!active || ablate == 1) continue;
+        const int ck = min(HAT_CH, n_k - c * HAT_CH);
+        const int nb2 = (ck + 31) >> 5;
+        const char* Ks = smema + (c & 1) * HAT_SLOT;
+        const unsigned vs_lds = lds0 + (c & 1) * HAT_SLOT + HAT_TENSOR;
+
+        // raw scores t = main + cross / 2048 (the softmax scale cs > 0 is applied inside the exponent's fma)
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s[kb][v] = -INFINITY;
+            if (kb < nb2) {
+                f32x16 mn, cr;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { mn[v] = 0.f; cr[v] = 0.f; }
+                const char* kr = Ks + (kb * 32 + r) * 256;
+                f16x8 kh[4], kl[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    kh[t] = *reinterpret_cast<const f16x8*>(kr + k_hi[t]);
+                    kl[t] = *reinterpret_cast<const f16x8*>(kr + k_lo[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    mn = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t], qh[t], mn, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t], ql[t], cr, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[t], qh[t], cr, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s[kb][v] = fmaf(cr[v], 1.0f / 2048.0f, mn[v]);
+                if ((kb + 1) * 32 > ck) {  // only the last chunk's last block has keys past n_k (wave-uniform branch)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        if (kb * 32 + acc_row(v, h) >= ck) s[kb][v] = -INFINITY;
+                }
             }
-            *reinterpret_cast<float4*>(Ks + row * HAT_LD + ch) = kv;
-            *reinterpret_cast<float4*>(Vs + row * HAT_LD + ch) = vv;
         }
-        __syncthreads();
-
-        // sub-chunks of 2 key blocks (64 keys): keeps the score registers at 64 per lane
-        for (int sb = 0; sb < nb; sb += 2) {
-            const int nb2 = min(2, nb - sb);
-            f32x16 s[2];
+        float cmax = -INFINITY;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) s[kb][v] = -INFINITY;
-                if (kb < nb2) {
-                    f32x16 mn, cr;
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) { mn[v] = 0.f; cr[v] = 0.f; }
-                    const char* kr = Ks + ((sb + kb) * 32 + r) * HAT_LD + h * 32;
-                    f16x8 kh[4], kl[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        kh[t] = *reinterpret_cast<const f16x8*>(kr + t * 64);
-                        kl[t] = *reinterpret_cast<const f16x8*>(kr + t * 64 + 16);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        mn = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t], qh[t], mn, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t], ql[t], cr, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[t], qh[t], cr, 0, 0, 0);
-                    }
-                    const bool tail = ((sb + kb) + 1) * 32 > ck;
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        float sv = (mn[v] + cr[v] * (1.0f / 2048.0f)) * cs;
-                        if (tail && (sb + kb) * 32 + acc_row(v, h) >= ck) sv = -INFINITY;
-                        s[kb][v] = sv;
-                    }
-                }
-            }
-            float cmax = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, s[kb][v]);
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, s[kb][v]);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        // Lazy running maximum: the reference point m_run only moves when some query's new maximum exceeds it by more
+        // than 2^8 in probability (p <= 256 then - harmless in fp32 and in the f16 split), which after the first chunk
+        // is rare; the 64-register rescale of O runs only then (wave-uniform branch).
+        const float lim = 8.0f / cs;
+        if (__builtin_amdgcn_ballot_w64(cmax > m_run + lim) != 0) {
             const float m_new = fmaxf(m_run, cmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
             m_run = m_new;
-            float psum = 0.f;
-            f16x8 ph[2][2], pl[2][2];  // [key block][16-key step]
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float p = __builtin_amdgcn_exp2f(s[kb][8 * u + j] - m_new);  // masked / absent: exp2(-inf) = 0
-                        psum += p;
-                        _Float16 hi, lo;
-                        split1(p, hi, lo);
-                        ph[kb][u][j] = hi;
-                        pl[kb][u][j] = lo;
-                    }
-                }
-            }
-            l_run = l_run * alpha + psum;
+            l_run *= alpha;
 #pragma unroll
             for (int v = 0; v < 16; ++v) { om[0][v] *= alpha; om[1][v] *= alpha; oc[0][v] *= alpha; oc[1][v] *= alpha; }
-            // O^T += V^T P^T
+        }
+        const float moff = -m_run * cs;
+        float psum = 0.f;
+        f16x8 ph[2][2], pl[2][2];  // [key block][16-key step]
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb < nb2) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int row1 = (sb + kb) * 32 + 16 * u + 4 * h + trq;  // keys 16u + 4h + {0..3}; second read: + 8
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-                        for (int db = 0; db < 2; ++db) {
-                            const int d0 = db * 32 + cb * 16 + 4 * trp;
-                            const unsigned base = vs_lds + row1 * HAT_LD + (d0 >> 3) * 32 + (d0 & 7) * 2;
-                            const f16x4 h1 = tr_read4(base), h2 = tr_read4(base + 8 * HAT_LD);
-                            const f16x4 l1 = tr_read4(base + 16), l2 = tr_read4(base + 16 + 8 * HAT_LD);
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_sched_barrier(0);
-                            f16x8 vh, vl;
+                for (int j = 0; j < 8; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * u + j], cs, moff));  // masked / absent: exp2(-inf) = 0
+                    psum += p;
+                    _Float16 hi, lo;
+                    split1(p, hi, lo);
+                    ph[kb][u][j] = hi;
+                    pl[kb][u][j] = lo;
+                }
+            }
+        }
+        l_run += psum;
+        // O^T += V^T P^T
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { vh[e] = h1[e]; vh[4 + e] = h2[e]; vl[e] = l1[e]; vl[4 + e] = l2[e]; }
-                            om[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kb][u], om[db], 0, 0, 0);
-                            oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][u], oc[db], 0, 0, 0);
-                            oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kb][u], oc[db], 0, 0, 0);
-                        }
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb < nb2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned rowA = vs_lds + (kb * 32 + 16 * u + vrow) * 256 + vsub;  // keys 16u + 4h + q; rowB: + 8
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const int pc = 8 * db + vpiece;
+                        const f16x4 h1 = tr_read4(rowA + ((pc ^ vswA) * 16)), h2 = tr_read4(rowA + 8 * 256 + ((pc ^ vswB) * 16));
+                        const f16x4 l1 = tr_read4(rowA + (((pc + 1) ^ vswA) * 16)), l2 = tr_read4(rowA + 8 * 256 + (((pc + 1) ^ vswB) * 16));
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        f16x8 vh, vl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vh[e] = h1[e]; vh[4 + e] = h2[e]; vl[e] = l1[e]; vl[4 + e] = l2[e]; }
+                        om[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kb][u], om[db], 0, 0, 0);
+                        oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][u], oc[db], 0, 0, 0);
+                        oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kb][u], oc[db], 0, 0, 0);
                     }
                 }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
+    if (!active) return;
 
     const float l = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l;
@@ -200,18 +254,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
 }
 
 template <int NW>
-static int launch_attn_h(const sm_attn_args& a, int nqb, hipStream_t st) {
-    const int kc_rows = min(((a.n_k + 31) / 32) * 32, HAT_KCH);
-    const size_t lds = (size_t)kc_rows * HAT_LD * 2;
+static int launch_attn_h(const sm_attn_args& a, int groups, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<NW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, HAT_KCH * HAT_LD * 2);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HAT_SLOT);
         (void)hipGetLastError();
         attr_set = true;
     }
-    dim3 grid((nqb + NW - 1) / NW, a.heads, a.batch);
-    hipLaunchKernelGGL((attention_f16x2_kernel<NW>), grid, dim3(NW * 64), lds, st, a, kc_rows);
+    static const int ablate = getenv("SM_ATTN_ABLATE") ? atoi(getenv("SM_ATTN_ABLATE")) : 0;  // timing-only: 1 = no compute, 2 = first chunk only
+    dim3 grid(groups * a.heads * a.batch);
+    hipLaunchKernelGGL((attention_f16x2_kernel<NW>), grid, dim3(NW * 64), 2 * HAT_SLOT, st, a, groups, ablate);
     return check_launch("sm_attention_f16x2");
 }
 
@@ -220,6 +273,7 @@ static int launch_attn_h(const sm_attn_args& a, int nqb, hipStream_t st) {
 extern "C" int sm_attention_f16x2(const sm_attn_args* a, void* stream) {
     SM_REQUIRE(a && a->Q && a->K && a->V && a->O, "sm_attention_f16x2: null pointer");
     SM_REQUIRE(a->batch > 0 && a->heads > 0 && a->n_q > 0 && a->n_k > 0, "sm_attention_f16x2: empty shape");
+    SM_REQUIRE(a->scale > 0.f, "sm_attention_f16x2: scale must be positive");
     SM_REQUIRE(a->sQr % 8 == 0 && a->sKr % 8 == 0 && a->sVr % 8 == 0 && a->sOr % 8 == 0 && a->sQb % 8 == 0 &&
                    a->sKb % 8 == 0 && a->sVb % 8 == 0 && a->sOb % 8 == 0,
                "sm_attention_f16x2: strides must be multiples of 8 elements (F16X2 groups)");
@@ -229,10 +283,7 @@ extern "C" int sm_attention_f16x2(const sm_attn_args* a, void* stream) {
     const int nqb = (a->n_q + 31) / 32;
     const int groups = (nqb + 3) / 4;
     const int nw = (nqb + groups - 1) / groups;
-    switch (nw) {
-        case 1: return sm::launch_attn_h<1>(*a, nqb, st);
-        case 2: return sm::launch_attn_h<2>(*a, nqb, st);
-        case 3: return sm::launch_attn_h<3>(*a, nqb, st);
-        default: return sm::launch_attn_h<4>(*a, nqb, st);
-    }
+    // always four waves: those past the last query block (decoder: a single block) issue their share of the ring's DMA
+    (void)nw;
+    return sm::launch_attn_h<4>(*a, groups, st);
 }

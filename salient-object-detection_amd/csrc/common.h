@@ -45,6 +45,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// One wave-wide LDS-DMA: every lane fetches 16 B from its own global address, the 64 pieces land contiguously at LDS
+// byte offset `lds_off` (wave-uniform, goes through M0) + 16 * lane.  Issued from inline asm (M0 saved / restored) so
+// that hipcc cannot put a vmcnt(0) in front of later LDS reads; completion is tracked by the caller's s_waitcnt vmcnt.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_off) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_off)
+        : "memory");
+}
+
 // ---- F16X2 split format (see gemm_f16x2.hip): hi = f16(x), lo = f16((x - hi) * 2^11) ---------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));

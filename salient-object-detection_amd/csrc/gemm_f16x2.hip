@@ -153,12 +153,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
 
-    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only runs: 2 = no MFMA, 3 = no DMA in the loop, 4 = no epilogue
+    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only runs: 2 = no MFMA, 3 = no DMA in the loop, 4 = no epilogue, 5 = 3 + 4, 6 = 5 without the barrier
     for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt_h<(NST - 2) * NI>();
-        __builtin_amdgcn_s_barrier();
+        if (ablate != 6) {
+            wait_vmcnt_h<(NST - 2) * NI>();
+            __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
-        if (ablate != 3) {
+        if (ablate != 3 && ablate < 5) {
             const int nt = kt + NST - 1;
             issue(nt < nk ? nt : nk - 1, nt % NST);
         }
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     wait_vmcnt_h<0>();
-    if (ablate == 4) return;  // timing-only: no epilogue
+    if (ablate >= 4) return;  // timing-only: no epilogue
 
     float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : bz) * g.strideC;
     const bool out_split = g.patch_n < 0;  // out-format flag travels in the sign of patch_n for non-PATCH epilogues

@@ -83,22 +83,28 @@ def split_f16x2(x: torch.Tensor) -> torch.Tensor:
 
 def gemm_f16x2(a_split: torch.Tensor, w_split: torch.Tensor, bias=None, epilogue: int = N.EPI_BIAS, residual=None,
                tile=(128, 128), out=None, out_f16x2: bool = False, split_k: int = 1):
-    """C = epilogue(A W^T + bias) with A, W in F16X2 format (see split_f16x2); 2-D operands only (test / tuning)."""
+    """C = epilogue(A W^T + bias) with A, W in F16X2 format (see split_f16x2).  2-D operands, or 3-D (batch, rows, K)
+    for a batched launch (no split_k then).  Test / tuning entry: the forward drives the kernel from C."""
     _dev(a_split, w_split, bias, residual)
-    M, K = a_split.shape
-    Nn = w_split.shape[0]
-    c = out if out is not None else torch.empty((max(1, split_k), M, Nn), device=a_split.device, dtype=torch.float32)
+    batched = a_split.dim() == 3
+    assert not (batched and split_k > 1)
+    a3 = a_split if batched else a_split.unsqueeze(0)
+    w3 = w_split if batched else w_split.unsqueeze(0)
+    nb, M, K = a3.shape
+    Nn = w3.shape[1]
+    c = out if out is not None else torch.empty((max(nb, split_k), M, Nn), device=a_split.device, dtype=torch.float32)
     c3 = c if c.dim() == 3 else c.unsqueeze(0)
     g = N.GemmArgs()
-    g.A, g.W, g.bias, g.C = a_split.data_ptr(), w_split.data_ptr(), _ptr(bias), c3.data_ptr()
-    g.strideC = c3.stride(0)
+    g.A, g.W, g.bias, g.C = a3.data_ptr(), w3.data_ptr(), _ptr(bias), c3.data_ptr()
+    g.strideA, g.strideW, g.strideC = a3.stride(0), w3.stride(0), c3.stride(0)
     g.M, g.N, g.K = M, Nn, K
-    g.lda, g.ldw, g.ldc = a_split.stride(0), w_split.stride(0), c3.stride(1)
-    g.batch, g.epilogue, g.split_k = 1, epilogue, split_k if split_k > 1 else 0
+    g.lda, g.ldw, g.ldc = a3.stride(1), w3.stride(1), c3.stride(1)
+    g.batch, g.epilogue, g.split_k = nb, epilogue, split_k if split_k > 1 else 0
     if residual is not None:
-        g.R, g.ldr = residual.data_ptr(), residual.stride(0)
+        r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
+        g.R, g.ldr, g.strideR = r3.data_ptr(), r3.stride(1), r3.stride(0)
     N.check(N.load().sm_gemm_f16x2_tile(g, 1 if out_f16x2 else 0, tile[0], tile[1], _stream()), "sm_gemm_f16x2_tile")
-    return c if (out is not None or split_k > 1) else c[0]
+    return c if (out is not None or split_k > 1 or batched) else c[0]
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,

@@ -27,13 +27,13 @@ for name, m, n, k, epi, osplit in shapes:
     a_s, w_s = ops.split_f16x2(a), ops.split_f16x2(w)
     c_out = torch.empty(1, m, n, device="cuda")
     for tile in [(256, 128), (128, 128), (128, 64), (64, 64)]:
-        for nst in ["2", "3"]:
+        for nst in ["2"]:
             os.environ["SM_F16X2_NST"] = nst
             line = f"{name:5s} {tile[0]}x{tile[1]} nst={nst}:"
-            for ab in ["0", "2", "3", "4"]:
+            for ab in ["0", "2", "3", "4", "5", "6"]:
                 if ab == "0": os.environ.pop("SM_F16X2_ABLATE", None)
                 else: os.environ["SM_F16X2_ABLATE"] = ab
                 us = t(lambda: ops.gemm_f16x2(a_s, w_s, b, epilogue=epi, residual=r, tile=tile, out=c_out, out_f16x2=osplit))
-                line += f"  {['full','noMFMA','noDMA','noEPI'][['0','2','3','4'].index(ab)]} {us:6.1f}"
+                line += f"  {['full','noMFMA','noDMA','noEPI','mfma+lds','nobarrier'][['0','2','3','4','5','6'].index(ab)]} {us:6.1f}"
             os.environ.pop("SM_F16X2_ABLATE", None)
             print(line, flush=True)
