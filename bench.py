@@ -3,13 +3,16 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank/GPU)
 
-A "step" is one MaskFormer.forward over one batch of synthetic images already resident in HBM (weights = synthetic
-checkpoint seed 0; there is no dataset or checkpoint offline).  Images shard across ranks with no data-path
-collective (weak scaling); the only exchange is the evaluator's end-of-run all-gather of per-image result rows
-(RCCL), issued once after the K steps inside the timed region.
+A "step" is one evaluator iteration - MaskFormer.forward + mask post-processing + the 14 metrics - over one batch of
+synthetic images already resident in HBM (weights = synthetic checkpoint seed 0; there is no dataset or checkpoint
+offline).  Consecutive steps are dealt onto --streams HIP streams (3 batches in flight, selfmask_amd/streams.py), as
+the shipped Evaluator does.  Images shard across ranks with no data-path collective (weak scaling); the only exchange
+is the evaluator's end-of-run all-gather of per-image result rows (RCCL), issued once after the K steps inside the
+timed region.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline      - the dominant kernel (fp32-MFMA GEMM family) timed live with HIP events on the launch stream;
+  roofline      - the kernel holding the largest share of the forward, timed in situ: HIP events around each of its
+                  launches on the launch stream inside real forwards (sm_forward_timing);
   cpu_baseline  - the CPU oracle (torch-CPU restatement of the reference) on this box's host cores, rank 0, N=1 only.
 """
 import argparse
@@ -42,82 +45,30 @@ def forward_flops_per_image(P, S, L=6, nq=20):
     return enc + dec + head
 
 
-def forward_gemm_launches(B, P, S, L=6, nq=20):
-    """Every GEMM launch of one MaskFormer.forward:
-    (name, M, N, K, epilogue, batch, launches per forward, split_k, F16X2 output in split mode)."""
+def time_forward_kernels(model, x, forwards=3):
+    """Per-kernel timing of the real forward: the library brackets each GEMM / attention / LayerNorm launch with two
+    HIP events on the launch stream (sm_forward_timing, include/selfmask_hip.h) while `forwards` forwards of the bench
+    batch run on one stream right after the timed steps.  Returns {kernel name: dict}, largest time first."""
     from selfmask_amd import _native as Nn
-    g = S // P
-    n, N = g * g, g * g + 1
-    M, Mp, Md, Mo = B * N, B * n, B * nq, B * nq * L
-    return [
-        ("patch_embed", Mp, 384, 3 * P * P, Nn.EPI_BIAS, 1, 1, 1, False),
-        ("enc.qkv", M, 1152, 384, Nn.EPI_BIAS, 1, 12, 1, True), ("enc.proj", M, 384, 384, Nn.EPI_RESIDUAL, 1, 12, 1, False),
-        ("enc.fc1", M, 1536, 384, Nn.EPI_GELU, 1, 12, 1, True), ("enc.fc2", M, 384, 1536, Nn.EPI_RESIDUAL, 1, 12, 1, False),
-        ("dec.ca_kv_all_layers", Mp, L * 768, 384, Nn.EPI_BIAS, 1, 1, 1, True),
-        ("dec.sa_qkv", Md, 1152, 384, Nn.EPI_BIAS, 1, L, 1, True), ("dec.sa_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1, False),
-        ("dec.ca_q", Md, 384, 384, Nn.EPI_BIAS, 1, L, 1, True), ("dec.ca_out", Md, 384, 384, Nn.EPI_RESIDUAL, 1, L, 1, False),
-        ("dec.lin1", Md, 1536, 384, Nn.EPI_RELU, 1, L, 1, True), ("dec.lin2_splitk4", Md, 384, 1536, Nn.EPI_BIAS, 1, L, 4, False),
-        ("mask_einsum", L * nq, 4 * n, 384, Nn.EPI_BIAS, B, 1, 1, False),
-        ("obj.ffn0", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1, True), ("obj.ffn1", Mo, 384, 384, Nn.EPI_RELU, 1, 1, 1, True),
-    ]
-
-
-def time_gemm_kernels(B, P, S, mode, iters=3):
-    """Live per-kernel timing of the GEMM instantiations (the kernels that hold most of the forward): for each
-    kernel name (= back end + workgroup tile) replay exactly the launch mix one forward issues, bracketed by HIP events
-    on the stream the library launches on (torch's current stream).  Returns {kernel: dict} sorted by time."""
-    import ctypes
-    from selfmask_amd import ops, _native as Nn
     lib = Nn.load()
-    dev = "cuda"
-    split_mode = mode == "f16x2"
-    groups = {}
-    for name, M, N, K, epi, batch, cnt, split, osplit in forward_gemm_launches(B, P, S):
-        ga = Nn.GemmArgs()
-        ga.M, ga.N, ga.K, ga.batch, ga.split_k = M, N, K, batch, split
-        bm, bn, nst = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-        if split_mode:
-            Nn.check(lib.sm_gemm_f16x2_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(nst)))
-            kname = f"gemm_f16x2_kernel<{bm.value}, {bn.value}, {nst.value}, 2, 2, 3>"  # 2x2 waves, 3 workgroups/CU
-        else:
-            Nn.check(lib.sm_gemm_f32_pick_tile(ga, ctypes.byref(bm), ctypes.byref(bn)))
-            nst_f32 = {(128, 128): 2, (128, 64): 3, (64, 64): 4}[(bm.value, bn.value)]
-            kname = f"gemm_f32_kernel<{bm.value}, {bn.value}, {nst_f32}>"
-        a = torch.randn(batch, M, K, device=dev)
-        w = torch.randn(batch, N, K, device=dev) * 0.03
-        if split_mode:  # operands in the F16X2 split format, as the forward's producers write them
-            a, w = ops.split_f16x2(a), ops.split_f16x2(w)
-        bias = torch.zeros(N, device=dev) if split == 1 else None
-        c = torch.empty(max(batch, split), M, N, device=dev)
-        r = torch.randn(batch, M, N, device=dev) if epi == Nn.EPI_RESIDUAL else None
-        groups.setdefault((kname, bm.value, bn.value), []).append((name, a, w, bias, c, r, epi, cnt, 2.0 * M * N * K * batch, split, osplit))
+    torch.cuda.synchronize()
+    Nn.check(lib.sm_forward_timing(1), "sm_forward_timing")
+    for _ in range(forwards):
+        model(x)
+    torch.cuda.synchronize()
+    buf = (Nn.KernelTime * 32)()
+    n = lib.sm_forward_timing_read(buf, 32)
+    lib.sm_forward_timing(0)
+    if n < 0:
+        raise RuntimeError(lib.sm_last_error().decode())
     out = {}
-    for (kname, bm, bn), items in groups.items():
-        def run_mix():
-            for name, a, w, bias, c, r, epi, cnt, fl, split, osplit in items:
-                for _ in range(cnt):
-                    if split_mode:
-                        batched = a.shape[0] > 1
-                        ops.gemm_f16x2(a if batched else a[0], w if batched else w[0], bias, epilogue=epi,
-                                       residual=None if r is None else (r if batched else r[0]), tile=(bm, bn),
-                                       out=c if (split > 1 or batched) else c[0], split_k=split, out_f16x2=osplit)
-                    else:
-                        ops.gemm(a, w, bias, epilogue=epi, residual=r, out=c, tile=(bm, bn), split_k=split)
-        run_mix()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(iters):
-            run_mix()
-        e1.record()
-        torch.cuda.synchronize()
-        launches = sum(i[7] for i in items)
-        flops = sum(i[7] * i[8] for i in items)
-        total_s = e0.elapsed_time(e1) * 1e-3 / iters
-        out[kname] = {
-            "launches_per_forward": launches, "avg_launch_us": total_s / launches * 1e6,
-            "flops_per_launch": flops / launches, "total_ms_per_forward": total_s * 1e3,
-            "achieved_tflops": flops / total_s / 1e12, "mix": [i[0] for i in items]}
+    for e in buf[:n]:
+        t = e.total_us * 1e-6
+        out[e.name.decode()] = {
+            "launches_per_forward": e.launches / forwards, "avg_launch_us": e.total_us / e.launches,
+            "total_ms_per_forward": e.total_us / forwards * 1e-3, "event_overhead_us": e.overhead_us,
+            "flops_per_launch": e.flops / e.launches, "bytes_per_launch": e.bytes / e.launches,
+            "achieved_tflops": e.flops / t / 1e12, "achieved_gbs": e.bytes / t / 1e9}
     return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms_per_forward"]))
 
 
@@ -239,10 +190,28 @@ def main():
     if rank == 0:
         value = world * a.steps * B / dt
         flops_img = forward_flops_per_image(P, S)
-        kern = time_gemm_kernels(B, P, S, model.gemm_mode)
+        kern = time_forward_kernels(model, x)
         dom_name, dom = next(iter(kern.items()))
-        ach = dom["achieved_tflops"]
+        # HBM bytes per launch from the PMC passes of this same command (profiles/r01_pmc_traffic.json holds the recipe;
+        # a profiler cannot run inside the timed process, so the committed measurement is quoted, null if absent)
+        traffic = None
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError, KeyError):
+            pass
+        gemm = "gemm" in dom_name or "attention" in dom_name
         peak = F32_MFMA_PEAK_TFLOPS if model.gemm_mode == "fp32" else F16_MFMA_PEAK_TFLOPS
+        issue = 3.0 if model.gemm_mode == "f16x2" else 1.0  # MFMA FLOPs issued per algorithmic FLOP (hi*hi, hi*lo, lo*hi)
+
+        def roof(v, name):
+            if "layernorm" in name:
+                return {"bound": "hbm", "achieved": round(v["achieved_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(v["achieved_gbs"] / HBM_PEAK_GBS, 4)}
+            return {"bound": "mfma", "achieved": round(v["achieved_tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(v["achieved_tflops"] / peak, 4),
+                    "mfma_issued_tflops": round(v["achieved_tflops"] * issue, 2)}
+
         res = {
             "metric": "images/sec (224^2, nq=20)", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -255,17 +224,16 @@ def main():
                        "streams": len(ring.streams),
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
-            "roofline": {"bound": "mfma", "kernel": dom_name, "launch_mix": dom["mix"],
-                         "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
-                         "mfma_issued_tflops": round(ach * (3.0 if model.gemm_mode == "f16x2" else 1.0), 2),
-                         "avg_launch_us": round(dom["avg_launch_us"], 2),
-                         "launches_per_forward": dom["launches_per_forward"],
-                         "flops_per_launch": dom["flops_per_launch"]},
-            "roofline_other_kernels": {k: {"achieved": round(v["achieved_tflops"], 2),
-                                           "frac": round(v["achieved_tflops"] / peak, 4),
-                                           "avg_launch_us": round(v["avg_launch_us"], 2),
-                                           "launches_per_forward": v["launches_per_forward"]}
+            "roofline": dict(roof(dom, dom_name), kernel=dom_name, traffic=traffic,
+                             avg_launch_us=round(dom["avg_launch_us"], 2),
+                             launches_per_forward=dom["launches_per_forward"],
+                             flops_per_launch=dom["flops_per_launch"],
+                             share_of_forward=round(dom["total_ms_per_forward"] / sum(v["total_ms_per_forward"] for v in kern.values()), 3),
+                             event_overhead_us=round(dom["event_overhead_us"], 2),
+                             how="HIP events around every launch of this kernel inside 3 real forwards "
+                                 "(sm_forward_timing); an empty event pair's time (event_overhead_us) is subtracted per launch"),
+            "roofline_other_kernels": {k: dict(roof(v, k), avg_launch_us=round(v["avg_launch_us"], 2),
+                                               launches_per_forward=v["launches_per_forward"])
                                        for k, v in list(kern.items())[1:]},
         }
         if world == 1 and not a.no_cpu_baseline:

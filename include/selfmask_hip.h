@@ -281,6 +281,22 @@ size_t sm_forward_workspace_bytes(const sm_weights* w, int32_t B, int32_t H, int
 int sm_maskformer_forward(const sm_weights* w, const sm_forward_io* io, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* In-situ kernel timing of sm_maskformer_forward (measurement aid for bench.py; not part of the reference surface).
+ * While enabled, every GEMM / attention / LayerNorm launch of a forward is bracketed by two HIP events recorded on the
+ * forward's own stream; sm_forward_timing_read waits for them and returns one entry per kernel family (GEMMs by their
+ * workgroup tile, i.e. by kernel instantiation) summed over all forwards issued since the enable.  Diagnostic mode:
+ * single caller thread, one stream at a time. */
+typedef struct {
+    char name[64];     /* kernel (template instantiation) name as rocprofv3 prints it, without the argument list */
+    int32_t launches;
+    double total_us;   /* sum of the launches' GPU durations (event-pair times minus overhead_us each) */
+    double overhead_us; /* what an EMPTY event pair measures on the same stream (mean of 16), subtracted per launch */
+    double flops;      /* algorithmic FLOPs of those launches (2*M*N*K for GEMMs, 4*nq*nk*64 per head for attention) */
+    double bytes;      /* algorithmic bytes (LayerNorm: rows * 384 * 4 * 2) */
+} sm_kernel_time;
+int sm_forward_timing(int enable);                                   /* 1: clear + start tapping; 0: stop + free */
+int sm_forward_timing_read(sm_kernel_time* out, int max_entries);    /* returns the number of entries written, < 0 on error */
+
 #ifdef __cplusplus
 }
 #endif

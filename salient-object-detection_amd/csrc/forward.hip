@@ -8,8 +8,37 @@
 //      produced directly in the F16X2 format by its producer (LayerNorm, attention, GELU/ReLU epilogues, im2col,
 //      up-sample); tensors that are also residuals / outputs exist in fp32 as well.  "(S)" marks them below.
 #include "common.h"
+#include <string.h>
+#include <string>
+#include <vector>
 
 namespace sm {
+
+// ---- timing taps (sm_forward_timing): event pairs around the heavy launches, on the forward's stream -----------------
+struct Tap {
+    hipStream_t st;
+    hipEvent_t e0, e1;
+    std::string name;
+    double flops, bytes;
+};
+static bool g_timing = false;
+static std::vector<Tap> g_taps;
+
+struct TapScope {
+    hipStream_t st;
+    bool on;
+    TapScope(hipStream_t st_, const std::string& name, double flops, double bytes) : st(st_), on(g_timing) {
+        if (!on) return;
+        Tap t;
+        t.st = st; t.name = name; t.flops = flops; t.bytes = bytes;
+        if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(t.e0, st);
+        g_taps.push_back(t);
+    }
+    ~TapScope() {
+        if (on) (void)hipEventRecord(g_taps.back().e1, st);
+    }
+};
 
 struct Shape {
     int B, H, W, P, gh, gw, n, N, L, nq;
@@ -76,6 +105,7 @@ struct Ctx {
     hipStream_t st;
 };
 
+static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s = false);
 // C = epilogue(A W^T + b); in split mode A and W are F16X2 and `out_s` asks for an F16X2 C
 static int linear(const Ctx& c, const float* A, int lda, const float* W, const float* b, float* C, int ldc, int64_t M, int N,
                   int K, int epi, const float* R, int ldr, bool out_s = false) {
@@ -83,13 +113,28 @@ static int linear(const Ctx& c, const float* A, int lda, const float* W, const f
     g.A = A; g.W = W; g.bias = b; g.C = C; g.R = R;
     g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldr = ldr;
     g.batch = 1; g.epilogue = epi;
-    return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
+    return gemm(c, g, out_s);
 }
-static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s = false) {
+static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
+    if (!g_timing) return std::string();
+    char buf[64];
+    int bm = 0, bn = 0, nst = 0;
+    if (c.S) {
+        sm_gemm_f16x2_pick_tile(&g, &bm, &bn, &nst);
+        snprintf(buf, sizeof buf, "gemm_f16x2_kernel<%d, %d, %d, 2, 2, 3>", bm, bn, nst);
+    } else {
+        sm_gemm_f32_pick_tile(&g, &bm, &bn);
+        snprintf(buf, sizeof buf, "gemm_f32_kernel<%d, %d, %d>", bm, bn, bm == 128 ? (bn == 128 ? 2 : 3) : 4);
+    }
+    return buf;
+}
+static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s) {
+    TapScope tap(c.st, gemm_name(c, g), 2.0 * g.M * g.N * g.K * (g.batch > 0 ? g.batch : 1), 0.0);
     return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
 }
 // in split mode Q, K and V are F16X2 (written so by the projection GEMMs) and the f16 matrix cores do the work
 static int attn(const Ctx& c, sm_attn_args& a) {
+    TapScope tap(c.st, c.S ? "attention_f16x2_kernel<4>" : "attention_f32_kernel", 4.0 * a.batch * a.heads * a.n_q * (double)a.n_k * SM_HEAD_DIM, 0.0);
     a.out_f16x2 = c.S;
     return c.S ? sm_attention_f16x2(&a, c.st) : sm_attention_f32(&a, c.st);
 }
@@ -114,6 +159,7 @@ static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, fl
     a.rows = (int)rows; a.eps = eps;
     a.n_partials = o.n_partials; a.partial_stride = o.partial_stride; a.pre_bias = o.pre_bias; a.residual = o.residual;
     a.ys = o.ys; a.y2_f16x2 = o.y2_s ? 1 : 0;
+    TapScope tap(c.st, "layernorm384_kernel", 0.0, 2.0 * rows * SM_EMBED * 4);
     return sm_layernorm_rows_f32(&a, c.st);
 }
 
@@ -314,4 +360,57 @@ extern "C" int sm_maskformer_forward(const sm_weights* w, const sm_forward_io* i
         return SM_ENOSPACE;
     }
     return sm::forward(w, io, (float*)workspace, (hipStream_t)stream);
+}
+
+extern "C" int sm_forward_timing(int enable) {
+    for (auto& t : sm::g_taps) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    sm::g_taps.clear();
+    sm::g_timing = enable != 0;
+    return SM_OK;
+}
+
+extern "C" int sm_forward_timing_read(sm_kernel_time* out, int max_entries) {
+    SM_REQUIRE(out && max_entries > 0, "sm_forward_timing_read: null output");
+    int n = 0;
+    // calibration: an event pair with nothing between it still measures the command processor's event handling
+    double overhead_us = 0.0;
+    if (!sm::g_taps.empty()) {
+        hipStream_t st = sm::g_taps.front().st;
+        (void)hipEventSynchronize(sm::g_taps.back().e1);
+        const int reps = 16;
+        hipEvent_t ev[2 * reps];
+        for (auto& e : ev) (void)hipEventCreate(&e);
+        for (auto& e : ev) (void)hipEventRecord(e, st);
+        (void)hipEventSynchronize(ev[2 * reps - 1]);
+        for (int i = 0; i < reps; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+            overhead_us += ms * 1e3 / reps;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
+    for (auto& t : sm::g_taps) {
+        float ms = 0.f;
+        if (hipEventSynchronize(t.e1) != hipSuccess || hipEventElapsedTime(&ms, t.e0, t.e1) != hipSuccess) {
+            sm::set_error("sm_forward_timing_read: event query failed");
+            return SM_ELAUNCH;
+        }
+        int k = 0;
+        while (k < n && t.name != out[k].name) ++k;
+        if (k == n) {
+            if (n == max_entries) continue;
+            memset(&out[n], 0, sizeof out[n]);
+            strncpy(out[n].name, t.name.c_str(), sizeof out[n].name - 1);
+            ++n;
+        }
+        out[k].launches += 1;
+        out[k].overhead_us = overhead_us;
+        out[k].total_us += ms * 1e3 > overhead_us ? ms * 1e3 - overhead_us : 0.0;
+        out[k].flops += t.flops;
+        out[k].bytes += t.bytes;
+    }
+    return n;
 }

@@ -72,6 +72,11 @@ class ForwardIO(C.Structure):
                 ("patch_tokens", fp), ("encoder_only", C.c_int32)]
 
 
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int32), ("total_us", C.c_double), ("overhead_us", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 class EvalImage(C.Structure):
     _fields_ = [("gt_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32)]
 
@@ -120,6 +125,8 @@ SYMBOLS = {
     "sm_bilateral_solver_f64": (C.c_int, [C.POINTER(BilateralArgs), fp]),
     "sm_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Weights), C.c_int32, C.c_int32, C.c_int32]),
     "sm_maskformer_forward": (C.c_int, [C.POINTER(Weights), C.POINTER(ForwardIO), fp, C.c_size_t, fp]),
+    "sm_forward_timing": (C.c_int, [C.c_int]),
+    "sm_forward_timing_read": (C.c_int, [C.POINTER(KernelTime), C.c_int]),
 }
 
 _lib = None
