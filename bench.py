@@ -108,6 +108,9 @@ def main():
                     help="batches in flight per GPU: step k runs on HIP stream k %% streams (own workspace), so one "
                          "batch's latency-bound decoder / metrics kernels fill CUs beside another's encoder GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-input", action="store_true",
+                    help="diagnostic: every step copies its batch from pinned host memory first (PCIe-inclusive rate; "
+                         "the metric keeps inputs resident in HBM)")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: skip the evaluator kernels (not the metric)")
     ap.add_argument("--gemm-mode", default=None, choices=["f16x2", "fp32"], help="GEMM back end (default f16x2)")
     a = ap.parse_args()
@@ -144,11 +147,12 @@ def main():
                                       ((xx - w * rng.uniform(.3, .7)) / (w * rng.uniform(.1, .3))) ** 2) <= 1)
                                     .astype(np.uint8)))
     gt_batch = ops.GtBatch(gts, dev)
+    x_host = x.cpu().pin_memory() if a.host_input else None
 
     def step():
         # one evaluator iteration over a batch (evaluator.pyc@L193-228, batched mode): forward, last decoder
         # layer, up-sample to each GT's size, upper-bound + arg-max-objectness query, 7 metrics x 2 -> 16 floats/image
-        out = model(x)
+        out = model(x_host.to(dev, non_blocking=True) if a.host_input else x)
         if a.forward_only:
             return out["objectness"][:, -1, :16, 0]
         return ops.evaluate_masks(out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0], gt_batch, scale=0.0)
@@ -221,7 +225,7 @@ def main():
             "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
                                    f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
                        "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20, "gemm_mode": model.gemm_mode,
-                       "streams": len(ring.streams),
+                       "streams": len(ring.streams), "host_input": bool(a.host_input),
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
             "roofline": dict(roof(dom, dom_name), kernel=dom_name, traffic=traffic,
