@@ -345,11 +345,24 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
 
 extern "C" int sm_gemm_f16x2_pick_tile(const sm_gemm_args* g, int* bm, int* bn, int* nst) {
     SM_REQUIRE(g && bm && bn && nst, "sm_gemm_f16x2_pick_tile: null pointer");
-    // measured on MI355X (B=64 ViT-S/16 shapes): 128x64 (2 stages) wherever it still yields >= 512 workgroups,
-    // 64x64 (3 stages) for the small decoder GEMMs; both are 48 KiB of LDS = three workgroups per CU
-    const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * (g->split_k > 1 ? g->split_k : g->batch);
-    if (wg128 >= 512) { *bm = 128; *bn = 64; *nst = 2; }
+    // Measured on MI355X (B=64 ViT-S/16 shapes).  A GEMM alone on the GPU is fastest as 128x64 tiles (three workgroups
+    // per CU hide each other's prologue / epilogue), but the evaluator keeps three batches in flight on three streams
+    // (streams.py), other kernels fill those gaps, and what counts is DMA instructions per FLOP: 128x128 tiles (two
+    // workgroups per CU, 64 KiB of LDS each) gave +5 % end to end over 128x64, 256x128 +3 %, 64x64 -8 %.
+    const long nb = g->split_k > 1 ? g->split_k : g->batch;
+    const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * nb;
+    const long wg128x128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
+    if (wg128x128 >= 256) { *bm = 128; *bn = 128; *nst = 2; }
+    else if (wg128 >= 512) { *bm = 128; *bn = 64; *nst = 2; }
     else { *bm = 64; *bn = 64; *nst = 3; }
+    // tuning knobs: "BMxBN" for the GEMMs with >= 512 workgroups, by output width (N >= 768 / narrower)
+    static const char* force_w = getenv("SM_F16X2_TILE_WIDE");
+    static const char* force_n = getenv("SM_F16X2_TILE_NARROW");
+    const char* force = g->N >= 768 ? force_w : force_n;
+    if (force && wg128 >= 512) {
+        int fbm = 0, fbn = 0;
+        if (sscanf(force, "%dx%d", &fbm, &fbn) == 2) { *bm = fbm; *bn = fbn; *nst = (fbm == 64) ? 3 : 2; }
+    }
     return SM_OK;
 }
 
