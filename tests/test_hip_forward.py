@@ -105,6 +105,34 @@ def test_forward_is_deterministic_and_batch_invariant():
     assert torch.equal(c["mask_logits"][0], a["mask_logits"][2])
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_full_bench_batch_64_properties(mode):
+    """BASELINE.json configs[1] at its full size (B=64, ViT-S/16, 224^2): too big for the CPU oracle in a test, so
+    (1) batch invariance - images 0, 29 and 63 alone give the same bits as inside the batch of 64 although the GEMMs
+    then run on other tile shapes; (2) the oracle is run on those three images only, strict 1e-4 gate (calib weights);
+    (3) two identical images in one batch give identical outputs; (4) a second call reproduces the first bit for bit."""
+    patch, B = 16, 64
+    sd = synthetic_state_dict(12, "calib", patch_size=patch)
+    xs = synthetic_images(777, (B, 3, 224, 224))
+    xs[40] = xs[7]
+    x = torch.from_numpy(xs)
+    m = _model(patch, 12, "calib", mode)
+    out = m(x.to(DEV), return_logits=True)
+    again = m(x.to(DEV), return_logits=True)
+    assert torch.equal(out["mask_logits"], again["mask_logits"]) and torch.equal(out["objectness"], again["objectness"])
+    assert torch.equal(out["mask_logits"][40], out["mask_logits"][7]) and torch.equal(out["features"][40], out["features"][7])
+    pick = [0, 29, 63]
+    for i in pick:
+        one = m(x[i:i + 1].to(DEV), return_logits=True)
+        assert torch.equal(one["mask_logits"][0], out["mask_logits"][i]), i
+        assert torch.equal(one["objectness"][0], out["objectness"][i]), i
+    o32 = O.forward(x[pick], sd, patch)
+    d = (out["mask_logits"][pick].cpu() - o32["mask_logits"]).abs().max().item()
+    print(f"\n[{mode}] B=64 calib, images {pick}: hip-oracle32={d:.2e}")
+    assert d <= ABS_TOL
+    assert (out["objectness"][pick].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
+
+
 def test_encoder_only_and_3d_path():
     m = _model(16, 0, "soft")
     x = torch.from_numpy(synthetic_images(5, (2, 3, 224, 224))).to(DEV)
