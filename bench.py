@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step k runs on HIP stream k %% streams (own workspace), so one "
                          "batch's latency-bound decoder / metrics kernels fill CUs beside another's encoder GEMMs")
+    ap.add_argument("--no-graph", action="store_true", help="launch the forward's 171 kernels eagerly instead of replaying "
+                                                            "one captured hipGraph per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-input", action="store_true",
                     help="diagnostic: every step copies its batch from pinned host memory first (PCIe-inclusive rate; "
@@ -149,10 +151,13 @@ def main():
     gt_batch = ops.GtBatch(gts, dev)
     x_host = x.cpu().pin_memory() if a.host_input else None
 
+    from selfmask_amd.graphs import GraphedForward
+    fwd = GraphedForward(model, enabled=not a.no_graph)
+
     def step():
         # one evaluator iteration over a batch (evaluator.pyc@L193-228, batched mode): forward, last decoder
         # layer, up-sample to each GT's size, upper-bound + arg-max-objectness query, 7 metrics x 2 -> 16 floats/image
-        out = model(x_host.to(dev, non_blocking=True) if a.host_input else x)
+        out = fwd(x_host.to(dev, non_blocking=True) if a.host_input else x)
         if a.forward_only:
             return out["objectness"][:, -1, :16, 0]
         return ops.evaluate_masks(out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0], gt_batch, scale=0.0)
@@ -231,6 +236,7 @@ def main():
                                    f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
                        "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20, "gemm_mode": model.gemm_mode,
                        "streams": len(ring.streams), "host_input": bool(a.host_input),
+                       "hip_graph": {"captures": fwd.captures, "replays": fwd.replays, "failed": fwd.failed},
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
             "roofline": dict(roof(dom, dom_name), kernel=dom_name, traffic=traffic,

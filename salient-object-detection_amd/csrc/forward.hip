@@ -164,6 +164,29 @@ static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, fl
     return sm_layernorm_rows_f32(&a, c.st);
 }
 
+// decoder start state in one launch: tgt = 0 (fp32 and F16X2 - zero bytes in both), tgt + query_pos = query_pos broadcast
+// over the batch (fp32, or F16X2 in split mode).  A kernel rather than hipMemsetAsync: memset nodes in a captured
+// hipGraph misbehaved on replay (graphs.py), and it saves three launches.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void decoder_init_kernel(const float* __restrict__ qpos, float* __restrict__ tgt,
+                                                          float* __restrict__ tgts, float* __restrict__ tgtq, int rows_per,
+                                                          int64_t total4) {
+    const int64_t per4 = (int64_t)rows_per * (SM_EMBED / 4);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
+        reinterpret_cast<float4*>(tgt)[t] = z;
+        reinterpret_cast<float4*>(tgts)[t] = z;
+        const float4 q = reinterpret_cast<const float4*>(qpos)[t % per4];
+        if constexpr (SPLIT) {
+            const int64_t e = t * 4, row = e / SM_EMBED;
+            const float v[4] = {q.x, q.y, q.z, q.w};
+            store_f16x2_4(tgtq + row * SM_EMBED, e - row * SM_EMBED, v);
+        } else {
+            reinterpret_cast<float4*>(tgtq)[t] = q;
+        }
+    }
+}
+
 #define TRY(x)                \
     do {                      \
         int _rc = (x);        \
@@ -228,17 +251,14 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // ---- 6 post-norm decoder layers (transformer_decoder.py:260-297, :112-150) ----------------------------------
     float* QD = io->queries ? io->queries : ws.QD;
     const float* qpos = w->query_embed;
-    // tgt = 0 (F16X2 zeros are zero bytes too); tgt + query_pos = query_pos broadcast over the batch
-    if (hipMemsetAsync(ws.TGT, 0, s.Md * D * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(ws.TGTs, 0, s.Md * D * sizeof(float), st) != hipSuccess) {
-        set_error("sm_maskformer_forward: hipMemsetAsync failed");
-        return SM_ELAUNCH;
-    }
-    if (S) {
-        TRY(sm_broadcast_rows_f32(qpos, ws.T2, s.nq, s.B, st));
-        TRY(sm_split_f16x2(ws.T2, D, ws.TGTQ, D, s.Md, D, st));
-    } else {
-        TRY(sm_broadcast_rows_f32(qpos, ws.TGTQ, s.nq, s.B, st));
+    {
+        const int64_t total4 = s.Md * D / 4;
+        const int grid = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+        if (S)
+            hipLaunchKernelGGL(decoder_init_kernel<true>, dim3(grid), dim3(256), 0, st, qpos, ws.TGT, ws.TGTs, ws.TGTQ, s.nq, total4);
+        else
+            hipLaunchKernelGGL(decoder_init_kernel<false>, dim3(grid), dim3(256), 0, st, qpos, ws.TGT, ws.TGTs, ws.TGTQ, s.nq, total4);
+        TRY(check_launch("decoder_init"));
     }
     // cross-attention keys/values of every layer depend only on the encoder memory: one large GEMM
     // (B*n x 384) x (384 x L*768) instead of L small ones on the critical chain

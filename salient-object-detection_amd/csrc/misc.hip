@@ -146,13 +146,21 @@ __global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __rest
 }
 
 __global__ void query_mean_kernel(const float* __restrict__ q, float* __restrict__ f, int L, int nq) {
-    const int b = blockIdx.x;
-    const float* src = q + (((int64_t)b * L + (L - 1)) * nq) * SM_EMBED;
-    for (int c = threadIdx.x; c < SM_EMBED; c += blockDim.x) {
-        float s = 0.f;
-        for (int i = 0; i < nq; ++i) s += src[(int64_t)i * SM_EMBED + c];
-        f[(int64_t)b * SM_EMBED + c] = s / (float)nq;
+    // one thread per (image, channel); the loads of a group of 8 queries are independent of the running sum, so they
+    // are all in flight before the (in-order) adds
+    const int b = blockIdx.x / (SM_EMBED / 128), c = (blockIdx.x % (SM_EMBED / 128)) * 128 + threadIdx.x;
+    const float* src = q + (((int64_t)b * L + (L - 1)) * nq) * SM_EMBED + c;
+    float s = 0.f;
+    int i = 0;
+    for (; i + 8 <= nq; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(i + j) * SM_EMBED];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
     }
+    for (; i < nq; ++i) s += src[(int64_t)i * SM_EMBED];
+    f[(int64_t)b * SM_EMBED + c] = s / (float)nq;
 }
 
 static inline int grid_for(int64_t work, int per_block = 256) {
@@ -231,6 +239,6 @@ extern "C" int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float
 
 extern "C" int sm_query_mean_f32(const float* queries, float* features, int32_t B, int32_t L, int32_t nq, void* stream) {
     SM_REQUIRE(queries && features && B > 0 && L > 0 && nq > 0, "sm_query_mean_f32: bad arguments");
-    hipLaunchKernelGGL(sm::query_mean_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, queries, features, L, nq);
+    hipLaunchKernelGGL(sm::query_mean_kernel, dim3(B * (SM_EMBED / 128)), dim3(128), 0, (hipStream_t)stream, queries, features, L, nq);
     return sm::check_launch("sm_query_mean_f32");
 }

@@ -6,6 +6,8 @@ Host side mirrors the reference's Python surface; arithmetic runs in hand-writte
 from .maskformer import MaskFormer, load_checkpoint  # noqa: F401
 from .misc import get_model, set_seeds  # noqa: F401
 from .base_structure import BaseStructure  # noqa: F401
+from .streams import StreamRing  # noqa: F401
+from .graphs import GraphedForward  # noqa: F401
 from .state_layout import state_shapes, synthetic_state_dict, synthetic_images  # noqa: F401
 
 __version__ = "0.1.0"

@@ -16,4 +16,8 @@ class BaseStructure:
         """base_structure.py:18-24.  ``device=`` is accepted because the compiled evaluator passes it
         (evaluator.pyc@L194) although the reference signature lacks it (a latent TypeError there)."""
         dev = device if device is not None else self.device
-        return self.model(dict_data['x'].to(dev), encoder_only=encoder_only, skip_decoder=skip_decoder)
+        x = dict_data['x'].to(dev)
+        fwd = getattr(self, "_graphed", None)  # graphs.GraphedForward installed by the Evaluator (plain forwards only)
+        if fwd is not None and not encoder_only and not skip_decoder:
+            return fwd(x)
+        return self.model(x, encoder_only=encoder_only, skip_decoder=skip_decoder)

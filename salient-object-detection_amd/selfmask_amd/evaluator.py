@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .base_structure import BaseStructure
 from .datasets import get_dataset
+from .graphs import GraphedForward
 from .streams import DEFAULT_STREAMS, StreamRing
 from .distributed import HEADER, KEYS, SingleComm, TorchDistComm, average_rows, gather_rows, shard_indices
 
@@ -32,7 +33,7 @@ class Evaluator(BaseStructure):
     @torch.no_grad()
     def __call__(self, dataset_name: str, dir_ckpt: str, img_size: Optional[int] = None, scale_factor: int = 2,
                  batch_size: int = 1, device: torch.device = torch.device("cuda:0"), cost_type: str = "iou",
-                 comm=None, streams: int = DEFAULT_STREAMS) -> dict:
+                 comm=None, streams: int = DEFAULT_STREAMS, hip_graph: bool = True) -> dict:
         assert cost_type == "iou", "the upper bound is chosen by IoU (evaluator.pyc@L216); other costs are unused"
         if not getattr(self.model, "use_binary_classifier", True):
             raise RuntimeError("the evaluator dereferences objectness unconditionally (evaluator.pyc@L219): "
@@ -51,6 +52,8 @@ class Evaluator(BaseStructure):
             raise ValueError("native-resolution evaluation runs at batch_size=1 (images differ in size)")
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
+        # recurring batch shapes replay one captured hipGraph per stream instead of 171 launches (graphs.py)
+        self._graphed = GraphedForward(self.model, enabled=hip_graph and isinstance(self.model, torch.nn.Module))
         for s in range(0, len(mine), batch_size):
             items = [dataset[i] for i in mine[s:s + batch_size]]
             x = torch.stack([it["x"] for it in items])
@@ -62,6 +65,9 @@ class Evaluator(BaseStructure):
                 gts = [it["m"].squeeze().to(device) for it in items]
                 rows_local[s:s + len(items)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gts, scale=scale)
         ring.join()
+        self.graph_stats = {"captures": self._graphed.captures, "replays": self._graphed.replays,
+                            "failed": self._graphed.failed}
+        self._graphed = None
         if self.debug:
             n_total = len(mine) * comm.world_size
             mine = list(range(comm.rank, n_total, comm.world_size))

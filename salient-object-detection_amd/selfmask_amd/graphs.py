@@ -1,0 +1,61 @@
+"""hipGraph replay of MaskFormer.forward.
+
+One forward is 171 kernel launches + 2 memsets issued by sm_maskformer_forward; the decoder's ~80 of them run 5-12 us
+each, so on a busy or slow host the launch path (not the GPU) can set the pace.  The forward allocates nothing and
+never synchronises, so it captures as is: ``GraphedForward`` records it once per (input shape, stream) into a HIP graph
+(torch.cuda.CUDAGraph, i.e. hipStreamBeginCapture / hipGraphLaunch underneath) and afterwards replays it - one launch
+per batch.  The second time a key is seen it is captured (the first call runs eagerly: it warms the kernels' function
+attributes and tells one-off shapes - a ragged last batch, native-resolution images - from recurring ones).
+
+The outputs of a replay live in the graph's memory pool and are overwritten by the next replay on the same key;
+consume them on the same stream before calling again (the Evaluator and bench.py do)."""
+from typing import Dict
+
+import torch
+
+
+class GraphedForward:
+    def __init__(self, model, enabled: bool = True):
+        self.model = model
+        self.enabled = enabled
+        self._seen: Dict[tuple, int] = {}
+        self._graphs: Dict[tuple, object] = {}
+        self.captures = 0
+        self.replays = 0
+        self.failed = None  # first capture error, kept for the caller to report; eager launches take over
+
+    @torch.no_grad()
+    def __call__(self, x: torch.Tensor, **kw):
+        if not self.enabled or kw or self.failed is not None or not x.is_cuda:
+            return self.model(x, **kw)
+        key = (x.device, tuple(x.shape), x.dtype, torch.cuda.current_stream(x.device).cuda_stream)
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n == 0:
+                return self.model(x)  # first sight: eager (also the warm-up of a later capture)
+            ent = self._capture(x, key)
+            if ent is None:
+                return self.model(x)
+        graph, static_x, out = ent[:3]
+        static_x.copy_(x, non_blocking=True)
+        graph.replay()
+        self.replays += 1
+        return out
+
+    def _capture(self, x, key):
+        try:
+            static_x = x.contiguous().float().clone()
+            # torch captures every graph on one shared side stream, so the model's per-stream workspace cache would hand
+            # all graphs the same scratch: each graph owns its workspace instead
+            ws = self.model.new_workspace(static_x)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.model(static_x, workspace=ws)
+        except Exception as e:  # capture unsupported here: keep the eager HIP path, say why once
+            self.failed = f"{type(e).__name__}: {e}"
+            return None
+        self._graphs[key] = (graph, static_x, out, ws)
+        self.captures += 1
+        return self._graphs[key]

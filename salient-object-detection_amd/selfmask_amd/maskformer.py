@@ -242,6 +242,15 @@ class MaskFormer(nn.Module):
         self._table = (w, key)
         return w
 
+    def new_workspace(self, x: torch.Tensor) -> torch.Tensor:
+        """A private scratch buffer for forwards of x's shape (for callers that keep several forwards in flight or
+        capture the forward into a hipGraph: pass it as ``forward(x, workspace=...)``)."""
+        B, _, H, W = x.shape
+        nbytes = N.load().sm_forward_workspace_bytes(self._weights(), B, H, W)
+        if nbytes == 0:
+            raise RuntimeError("sm_forward_workspace_bytes returned 0 (bad shape)")
+        return torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+
     def _get_workspace(self, w: N.Weights, x: torch.Tensor) -> torch.Tensor:
         B, _, H, W = x.shape
         # one workspace per (shape, stream): batches in flight on different streams must not share scratch
@@ -260,7 +269,7 @@ class MaskFormer(nn.Module):
     # ---- forward ----------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, x: torch.Tensor, encoder_only: bool = False, skip_decoder: bool = False,
-                return_logits: bool = False) -> Dict[str, torch.Tensor]:
+                return_logits: bool = False, workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """x: (B,3,H,W) normalised image on a HIP device.  Output dict as maskformer.py:240-251:
         5-D path -> {"objectness" (B,L,nq,1), "mask_pred" (B,L,nq,2gh,2gw) in [0,1], "features" (B,384)};
         3-D path (return_intermediate=False, use_binary_classifier=False) -> {"mask_pred" logits (B,nq,2gh,2gw),
@@ -284,7 +293,7 @@ class MaskFormer(nn.Module):
         gh, gw = ceil(H / p), ceil(W / p)
         L, nq, dev = self.n_decoder_layers, self.n_queries, x.device
         w = self._weights()
-        ws = self._get_workspace(w, x)
+        ws = workspace if workspace is not None else self._get_workspace(w, x)
         io = N.ForwardIO()
         io.x, io.B, io.H, io.W = x.data_ptr(), B, H, W
         if encoder_only:

@@ -106,4 +106,8 @@ def test_batches_in_flight_on_several_streams_give_identical_rows(tmp_path):
     for n in (1, 2, 3):
         ev("duts", dir_ckpt=str(tmp_path / f"s{n}"), img_size=224, batch_size=3, device=DEV, streams=n)
         rows.append(ev.last_rows.copy())
+        # 13 images in batches of 3 = 4 full batches + 1 ragged: every stream that sees the full shape twice captures it
+        assert ev.graph_stats["failed"] is None and ev.graph_stats["replays"] >= 1
     assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows[0], rows[2])
+    ev("duts", dir_ckpt=str(tmp_path / "eager"), img_size=224, batch_size=3, device=DEV, streams=2, hip_graph=False)
+    assert np.array_equal(rows[0], ev.last_rows) and ev.graph_stats["replays"] == 0

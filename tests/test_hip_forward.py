@@ -133,6 +133,29 @@ def test_full_bench_batch_64_properties(mode):
     assert (out["objectness"][pick].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
 
 
+def test_hip_graph_replay_gives_the_eager_bits():
+    """graphs.GraphedForward: first call eager, second captures + replays, later ones replay; a new batch through the
+    captured graph equals the eager forward bit for bit, on the default stream and on a side stream."""
+    from selfmask_amd import GraphedForward
+    m = _model(16, 3, "soft")
+    xs = [torch.from_numpy(synthetic_images(200 + i, (3, 3, 224, 224))).to(DEV) for i in range(4)]
+    eager = [{k: v.clone() for k, v in m(x).items()} for x in xs]
+    for stream in (None, torch.cuda.Stream()):
+        g = GraphedForward(m)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            for x, e in zip(xs, eager):
+                out = g(x)
+                for k in e:
+                    assert torch.equal(out[k], e[k]), k
+        torch.cuda.synchronize()
+        assert g.failed is None and g.captures == 1 and g.replays == 3
+    # a shape seen once stays eager
+    g = GraphedForward(m)
+    g(xs[0][:2])
+    assert g.captures == 0 and g.replays == 0
+
+
 def test_encoder_only_and_3d_path():
     m = _model(16, 0, "soft")
     x = torch.from_numpy(synthetic_images(5, (2, 3, 224, 224))).to(DEV)
