@@ -224,6 +224,10 @@ typedef struct sm_bilateral_args {
  * largest label (background included). */
 size_t sm_bilateral_workspace_bytes(int32_t H, int32_t W, double sigma_spatial, double sigma_luma, double sigma_chroma);
 int sm_bilateral_solver_f64(const sm_bilateral_args* args, void* stream);
+/* n_images solves of one size in one launch sequence (blockIdx.z = image): img (n,H,W,3), target / soft (n,H,W) f64,
+ * binary (n,H,W) u8, info (n,4) or NULL, workspace >= n * sm_bilateral_workspace_bytes(...).  The solver's long kernels
+ * use one workgroup per image, so a batch fills the GPU where a single solve occupies one CU. */
+int sm_bilateral_solver_batch_f64(const sm_bilateral_args* args, int32_t n_images, void* stream);
 
 /* ---- whole forward --------------------------------------------------------------------------------------------- */
 typedef struct sm_enc_layer {

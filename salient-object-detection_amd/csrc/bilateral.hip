@@ -14,6 +14,7 @@
 //   * post-processing (threshold, binary_fill_holes, 4-connected label, second-largest label incl. background) is
 //     an atomicMin union-find run by one workgroup (labels are ordered by their first raster pixel, as ndimage.label).
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 
 #pragma clang fp contract(off)  // the oracle / reference use separate fp64 mul and add; fused ops are explicit
@@ -45,6 +46,20 @@ struct BsWs {  // workspace carve-up
     unsigned long long* keys;  // [4]
     size_t total;
 };
+
+// Batched solves: image i of a launch lives at workspace + i * ws_bytes and at pixel offset i * npx of the image /
+// target / output arrays; blockIdx.z is the image.  Single-workgroup kernels then run one workgroup PER IMAGE, which
+// is what fills the GPU (a lone solve occupies one CU).
+struct BsBatch {
+    size_t ws_bytes;
+};
+__device__ __forceinline__ BsWs bs_image_ws(BsWs w, size_t bytes) {
+    auto mv = [&](auto*& ptr) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<char*>(ptr) + bytes); };
+    mv(w.bitmap); mv(w.wordrank); mv(w.cell); mv(w.idx); mv(w.vcell); mv(w.nbr);
+    mv(w.m); mv(w.ws); mv(w.b); mv(w.n0); mv(w.n1); mv(w.diag); mv(w.minv); mv(w.x); mv(w.r); mv(w.p); mv(w.q);
+    mv(w.parent); mv(w.bin); mv(w.csize); mv(w.scal); mv(w.keys);
+    return w;
+}
 
 static BsDims make_dims(int H, int W, double ss, double sl, double sc) {
     BsDims d;
@@ -84,7 +99,9 @@ static BsWs carve_bs(const BsDims& d, char* base) {
 }
 
 // ---- grid construction ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bs_cells_kernel(const unsigned char* __restrict__ img, BsDims d, BsWs w) {
+__global__ __launch_bounds__(256) void bs_cells_kernel(const unsigned char* __restrict__ img, BsDims d, BsWs w, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
+    img += (size_t)blockIdx.z * d.npx * 3;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= d.npx) return;
     const int y = p / d.W, x = p - y * d.W;
@@ -101,7 +118,8 @@ __global__ __launch_bounds__(256) void bs_cells_kernel(const unsigned char* __re
 }
 
 // exclusive prefix sum of popcount(bitmap[w]) by one workgroup; scal[0] = number of vertices
-__global__ __launch_bounds__(BS_THREADS) void bs_scan_kernel(BsDims d, BsWs w) {
+__global__ __launch_bounds__(BS_THREADS) void bs_scan_kernel(BsDims d, BsWs w, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
     __shared__ unsigned part[BS_THREADS];
     const int t = threadIdx.x;
     const int per = (d.nwords + BS_THREADS - 1) / BS_THREADS;
@@ -126,7 +144,8 @@ __device__ __forceinline__ int bs_rank(const BsWs& w, unsigned cell) {
     return (int)(w.wordrank[cell >> 5] + __popc(word & ((1u << bit) - 1u)));
 }
 
-__global__ __launch_bounds__(256) void bs_vertices_kernel(BsDims d, BsWs w) {
+__global__ __launch_bounds__(256) void bs_vertices_kernel(BsDims d, BsWs w, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= d.nwords) return;
     unsigned word = w.bitmap[i], r = w.wordrank[i];
@@ -137,13 +156,15 @@ __global__ __launch_bounds__(256) void bs_vertices_kernel(BsDims d, BsWs w) {
     }
 }
 
-__global__ __launch_bounds__(256) void bs_pixel_vertex_kernel(BsDims d, BsWs w) {
+__global__ __launch_bounds__(256) void bs_pixel_vertex_kernel(BsDims d, BsWs w, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < d.npx) w.idx[p] = bs_rank(w, w.cell[p]);
 }
 
 // blur matrices (:66-81) as neighbour tables: +-1 along each of the 5 lattice axes, present iff the cell is occupied
-__global__ __launch_bounds__(256) void bs_neighbors_kernel(BsDims d, BsWs w, int maxV) {
+__global__ __launch_bounds__(256) void bs_neighbors_kernel(BsDims d, BsWs w, int maxV, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int V = w.scal[0];
     if (v >= V) return;
@@ -171,7 +192,9 @@ __global__ __launch_bounds__(256) void bs_neighbors_kernel(BsDims d, BsWs w, int
 
 // splat of {1, w, t*w} (:87-88, :133-137): one workgroup per ss x ss spatial cell; every vertex lives in exactly one
 // such cell, its leader (first pixel in raster order) sums the cell's pixels of that vertex in ascending pixel order.
-__global__ void bs_splat_kernel(const double* __restrict__ target, double conf, BsDims d, BsWs w) {
+__global__ void bs_splat_kernel(const double* __restrict__ target, double conf, BsDims d, BsWs w, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
+    target += (size_t)blockIdx.z * d.npx;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int n = d.ss * d.ss;
     int* vid = (int*)lds;
@@ -243,8 +266,9 @@ __device__ __forceinline__ double bs_matvec(const double* __restrict__ p, const 
 }
 
 __global__ __launch_bounds__(BS_THREADS) void bs_solve_kernel(BsWs w, int maxV, double lam, double diag_min, int maxiter,
-                                                             double tol) {
+                                                             double tol, BsBatch batch) {
     __shared__ double red[BS_THREADS / 64];
+    w = bs_image_ws(w, blockIdx.z * batch.ws_bytes);
     const int t = threadIdx.x, V = w.scal[0];
     double *na = w.n0, *nb = w.n1;
     // bistochastize (:107-118): n <- sqrt(n*m / blur(n)) x10 from n = 1, then m <- n * blur(n)
@@ -310,7 +334,9 @@ __global__ __launch_bounds__(BS_THREADS) void bs_solve_kernel(BsWs w, int maxV, 
     if (t == 0) w.scal[1] = iters;
 }
 
-__global__ __launch_bounds__(256) void bs_slice_kernel(BsDims d, BsWs w, double* __restrict__ soft) {
+__global__ __launch_bounds__(256) void bs_slice_kernel(BsDims d, BsWs w, double* __restrict__ soft, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
+    soft += (size_t)blockIdx.z * d.npx;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p < d.npx) soft[p] = w.x[w.idx[p]];  // S^T y (:90-91)
 }
@@ -350,8 +376,11 @@ __device__ void uf_label(int* parent, const unsigned char* bin, int H, int W, bo
 }
 
 __global__ __launch_bounds__(BS_THREADS) void bs_post_kernel(BsDims d, BsWs w, const double* __restrict__ soft,
-                                                            unsigned char* __restrict__ out) {
+                                                            unsigned char* __restrict__ out, BsBatch bb) {
     __shared__ unsigned long long best, second;
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
+    soft += (size_t)blockIdx.z * d.npx;
+    out += (size_t)blockIdx.z * d.npx;
     __shared__ unsigned nfg, ncomp;
     const int npx = d.npx, t = threadIdx.x, H = d.H, W = d.W;
     int* parent = w.parent;
@@ -407,7 +436,9 @@ __global__ __launch_bounds__(BS_THREADS) void bs_post_kernel(BsDims d, BsWs w, c
     if (t == 0) { w.scal[2] = (int)ncomp; w.scal[3] = none ? -2 : pick_root; }
 }
 
-__global__ void bs_info_kernel(BsWs w, int* info) {
+__global__ void bs_info_kernel(BsWs w, int* info, BsBatch bb) {
+    w = bs_image_ws(w, blockIdx.z * bb.ws_bytes);
+    info += 4 * blockIdx.z;
     if (threadIdx.x < 4) info[threadIdx.x] = w.scal[threadIdx.x];
 }
 
@@ -421,13 +452,15 @@ extern "C" size_t sm_bilateral_workspace_bytes(int32_t H, int32_t W, double sigm
     return sm::carve_bs(d, nullptr).total;
 }
 
-extern "C" int sm_bilateral_solver_f64(const sm_bilateral_args* a, void* stream) {
+extern "C" int sm_bilateral_solver_batch_f64(const sm_bilateral_args* a, int32_t n_images, void* stream) {
     SM_REQUIRE(a && a->img && a->target && a->soft && a->binary && a->workspace, "sm_bilateral_solver_f64: null pointer");
+    SM_REQUIRE(n_images >= 1 && n_images <= 65535, "sm_bilateral_solver_batch_f64: n_images=%d (1..65535)", n_images);
     SM_REQUIRE(a->H > 0 && a->W > 0 && a->sigma_spatial >= 1 && a->sigma_spatial == (int)a->sigma_spatial &&
                    a->sigma_luma > 0 && a->sigma_chroma > 0,
                "sm_bilateral_solver_f64: bad shape / sigmas (sigma_spatial must be a positive integer)");
-    const size_t need = sm_bilateral_workspace_bytes(a->H, a->W, a->sigma_spatial, a->sigma_luma, a->sigma_chroma);
-    SM_REQUIRE(need != 0, "sm_bilateral_solver_f64: lattice too large (>2^31 cells) or sigma_spatial > 32");
+    const size_t need1 = sm_bilateral_workspace_bytes(a->H, a->W, a->sigma_spatial, a->sigma_luma, a->sigma_chroma);
+    SM_REQUIRE(need1 != 0, "sm_bilateral_solver_f64: lattice too large (>2^31 cells) or sigma_spatial > 32");
+    const size_t need = need1 * (size_t)n_images;
     if (a->workspace_bytes < need || ((uintptr_t)a->workspace % 256) != 0) {
         sm::set_error("sm_bilateral_solver_f64: workspace %zu B < %zu B needed (or not 256-B aligned)", a->workspace_bytes,
                       need);
@@ -436,25 +469,32 @@ extern "C" int sm_bilateral_solver_f64(const sm_bilateral_args* a, void* stream)
     hipStream_t st = (hipStream_t)stream;
     const sm::BsDims d = sm::make_dims(a->H, a->W, a->sigma_spatial, a->sigma_luma, a->sigma_chroma);
     const sm::BsWs w = sm::carve_bs(d, (char*)a->workspace);
+    const sm::BsBatch bb = {need1};  // per-image workspaces are laid end to end (need1 is a multiple of 256)
+    const unsigned nz = (unsigned)n_images;
     const int maxV = d.npx;
-    if (hipMemsetAsync(w.bitmap, 0, (size_t)d.nwords * 4, st) != hipSuccess) {
-        sm::set_error("sm_bilateral_solver_f64: hipMemsetAsync failed");
+    // the occupancy bitmap is the first region of each image's workspace: one strided memset clears them all
+    if (hipMemset2DAsync(w.bitmap, need1, 0, (size_t)d.nwords * 4, (size_t)n_images, st) != hipSuccess) {
+        sm::set_error("sm_bilateral_solver_f64: hipMemset2DAsync failed");
         return SM_ELAUNCH;
     }
     const int pb = (d.npx + 255) / 256;
-    hipLaunchKernelGGL(sm::bs_cells_kernel, dim3(pb), dim3(256), 0, st, a->img, d, w);
-    hipLaunchKernelGGL(sm::bs_scan_kernel, dim3(1), dim3(sm::BS_THREADS), 0, st, d, w);
-    hipLaunchKernelGGL(sm::bs_vertices_kernel, dim3((d.nwords + 255) / 256), dim3(256), 0, st, d, w);
-    hipLaunchKernelGGL(sm::bs_pixel_vertex_kernel, dim3(pb), dim3(256), 0, st, d, w);
-    hipLaunchKernelGGL(sm::bs_neighbors_kernel, dim3(pb), dim3(256), 0, st, d, w, maxV);
+    hipLaunchKernelGGL(sm::bs_cells_kernel, dim3(pb, 1, nz), dim3(256), 0, st, a->img, d, w, bb);
+    hipLaunchKernelGGL(sm::bs_scan_kernel, dim3(1, 1, nz), dim3(sm::BS_THREADS), 0, st, d, w, bb);
+    hipLaunchKernelGGL(sm::bs_vertices_kernel, dim3((d.nwords + 255) / 256, 1, nz), dim3(256), 0, st, d, w, bb);
+    hipLaunchKernelGGL(sm::bs_pixel_vertex_kernel, dim3(pb, 1, nz), dim3(256), 0, st, d, w, bb);
+    hipLaunchKernelGGL(sm::bs_neighbors_kernel, dim3(pb, 1, nz), dim3(256), 0, st, d, w, maxV, bb);
     const int n = d.ss * d.ss;
     const int threads = ((n + 63) / 64) * 64;
     const size_t lds = ((n * 4 + 15) & ~15) + (size_t)n * 8;
-    hipLaunchKernelGGL(sm::bs_splat_kernel, dim3(d.NX, d.NY), dim3(threads), lds, st, a->target, a->confidence, d, w);
-    hipLaunchKernelGGL(sm::bs_solve_kernel, dim3(1), dim3(sm::BS_THREADS), 0, st, w, maxV, a->lam, a->a_diag_min,
-                       a->cg_maxiter, a->cg_tol);
-    hipLaunchKernelGGL(sm::bs_slice_kernel, dim3(pb), dim3(256), 0, st, d, w, a->soft);
-    hipLaunchKernelGGL(sm::bs_post_kernel, dim3(1), dim3(sm::BS_THREADS), 0, st, d, w, a->soft, a->binary);
-    if (a->info) hipLaunchKernelGGL(sm::bs_info_kernel, dim3(1), dim3(64), 0, st, w, a->info);
+    hipLaunchKernelGGL(sm::bs_splat_kernel, dim3(d.NX, d.NY, nz), dim3(threads), lds, st, a->target, a->confidence, d, w, bb);
+    hipLaunchKernelGGL(sm::bs_solve_kernel, dim3(1, 1, nz), dim3(sm::BS_THREADS), 0, st, w, maxV, a->lam, a->a_diag_min,
+                       a->cg_maxiter, a->cg_tol, bb);
+    hipLaunchKernelGGL(sm::bs_slice_kernel, dim3(pb, 1, nz), dim3(256), 0, st, d, w, a->soft, bb);
+    hipLaunchKernelGGL(sm::bs_post_kernel, dim3(1, 1, nz), dim3(sm::BS_THREADS), 0, st, d, w, a->soft, a->binary, bb);
+    if (a->info) hipLaunchKernelGGL(sm::bs_info_kernel, dim3(1, 1, nz), dim3(64), 0, st, w, a->info, bb);
     return sm::check_launch("sm_bilateral_solver_f64");
+}
+
+extern "C" int sm_bilateral_solver_f64(const sm_bilateral_args* a, void* stream) {
+    return sm_bilateral_solver_batch_f64(a, 1, stream);
 }

@@ -336,6 +336,8 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     const int nst = env ? atoi(env) : 0;
     if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
     if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
+    if (bm == 128 && bn == 128 && nst == 8) return sm::launch_gemm_h<128, 128, 2, 2, 4, 2>(a, st);  // 8 waves of 64x32
+    if (bm == 128 && bn == 128 && nst == 9) return sm::launch_gemm_h<128, 128, 2, 4, 2, 2>(a, st);  // 8 waves of 32x64
     if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2>(a, st);
     if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2, 2, 2, 3>(a, st);
     if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 2 ? sm::launch_gemm_h<64, 64, 2, 2, 2, 5>(a, st) : sm::launch_gemm_h<64, 64, 3, 2, 2, 3>(a, st);

@@ -123,6 +123,7 @@ SYMBOLS = {
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "sm_bilateral_solver_f64": (C.c_int, [C.POINTER(BilateralArgs), fp]),
+    "sm_bilateral_solver_batch_f64": (C.c_int, [C.POINTER(BilateralArgs), C.c_int32, fp]),
     "sm_forward_workspace_bytes": (C.c_size_t, [C.POINTER(Weights), C.c_int32, C.c_int32, C.c_int32]),
     "sm_maskformer_forward": (C.c_int, [C.POINTER(Weights), C.POINTER(ForwardIO), fp, C.c_size_t, fp]),
     "sm_forward_timing": (C.c_int, [C.c_int]),

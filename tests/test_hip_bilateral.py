@@ -51,3 +51,27 @@ def test_degenerate_targets():
         soft, binary = bilateral_solver_output(img, tgt, device=DEV)
         rs, rb, _ = B.bilateral_solver_output(img, tgt)
         assert np.abs(soft - rs).max() <= 1e-12 and np.array_equal(binary, rb)
+
+
+def test_batched_solve_equals_per_image_solves():
+    """sm_bilateral_solver_batch_f64 (one workgroup per image in the long kernels): every image of a batch of different
+    scenes - including an all-zero target - gives the bits of its own single solve, vertex / iteration counts included."""
+    from selfmask_amd.bilateral_solver import bilateral_solver_batch_device
+    h, w, n = 120, 152, 7
+    rng = np.random.Generator(np.random.PCG64(11))
+    yy, xx = np.mgrid[:h, :w]
+    imgs, tgts = [], []
+    for i in range(n):
+        img = np.clip(np.stack([110 + 50 * np.sin(xx / (11.0 + 3 * i)), 90 + 60 * np.cos(yy / (9.0 + 2 * i)),
+                                80 + 0.5 * xx + 0 * yy], -1) + rng.standard_normal((h, w, 3)) * (3 + 2 * i), 0, 255).astype(np.uint8)
+        blob = (((yy - h * rng.uniform(.35, .65)) / (h * .25)) ** 2 + ((xx - w * rng.uniform(.35, .65)) / (w * .2)) ** 2) <= 1
+        tgts.append(np.zeros((h, w)) if i == 3 else np.clip(0.15 + 0.7 * blob + rng.standard_normal((h, w)) * 0.1, 0, 1))
+        imgs.append(img)
+    I = torch.from_numpy(np.stack(imgs)).to(DEV)
+    T = torch.from_numpy(np.stack(tgts)).to(DEV)
+    soft, binary, info = bilateral_solver_batch_device(I, T, return_info=True)
+    for i in range(n):
+        s1, b1, i1 = bilateral_solver_output_device(I[i], T[i], return_info=True)
+        assert torch.equal(soft[i], s1) and torch.equal(binary[i], b1) and torch.equal(info[i], i1), i
+    rs, rb, _ = B.bilateral_solver_output(imgs[5], tgts[5])
+    assert np.abs(soft[5].cpu().numpy() - rs).max() <= 1e-9 and np.array_equal(binary[5].cpu().numpy().astype(bool), rb)
