@@ -8,6 +8,9 @@ from .misc import get_model, set_seeds  # noqa: F401
 from .base_structure import BaseStructure  # noqa: F401
 from .streams import StreamRing  # noqa: F401
 from .graphs import GraphedForward  # noqa: F401
+from .bilateral_solver import (bilateral_solver_output, bilateral_solver_output_device,  # noqa: F401
+                               bilateral_solver_batch_device)
+from .evaluator import Evaluator  # noqa: F401
 from .state_layout import state_shapes, synthetic_state_dict, synthetic_images  # noqa: F401
 
 __version__ = "0.1.0"
