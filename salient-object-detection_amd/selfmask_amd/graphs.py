@@ -51,7 +51,9 @@ class GraphedForward:
             # all graphs the same scratch: each graph owns its workspace instead
             ws = self.model.new_workspace(static_x)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: the capture only polices this thread - an RCCL watchdog thread polling its events while we
+            # capture (torch.distributed is initialised in multi-GPU runs) must not invalidate it
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self.model(static_x, workspace=ws)
         except Exception as e:  # capture unsupported here: keep the eager HIP path, say why once
             self.failed = f"{type(e).__name__}: {e}"
