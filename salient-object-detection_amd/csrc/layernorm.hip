@@ -1,5 +1,5 @@
-// LayerNorm over rows of 384 floats: one 64-lane wave per row, 6 elements per lane held in registers,
-// mean and (two-pass, biased) variance by wavefront shuffle butterflies.  HBM-bound: reads x once, writes y once.
+// LayerNorm over rows of 384 floats: four rows per 64-lane wave (16 lanes x 24 register-resident elements per row),
+// mean and (two-pass, biased) variance by shuffle butterflies.  HBM-bound: reads x once, writes y once.
 // Reference: nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6), transformer_decoder.py:280,290,295,
 // 139 (eps 1e-5).
 #include "common.h"
@@ -10,40 +10,66 @@ __device__ __forceinline__ int64_t map_row(int r, sm_row_map m) {
     return m.group > 0 ? (int64_t)(r / m.group) * m.stride + m.offset + r % m.group : r;
 }
 
-__global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;  // whole wave exits together
-    const float* xr = a.x + map_row(row, a.in_map) * a.ldx;
-    float2 v[3];
+// 16 lanes per row (four rows per wave), each lane owning the three 8-element groups g = l16 + 16 i: every access is a
+// 16-B (fp32: 2 x 16 B) piece and an F16X2 group leaves as one contiguous 32-B store; statistics are 4-step butterflies
+// inside the 16-lane group.
+__device__ __forceinline__ float group16_sum(float v) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) v[i] = *reinterpret_cast<const float2*>(xr + i * 128 + lane * 2);
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = row < a.rows;
+    const int rrow = live ? row : a.rows - 1;  // dead groups shadow the last row (they join the shuffles, never store)
+    const float* xr = a.x + map_row(rrow, a.in_map) * a.ldx;
+    float v[3][8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float4 p0 = *reinterpret_cast<const float4*>(xr + (l16 + 16 * i) * 8);
+        const float4 p1 = *reinterpret_cast<const float4*>(xr + (l16 + 16 * i) * 8 + 4);
+        v[i][0] = p0.x; v[i][1] = p0.y; v[i][2] = p0.z; v[i][3] = p0.w;
+        v[i][4] = p1.x; v[i][5] = p1.y; v[i][6] = p1.z; v[i][7] = p1.w;
+    }
     if (a.n_partials > 0) {  // fused split-K reduction: slices in order, then bias, then the residual
         for (int sidx = 1; sidx < a.n_partials; ++sidx) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const float2 t = *reinterpret_cast<const float2*>(xr + sidx * a.partial_stride + i * 128 + lane * 2);
-                v[i].x += t.x; v[i].y += t.y;
+                const float* t = xr + sidx * a.partial_stride + (l16 + 16 * i) * 8;
+                const float4 p0 = *reinterpret_cast<const float4*>(t), p1 = *reinterpret_cast<const float4*>(t + 4);
+                v[i][0] += p0.x; v[i][1] += p0.y; v[i][2] += p0.z; v[i][3] += p0.w;
+                v[i][4] += p1.x; v[i][5] += p1.y; v[i][6] += p1.z; v[i][7] += p1.w;
             }
         }
-        const float* rr = a.residual + map_row(row, a.in_map) * a.ldx;
+        const float* rr = a.residual + map_row(rrow, a.in_map) * a.ldx;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float2 bb = *reinterpret_cast<const float2*>(a.pre_bias + i * 128 + lane * 2);
-            const float2 t = *reinterpret_cast<const float2*>(rr + i * 128 + lane * 2);
-            v[i].x = t.x + (v[i].x + bb.x); v[i].y = t.y + (v[i].y + bb.y);
+            const int k = (l16 + 16 * i) * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 bb = *reinterpret_cast<const float4*>(a.pre_bias + k + 4 * h);
+                const float4 t = *reinterpret_cast<const float4*>(rr + k + 4 * h);
+                v[i][4 * h + 0] = t.x + (v[i][4 * h + 0] + bb.x); v[i][4 * h + 1] = t.y + (v[i][4 * h + 1] + bb.y);
+                v[i][4 * h + 2] = t.z + (v[i][4 * h + 2] + bb.z); v[i][4 * h + 3] = t.w + (v[i][4 * h + 3] + bb.w);
+            }
         }
     }
-    float s = (v[0].x + v[0].y) + (v[1].x + v[1].y) + (v[2].x + v[2].y);
-    const float mean = wave_sum(s) * (1.0f / 384.0f);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    const float mean = group16_sum(s) * (1.0f / 384.0f);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        v[i].x -= mean;
-        v[i].y -= mean;
-        q += v[i].x * v[i].x + v[i].y * v[i].y;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / 384.0f) + a.eps);
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] -= mean;
+            q += v[i][e] * v[i][e];
+        }
+    const float rstd = 1.0f / sqrtf(group16_sum(q) * (1.0f / 384.0f) + a.eps);
+    if (!live) return;
     const int64_t orow = map_row(row, a.out_map);
     float* yr = a.y ? a.y + orow * a.ldy : nullptr;
     float* ysr = a.ys ? a.ys + orow * a.ldy : nullptr;
@@ -51,19 +77,33 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
     const float* ar = a.y2 ? a.add + (int64_t)(row % a.add_rows) * SM_EMBED : nullptr;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float2 gm = *reinterpret_cast<const float2*>(a.gamma + i * 128 + lane * 2);
-        const float2 bt = *reinterpret_cast<const float2*>(a.beta + i * 128 + lane * 2);
-        float2 o;
-        o.x = v[i].x * rstd * gm.x + bt.x;
-        o.y = v[i].y * rstd * gm.y + bt.y;
-        if (yr) *reinterpret_cast<float2*>(yr + i * 128 + lane * 2) = o;
-        if (ysr) store_f16x2_2(ysr, i * 128 + lane * 2, o.x, o.y);
+        const int k = (l16 + 16 * i) * 8;
+        float o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 gm = *reinterpret_cast<const float4*>(a.gamma + k + 4 * h);
+            const float4 bt = *reinterpret_cast<const float4*>(a.beta + k + 4 * h);
+            o[4 * h + 0] = v[i][4 * h + 0] * rstd * gm.x + bt.x; o[4 * h + 1] = v[i][4 * h + 1] * rstd * gm.y + bt.y;
+            o[4 * h + 2] = v[i][4 * h + 2] * rstd * gm.z + bt.z; o[4 * h + 3] = v[i][4 * h + 3] * rstd * gm.w + bt.w;
+        }
+        const float (&o0)[4] = *reinterpret_cast<const float (*)[4]>(&o[0]);
+        const float (&o1)[4] = *reinterpret_cast<const float (*)[4]>(&o[4]);
+        if (yr) {
+            *reinterpret_cast<float4*>(yr + k) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(yr + k + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (ysr) store_f16x2_8(ysr, k, o0, o1);
         if (y2r) {
-            const float2 ad = *reinterpret_cast<const float2*>(ar + i * 128 + lane * 2);
-            o.x += ad.x;
-            o.y += ad.y;
-            if (a.y2_f16x2) store_f16x2_2(y2r, i * 128 + lane * 2, o.x, o.y);
-            else *reinterpret_cast<float2*>(y2r + i * 128 + lane * 2) = o;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 ad = *reinterpret_cast<const float4*>(ar + k + 4 * h);
+                o[4 * h + 0] += ad.x; o[4 * h + 1] += ad.y; o[4 * h + 2] += ad.z; o[4 * h + 3] += ad.w;
+            }
+            if (a.y2_f16x2) store_f16x2_8(y2r, k, o0, o1);
+            else {
+                *reinterpret_cast<float4*>(y2r + k) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(y2r + k + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
         }
     }
 }
@@ -80,13 +120,17 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __rest
 extern "C" int sm_layernorm_rows_f32(const sm_ln_args* a, void* stream) {
     SM_REQUIRE(a && a->x && a->gamma && a->beta && (a->y || a->ys), "sm_layernorm_f32: null pointer");
     if (a->ys || a->y2_f16x2) SM_REQUIRE(a->ldy % 8 == 0 && a->ldy2 % 8 == 0, "sm_layernorm_f32: F16X2 outputs need ld %% 8 == 0");
-    SM_REQUIRE(a->rows >= 0 && a->ldx >= SM_EMBED && a->ldy >= SM_EMBED && a->ldx % 2 == 0 && a->ldy % 2 == 0,
-               "sm_layernorm_f32: bad rows/strides");
+    SM_REQUIRE(a->rows >= 0 && a->ldx >= SM_EMBED && a->ldy >= SM_EMBED && a->ldx % 4 == 0 && a->ldy % 4 == 0,
+               "sm_layernorm_f32: bad rows/strides (row strides must be multiples of 4 floats)");
+    SM_REQUIRE(((uintptr_t)a->x | (uintptr_t)a->y | (uintptr_t)a->ys | (uintptr_t)a->y2 | (uintptr_t)a->gamma | (uintptr_t)a->beta |
+                (uintptr_t)a->add | (uintptr_t)a->pre_bias | (uintptr_t)a->residual) % 16 == 0,
+               "sm_layernorm_f32: pointers must be 16-B aligned");
     SM_REQUIRE(a->in_map.group >= 0 && a->out_map.group >= 0, "sm_layernorm_f32: bad row map");
-    if (a->n_partials > 0) SM_REQUIRE(a->pre_bias && a->residual && a->partial_stride > 0, "sm_layernorm_f32: bad partials");
-    if (a->y2) SM_REQUIRE(a->add && a->add_rows > 0 && a->ldy2 >= SM_EMBED && a->ldy2 % 2 == 0, "sm_layernorm_f32: bad y2/add");
+    if (a->n_partials > 0)
+        SM_REQUIRE(a->pre_bias && a->residual && a->partial_stride > 0 && a->partial_stride % 4 == 0, "sm_layernorm_f32: bad partials");
+    if (a->y2) SM_REQUIRE(a->add && a->add_rows > 0 && a->ldy2 >= SM_EMBED && a->ldy2 % 4 == 0, "sm_layernorm_f32: bad y2/add");
     if (a->rows == 0) return SM_OK;
-    hipLaunchKernelGGL(sm::layernorm384_kernel, dim3((a->rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(sm::layernorm384_kernel, dim3((a->rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
     return sm::check_launch("sm_layernorm_f32");
 }
 
