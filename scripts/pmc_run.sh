@@ -8,7 +8,7 @@ cd "$ROOT"
 mkdir -p gpurun_out
 rocprofv3 --pmc $CNT --output-format csv -d gpurun_out/$TAG -- python3 "$@" > gpurun_out/$TAG.log 2>&1
 echo rc=$?
-F=$(find gpurun_out/$TAG -name "*counter_collection.csv" | head -1)
+F=$(ls -t $(find gpurun_out/$TAG -name "*counter_collection.csv") | head -1)
 python3 - "$F" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
