@@ -192,8 +192,10 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
 }
 
 // K1b: sum the per-chunk partials of an image (one thread per query)
+__device__ int select_query(const sm_eval_args& a, const QueryStats* qs, int b, int which, bool write_ious);
+
 __global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
-                                                               QueryStats* qs, GtStats* gs, int nchunk) {
+                                                               QueryStats* qs, GtStats* gs, int* sel, int nchunk) {
     const int b = blockIdx.x, t = threadIdx.x;
     if (t < a.nq) {
         QueryStats o; o.inter = 0; o.uni = 0;
@@ -211,6 +213,21 @@ __global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, c
         }
         gs[b] = o;
     }
+    // the two selected queries of the image, once, for every later kernel (each of their ~10^4 workgroups used to
+    // repeat this 20-load chain on one thread before starting)
+    __syncthreads();
+    if (t < 2) sel[b * 2 + t] = select_query(a, qs, b, t, true);
+}
+
+// K2b: adaptive threshold 2 * mean(p) of the selected masks (f_measure.py:76): fixed-order fp64 sum of K2's partials
+__global__ __launch_bounds__(64) void eval_adapt_kernel(sm_eval_args a, const double* part, float* thr_adapt, int nchunk) {
+    const int which = blockIdx.x, b = blockIdx.y;
+    if (threadIdx.x != 0) return;
+    const sm_eval_image im = a.images[b];
+    double sp = 0.0;
+    const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
+    for (int k = 0; k < nchunk; ++k) sp += p0[(int64_t)k * EV_NACC];
+    thr_adapt[b * 2 + which] = SM_MUL(2.0f, (float)(sp / (double)(im.H * im.W)));
 }
 
 // selection (evaluator.pyc@L216-221): which = 0 arg-max objectness, which = 1 arg-max IoU (first maximum)
@@ -265,17 +282,15 @@ __device__ float object_score(double n, double s, double ss) {
 }
 
 // K2: sum of the selected mask's probabilities per chunk (needed for the adaptive threshold 2*mean before K3)
-__global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, const QueryStats* qs, double* part,
+__global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, const int* __restrict__ sel, double* part,
                                                               int nchunk) {
     __shared__ double red[EV_THREADS / 64];
-    __shared__ int sel_q;
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W, base = c * EV_CHUNK;
     double* slot = part + ((int64_t)(b * 2 + which) * nchunk + c) * EV_NACC;
     if (base >= npx) { if (threadIdx.x == 0) slot[0] = 0.0; return; }
-    if (threadIdx.x == 0) sel_q = select_query(a, qs, b, which, c == 0);
-    __syncthreads();
+    const int sel_q = sel[b * 2 + which];
     const float* __restrict__ m = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)sel_q * a.mh * a.mw;
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
@@ -298,13 +313,11 @@ struct MetricCounts { unsigned tp5, np5, ng, eq5, tpa, npa; unsigned hist[2][256
 
 // K3: everything else in one pass per chunk.  Integer counts and the 2x256-bin histogram use integer atomics;
 // the fp64 moments are written as per-chunk partials and summed in a fixed order by K4 (bit-reproducible).
-__global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs,
-                                                                  double* part, MetricCounts* cnt, int nchunk) {
+__global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a, const int* __restrict__ sel, const float* __restrict__ thr_adapt_all,
+                                                                  const GtStats* gs, double* part, MetricCounts* cnt, int nchunk) {
     __shared__ unsigned hist[2][256];
     __shared__ float thr[256];
     __shared__ double red[EV_THREADS / 64][EV_NACC];
-    __shared__ int sel_q;
-    __shared__ float s_thr_adapt;
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W, base = c * EV_CHUNK;
@@ -316,13 +329,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
         mz->hist[0][tid] = 0; mz->hist[1][tid] = 0;
         return;
     }
-    if (tid == 0) {
-        sel_q = select_query(a, qs, b, which, false);
-        double sp = 0.0;  // fixed-order sum of the per-chunk partials of K2
-        const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
-        for (int k = 0; k < nchunk; ++k) sp += p0[(int64_t)k * EV_NACC];
-        s_thr_adapt = SM_MUL(2.0f, (float)(sp / (double)npx));  // f_measure.py:76
-    }
+    const int sel_q = sel[b * 2 + which];
     hist[0][tid] = 0; hist[1][tid] = 0;
     thr[tid] = tid < 255 ? a.thresholds[tid] : INFINITY;
     __syncthreads();
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
     const float inv_w = 1.0f / (float)im.W;
-    const float thr_adapt = s_thr_adapt;
+    const float thr_adapt = thr_adapt_all[b * 2 + which];
     const GtStats g0 = gs[b];
     // centroid (s_measure.py:13-31): round-half-even of the fp32 quotient of exact integer sums
     const int X = (int)rintf(SM_DIV((float)g0.sum_gx, (float)g0.sum_g)), Y = (int)rintf(SM_DIV((float)g0.sum_gy, (float)g0.sum_g));
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
 
 // K4: finalise the 7 metrics of (image, which) with the reference's fp32 operation order; 256 threads: fixed-order
 // partial sums, suffix sums of the histogram and the 255 F-measures in parallel, the scalar tail on thread 0
-__global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, const QueryStats* qs, const GtStats* gs,
+__global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, const int* __restrict__ sel, const GtStats* gs,
                                                             const double* part, const MetricCounts* cnt, int nchunk) {
     __shared__ double accs[EV_NACC];
     __shared__ unsigned s_tp[257], s_np[257];
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     const unsigned tp5 = cts[0], np5 = cts[1], eq5 = cts[3], tpa = cts[4], npa = cts[5];
     const GtStats g0 = gs[b];
     const int X = (int)rintf(SM_DIV((float)g0.sum_gx, (float)g0.sum_g)), Y = (int)rintf(SM_DIV((float)g0.sum_gy, (float)g0.sum_g));
-    const int q = select_query(a, qs, b, which, false);
+    const int q = sel[b * 2 + which];
 
     float* row = a.rows + (int64_t)b * 16 + which * 7;
     const float N = (float)npx;
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     a.rows[(int64_t)b * 16 + 14 + which] = (float)q;
 }
 
-struct EvalWs { QueryStats *qs, *qpart; GtStats *gs, *gpart; MetricCounts* cnt; double* part; float* maskT; size_t total; };
+struct EvalWs { QueryStats *qs, *qpart; GtStats *gs, *gpart; MetricCounts* cnt; double* part; float* maskT; int* sel; float* thr_adapt; size_t total; };
 
 static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
     EvalWs w;
@@ -500,6 +507,8 @@ static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
     w.cnt = (MetricCounts*)take((size_t)B * 2 * nchunk * sizeof(MetricCounts));
     w.part = (double*)take((size_t)B * 2 * nchunk * EV_NACC * sizeof(double));
     w.maskT = (float*)take((size_t)B * plane * EV_QS * sizeof(float));
+    w.sel = (int*)take((size_t)B * 2 * sizeof(int));
+    w.thr_adapt = (float*)take((size_t)B * 2 * sizeof(float));
     w.total = off;
     return w;
 }
@@ -530,10 +539,11 @@ extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
     hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B), dim3(256), 0, st, *a, w.maskT);
     hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B), dim3(sm::EV_THREADS),
                        (size_t)sm::EV_LDS_ROWS * a->mw * sm::EV_QS * sizeof(float), st, *a, w.maskT, w.qpart, w.gpart, nchunk);
-    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(64), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, nchunk);
-    hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.part, nchunk);
-    hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.qs, w.gs, w.part,
-                       w.cnt, nchunk);
-    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(256), 0, st, *a, w.qs, w.gs, w.part, w.cnt, nchunk);
+    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(64), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, w.sel, nchunk);
+    hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.part, nchunk);
+    hipLaunchKernelGGL(sm::eval_adapt_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.part, w.thr_adapt, nchunk);
+    hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.thr_adapt, w.gs,
+                       w.part, w.cnt, nchunk);
+    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(256), 0, st, *a, w.sel, w.gs, w.part, w.cnt, nchunk);
     return sm::check_launch("sm_evaluate_masks_f32");
 }
