@@ -199,6 +199,7 @@ __global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, c
     const int b = blockIdx.x, t = threadIdx.x;
     if (t < a.nq) {
         QueryStats o; o.inter = 0; o.uni = 0;
+        #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) {
             const QueryStats p = qpart[((int64_t)b * nchunk + c) * a.nq + t];
             o.inter += p.inter; o.uni += p.uni;
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, c
     }
     if (t == 63) {
         GtStats o; o.sum_g = 0; o.sum_gx = 0; o.sum_gy = 0;
+        #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) {
             const GtStats p = gpart[(int64_t)b * nchunk + c];
             o.sum_g += p.sum_g; o.sum_gx += p.sum_gx; o.sum_gy += p.sum_gy;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(64) void eval_adapt_kernel(sm_eval_args a, const do
     const sm_eval_image im = a.images[b];
     double sp = 0.0;
     const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
+    #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
     for (int k = 0; k < nchunk; ++k) sp += p0[(int64_t)k * EV_NACC];
     thr_adapt[b * 2 + which] = SM_MUL(2.0f, (float)(sp / (double)(im.H * im.W)));
 }
@@ -417,10 +420,12 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     __shared__ unsigned h0[256], h1[256], cts[6];
     {
         unsigned s0 = 0, s1 = 0;
+        #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) { s0 += mcp[c].hist[0][tid]; s1 += mcp[c].hist[1][tid]; }
         h0[tid] = s0; h1[tid] = s1;
         if (tid < 6) {
             unsigned v = 0;
+            #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
             for (int c = 0; c < nchunk; ++c) v += (&mcp[c].tp5)[tid];
             cts[tid] = v;
         }
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     if (tid < EV_NACC) {
         const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC + tid;
         double sacc = 0.0;
+        #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) sacc += p0[(int64_t)c * EV_NACC];  // chunk order: deterministic
         accs[tid] = sacc;
     }
