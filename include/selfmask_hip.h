@@ -166,6 +166,12 @@ int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32
 int sm_upsample2x_tokens_f16x2(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
                                void* stream);
 
+/* Bilinear x2 (align_corners=False) of low-resolution mask logits (planes, gh, gw) -> logits (planes, 2gh, 2gw)
+ * (optional, may be NULL) and prob = sigmoid(logits).  maskformer.py:144-162,219-225 computes einsum(Q, up(tokens));
+ * both maps are linear, so the forward evaluates up(einsum(Q, tokens)) - same taps and weights, a quarter of the FLOPs. */
+int sm_upsample2x_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh, int32_t gw,
+                                     void* stream);
+
 /* objectness = sigmoid(h . w3 + b3) for each row of h (rows,384): last layer of MLP + sigmoid (maskformer.py:231-239) */
 int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows, void* stream);
 

@@ -327,9 +327,20 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
 
     // ---- heads --------------------------------------------------------------------------------------------------
     TRY(sm_query_mean_f32(QD, io->features, s.B, s.L, s.nq, st));
-    TRY(S ? sm_upsample2x_tokens_f16x2(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st)
-          : sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
-    {
+    if (s.n % 4 == 0) {
+        // mask_pred = sigmoid(up(Q . tok^T)): the einsum of maskformer.py:223 commutes with the bilinear x2 of the pixel
+        // decoder (:144-162) - both linear - so the GEMM runs on the token grid (N = n instead of 4n) and the (B, 4n,
+        // 384) up-sampled feature map is never built
+        sm_gemm_args g = {};
+        g.A = qd_a; g.W = tok_a; g.C = ws.LOG;
+        g.M = s.L * s.nq; g.N = s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = s.n;
+        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)s.n * D; g.strideC = (int64_t)s.L * s.nq * s.n;
+        g.batch = s.B; g.epilogue = SM_EPI_BIAS;
+        TRY(gemm(c, g));
+        TRY(sm_upsample2x_logits_sigmoid_f32(ws.LOG, io->mask_logits, io->mask_pred, (int64_t)s.B * s.L * s.nq, s.gh, s.gw, st));
+    } else {  // token counts that are not a multiple of 4 (float4 rows of the GEMM output): the literal order
+        TRY(S ? sm_upsample2x_tokens_f16x2(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st)
+              : sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
         // mask_pred[b] = sigmoid(Q[b] (L*nq x 384) . up[b]^T (384 x 4n))   (maskformer.py:223)
         sm_gemm_args g = {};
         g.A = qd_a; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;

@@ -126,6 +126,30 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     }
 }
 
+// ---- bilinear x2 (align_corners=False) of low-resolution mask logits + sigmoid ---------------------------------------
+// The mask einsum is linear in the up-sampled features and the up-sampling is linear in the tokens, so
+// einsum(Q, up(tok)) = up(einsum(Q, tok)): the GEMM runs on the gh x gw grid (4x fewer FLOPs, no 4n x 384 feature
+// map in HBM) and this kernel up-samples its (B, R, gh, gw) output with the same taps and weights as upsample2x_kernel.
+__global__ __launch_bounds__(256) void upsample2x_logits_kernel(const float* __restrict__ low, float* __restrict__ logits,
+                                                                float* __restrict__ prob, int gh, int gw, int64_t total) {
+    const int oh = 2 * gh, ow = 2 * gw;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(t % ow), oy = (int)((t / ow) % oh);
+        const int64_t plane = t / ((int64_t)ow * oh);  // (b, r)
+        float syf = 0.5f * (oy + 0.5f) - 0.5f, sxf = 0.5f * (ox + 0.5f) - 0.5f;
+        syf = syf < 0.f ? 0.f : syf;
+        sxf = sxf < 0.f ? 0.f : sxf;
+        const int y0 = (int)syf, x0 = (int)sxf;
+        const int y1 = y0 + (y0 < gh - 1 ? 1 : 0), x1 = x0 + (x0 < gw - 1 ? 1 : 0);
+        const float ly1 = syf - y0, ly0 = 1.f - ly1, lx1 = sxf - x0, lx0 = 1.f - lx1;
+        const float* base = low + plane * gh * gw;
+        const float p00 = base[y0 * gw + x0], p01 = base[y0 * gw + x1], p10 = base[y1 * gw + x0], p11 = base[y1 * gw + x1];
+        const float o = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+        if (logits) logits[t] = o;
+        prob[t] = 1.0f / (1.0f + expf(-o));
+    }
+}
+
 // ---- out[row] = sigmoid(h[row] . w + b): one wave per row ---------------------------------------------------------
 __global__ __launch_bounds__(256) void rowdot_sigmoid_kernel(const float* __restrict__ hbuf, const float* __restrict__ w,
                                                              const float* __restrict__ bias, float* __restrict__ out,
@@ -227,6 +251,15 @@ extern "C" int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float
 extern "C" int sm_upsample2x_tokens_f16x2(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
                                           void* stream) {
     return upsample_impl(tok, strideb, up, B, gh, gw, stream, true);
+}
+
+extern "C" int sm_upsample2x_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh,
+                                                int32_t gw, void* stream) {
+    SM_REQUIRE(low && prob && planes > 0 && gh > 0 && gw > 0, "sm_upsample2x_logits_sigmoid_f32: bad arguments");
+    const int64_t total = planes * 4 * gh * gw;
+    hipLaunchKernelGGL(sm::upsample2x_logits_kernel, dim3(sm::grid_for(total)), dim3(256), 0, (hipStream_t)stream, low, logits,
+                       prob, gh, gw, total);
+    return sm::check_launch("sm_upsample2x_logits_sigmoid_f32");
 }
 
 extern "C" int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows,

@@ -117,6 +117,7 @@ SYMBOLS = {
     "sm_cls_rows_f32": (C.c_int, [fp, fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_pos_embed_bicubic_f32": (C.c_int, [fp, C.c_int32, fp, C.c_int32, C.c_int32, fp]),
     "sm_upsample2x_tokens_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_upsample2x_logits_sigmoid_f32": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, fp]),
     "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
