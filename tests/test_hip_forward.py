@@ -156,6 +156,31 @@ def test_hip_graph_replay_gives_the_eager_bits():
     assert g.captures == 0 and g.replays == 0
 
 
+@pytest.mark.parametrize("patch,B,H,W,nq,L,seed", [
+    (16, 1, 224, 224, 100, 3, 1),   # the reference's default n_queries, fewer decoder layers, 4 query blocks in cross-attention
+    (16, 5, 97, 211, 7, 1, 2),      # ragged image (zero-padded to 112 x 224), odd batch, single decoder layer
+    (8, 3, 72, 88, 20, 6, 3),       # ViT-S/8, 99 tokens (not a multiple of 4: literal up-sample + einsum order)
+    (16, 2, 32, 32, 20, 2, 4),      # four tokens per image: every GEMM / attention tile is mostly padding
+    (8, 1, 250, 130, 33, 4, 5),     # off-grid position embedding (bicubic), 33 queries = two query blocks
+])
+def test_forward_other_shapes_and_model_sizes_vs_oracle(patch, B, H, W, nq, L, seed):
+    """Edge shapes the bench never sees, calib weights, strict 1e-4 against the CPU oracle (fp32) on this box."""
+    sd = synthetic_state_dict(seed, "calib", n_queries=nq, patch_size=patch, n_decoder_layers=L)
+    m = MaskFormer(n_queries=nq, patch_size=patch, n_decoder_layers=L, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    x = torch.from_numpy(synthetic_images(900 + seed, (B, 3, H, W)))
+    out = m(x.to(DEV), return_logits=True)
+    ref = O.forward(x, sd, patch, n_layers=L)
+    scale = ref["mask_logits"].abs().max().item()
+    d = (out["mask_logits"].cpu() - ref["mask_logits"]).abs().max().item()
+    print(f"\n P{patch} B={B} {H}x{W} nq={nq} L={L}: |logit|max={scale:.1f} hip-oracle32={d:.2e}")
+    assert out["mask_pred"].shape == ref["mask_pred"].shape
+    assert d <= _tol(scale)
+    assert (out["objectness"].cpu() - ref["objectness"]).abs().max().item() <= 2e-5
+    assert (out["features"].cpu() - ref["features"]).abs().max().item() <= 5e-5
+
+
 def test_encoder_only_and_3d_path():
     m = _model(16, 0, "soft")
     x = torch.from_numpy(synthetic_images(5, (2, 3, 224, 224))).to(DEV)
