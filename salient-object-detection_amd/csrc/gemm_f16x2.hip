@@ -36,37 +36,6 @@ __device__ __forceinline__ void wait_vmcnt_h() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// store 4 consecutive outputs (columns n..n+3, n % 4 == 0) of row m
-template <int EPI, bool OUT_F16X2>
-__device__ __forceinline__ void store4(const sm_gemm_args& g, float* C, int64_t bz, int m, int n, float (&val)[4]) {
-    if constexpr (EPI == SM_EPI_GELU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) val[i] = 0.5f * val[i] * (1.0f + fast_erff(val[i] * 0.70710678118654752440f));
-    } else if constexpr (EPI == SM_EPI_RELU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) val[i] = fmaxf(val[i], 0.f);
-    } else if constexpr (EPI == SM_EPI_RESIDUAL) {
-        const float4 r = *reinterpret_cast<const float4*>((g.R + bz * g.strideR) + (int64_t)m * g.ldr + n);
-        val[0] = r.x + val[0]; val[1] = r.y + val[1]; val[2] = r.z + val[2]; val[3] = r.w + val[3];
-    } else if constexpr (EPI == SM_EPI_SIGMOID2) {
-        float4 sg;
-        sg.x = 1.0f / (1.0f + expf(-val[0])); sg.y = 1.0f / (1.0f + expf(-val[1]));
-        sg.z = 1.0f / (1.0f + expf(-val[2])); sg.w = 1.0f / (1.0f + expf(-val[3]));
-        *reinterpret_cast<float4*>((g.C2 + bz * g.strideC) + (int64_t)m * g.ldc + n) = sg;
-    } else if constexpr (EPI == SM_EPI_PATCH) {
-        const int img = m / g.patch_n, p = m - img * g.patch_n;
-        const float4 r = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
-        val[0] += r.x; val[1] += r.y; val[2] += r.z; val[3] += r.w;
-        m = img * (g.patch_n + 1) + 1 + p;
-    }
-    if constexpr (OUT_F16X2) {
-        // row m, group n/8: hi chunk at +0, lo chunk at +16 B; this lane owns elements (n%8)..(n%8)+3 of each
-        store_f16x2_4(C + (int64_t)m * g.ldc, n, val);
-    } else {
-        *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = make_float4(val[0], val[1], val[2], val[3]);
-    }
-}
-
 // NWM x NWN waves per workgroup, each owning a (BM/NWM) x (BN/NWN) block of the tile as TM x TN 32x32 accumulators.
 // The kernel is fed from L2 at a roughly fixed rate per CU (~50 GB/s measured), so what a tile shape buys is MACs per
 // byte staged: BM*BN/(BM+BN) - 43 for 128x64, 85 for 256x128.
@@ -201,17 +170,31 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
 
     float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : bz) * g.strideC;
     const bool out_split = g.patch_n < 0;  // out-format flag travels in the sign of patch_n for non-PATCH epilogues
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------------
+    // In the accumulator layout a lane owns one output ROW: stored from there, a wave-wide store touches 32 rows with
+    // 16-B pieces (32 partial cache lines per instruction), and with three batches in flight those partial writes cost
+    // as much as the whole K loop (removing the epilogue: +40 % images/s).  So each wave turns its 32 x WTN blocks
+    // through a private piece of the (now idle) LDS ring: values - bias, GELU / ReLU applied, already in their final
+    // fp32 or F16X2 byte layout - are written row-major, read back with consecutive lanes on consecutive 16-B pieces,
+    // and leave as contiguous row segments (WTN * 4 B = 256 B for the 128x128 tile); the residual / position-embedding
+    // rows are read the same way.  Same arithmetic, same order: bit-identical results.
+    constexpr int EPLD = WTN * 4 + 16;            // bytes per staged row (+16: conflict-free b128 column writes)
+    constexpr int PIECES = WTN / 4;               // 16-B pieces per row
+    static_assert(NW * 32 * EPLD <= NST * STAGE, "epilogue staging must fit in the ring");
+    __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring
+    char* ep = smemh + wave * (32 * EPLD);
+
     auto run = [&](auto epi_tag, auto fmt_tag) {
         constexpr int EPI = decltype(epi_tag)::value;
         constexpr bool F = decltype(fmt_tag)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WTM + i * 32 + r;
-            if (m >= M) continue;
+            // phase A: accumulator layout -> staged rows
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if constexpr (F) {
-                    // F16X2 output: lanes l / l^32 trade halves so each writes one whole 32-B group (N % 8 == 0)
+                    // F16X2 output: lanes l / l^32 trade halves so each owns one whole 32-B group (N % 8 == 0)
 #pragma unroll
                     for (int q = 0; q < 4; q += 2) {
                         float x[4], y[4];
@@ -229,24 +212,53 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
                             }
                         }
                         pair_groups(x, y);
-                        const int n = n0 + wn * WTN + j * 32 + 8 * (q + h);
-                        if (n < N) store_f16x2_8(C + (int64_t)m * g.ldc, n, x, y);
+                        store_f16x2_8(ep + r * EPLD, j * 32 + 8 * (q + h), x, y);
                     }
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + wn * WTN + j * 32 + 8 * q + 4 * h;
-                        if (n >= N) continue;
-                        float val[4];
+                        const int nl = j * 32 + 8 * q + 4 * h, n = n0 + wn * WTN + nl;
+                        float4 val;
+                        float* vp = &val.x;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float b = g.bias ? g.bias[n + e] : 0.f;
-                            val[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + b;
+                            const float b = (g.bias && n < N) ? g.bias[n + e] : 0.f;
+                            float t = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + b;
+                            if constexpr (EPI == SM_EPI_GELU) t = 0.5f * t * (1.0f + fast_erff(t * 0.70710678118654752440f));
+                            else if constexpr (EPI == SM_EPI_RELU) t = fmaxf(t, 0.f);
+                            vp[e] = t;
                         }
-                        store4<EPI, false>(g, C, bz, m, n, val);
+                        *reinterpret_cast<float4*>(ep + r * EPLD + nl * 4) = val;
                     }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes have landed (LDS is in-order)
+            // phase B: staged rows -> global, lane = (row, 16-B piece)
+#pragma unroll
+            for (int it = 0; it < 32 * PIECES / 64; ++it) {
+                const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
+                int m = m0 + wm * WTM + i * 32 + row;
+                const int n = n0 + wn * WTN + pc * 4;
+                if (m < M && n < N) {
+                    float4 v = *reinterpret_cast<const float4*>(ep + row * EPLD + pc * 16);
+                    if constexpr (EPI == SM_EPI_RESIDUAL) {
+                        const float4 rr = *reinterpret_cast<const float4*>((g.R + bz * g.strideR) + (int64_t)m * g.ldr + n);
+                        v.x = rr.x + v.x; v.y = rr.y + v.y; v.z = rr.z + v.z; v.w = rr.w + v.w;
+                    } else if constexpr (EPI == SM_EPI_SIGMOID2) {
+                        float4 sg;
+                        sg.x = 1.0f / (1.0f + expf(-v.x)); sg.y = 1.0f / (1.0f + expf(-v.y));
+                        sg.z = 1.0f / (1.0f + expf(-v.z)); sg.w = 1.0f / (1.0f + expf(-v.w));
+                        *reinterpret_cast<float4*>((g.C2 + bz * g.strideC) + (int64_t)m * g.ldc + n) = sg;
+                    } else if constexpr (EPI == SM_EPI_PATCH) {
+                        const int img = m / g.patch_n, p = m - img * g.patch_n;
+                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                        m = img * (g.patch_n + 1) + 1 + p;
+                    }
+                    *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next block overwrites the rows
         }
     };
     using T = std::true_type;
@@ -337,7 +349,6 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
     if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
     if (bm == 128 && bn == 128 && nst == 8) return sm::launch_gemm_h<128, 128, 2, 2, 4, 2>(a, st);  // 8 waves of 64x32
-    if (bm == 128 && bn == 128 && nst == 9) return sm::launch_gemm_h<128, 128, 2, 4, 2, 2>(a, st);  // 8 waves of 32x64
     if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2>(a, st);
     if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2, 2, 2, 3>(a, st);
     if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 2 ? sm::launch_gemm_h<64, 64, 2, 2, 2, 5>(a, st) : sm::launch_gemm_h<64, 64, 3, 2, 2, 3>(a, st);
