@@ -39,14 +39,23 @@ __device__ __forceinline__ void wait_vmcnt_h() {
 // NWM x NWN waves per workgroup, each owning a (BM/NWM) x (BN/NWN) block of the tile as TM x TN 32x32 accumulators.
 // The kernel is fed from L2 at a roughly fixed rate per CU (~50 GB/s measured), so what a tile shape buys is MACs per
 // byte staged: BM*BN/(BM+BN) - 43 for 128x64, 85 for 256x128.
-template <int BM, int BN, int NST, int NWM, int NWN, int MINB>
+// Rings: W tiles NST deep, A tiles NST + AX deep (AX = 0 or 1).  Weights are re-read by every workgroup and come from
+// L2; activation panels come from HBM / the Infinity Cache with several times the latency, so the LDS that two
+// workgroups per CU leave free (2 x 80 of 160 KiB with the 128x128 tile) can buy the A stream one more K-tile of
+// run-ahead.  Measured with three batches in flight: 1 % SLOWER than AX = 0 (a CU whose LDS is full takes no workgroup
+// of another stream's kernel), so the shipped shapes use AX = 0; SM_F16X2_NST=7 selects the AX = 1 variant.
+template <int BM, int BN, int NST, int NWM, int NWN, int MINB, int AX>
 __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gemm_args g) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_INST = BM / 8 / NW, W_INST = BN / 8 / NW;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) per wave and stage
     static_assert(A_INST * 8 * NW == BM && W_INST * 8 * NW == BN && TM * 32 * NWM == BM && TN * 32 * NWN == BN, "tile split");
     constexpr int NI = A_INST + W_INST;
-    constexpr int STAGE = (BM + BN) * 128;  // bytes per stage (128 B per row per 32-k tile)
+    constexpr int NSTA = NST + AX;
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128;  // bytes per ring slot (128 B per row per 32-k tile)
+    constexpr int W_RING = NSTA * A_STAGE;                 // the W ring follows the A ring
+    constexpr int RING_BYTES = NSTA * A_STAGE + NST * W_STAGE;
+    static_assert(AX == 0 || AX == 1, "A runs at most one tile further ahead than W");
     extern __shared__ __attribute__((aligned(16))) char smemh[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,13 +100,22 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
         w_src[i] = W + ((int64_t)gn * g.ldw) * 4 + c * 16;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smemh;
-    auto issue = [&](int kt, int stage) {
-        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + wave * A_INST * 1024);
-        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + stage * STAGE + BM * 128 + wave * W_INST * 1024);
+    auto issue_a = [&](int kt, int slot) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + wave * A_INST * 1024);
 #pragma unroll
         for (int i = 0; i < A_INST; ++i) dma16h(a_src[i] + kt * 128, sa + i * 1024);
+    };
+    auto issue_w = [&](int kt, int slot) {
+        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + wave * W_INST * 1024);
 #pragma unroll
         for (int i = 0; i < W_INST; ++i) dma16h(w_src[i] + kt * 128, sw + i * 1024);
+    };
+    // one pipeline step: the W tile NST-1 ahead, then the A tile NSTA-1 ahead (this order is what the counted wait below
+    // relies on); tiles past the end re-fetch the last one so that every step issues the same number of pieces
+    auto issue_step = [&](int kt) {
+        const int tw = kt + NST - 1, ta = kt + NSTA - 1;
+        if (tw >= 0) issue_w(tw < nk ? tw : nk - 1, tw % NST);
+        if (ta >= 0) issue_a(ta < nk ? ta : nk - 1, ta % NSTA);
     };
 
     // fragment byte offsets inside a 128-B row: k16-step s, lane half h -> k-group 2s+h -> chunks 2(2s+h) [hi], +1 [lo]
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
         off_lo[s] = ((2 * (2 * s + h) + 1) ^ swz) * 16;
     }
     const int a_row = (wm * WTM + r) * 128;
-    const int w_row = BM * 128 + (wn * WTN + r) * 128;
+    const int w_row = (wn * WTN + r) * 128;
 
     f32x16 acc[TM][TN], crs[TM][TN];
 #pragma unroll
@@ -120,21 +138,21 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
             for (int v = 0; v < 16; ++v) { acc[i][j][v] = 0.f; crs[i][j][v] = 0.f; }
 
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t) issue(t < nk ? t : nk - 1, t);
+    for (int v = -(NSTA - 1); v < 0; ++v) issue_step(v);  // prologue = the virtual steps before kt = 0
 
     const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only runs: 2 = no MFMA, 3 = no DMA in the loop, 4 = no epilogue, 5 = 3 + 4, 6 = 5 without the barrier
     for (int kt = 0; kt < nk; ++kt) {
         if (ablate != 6) {
-            wait_vmcnt_h<(NST - 2) * NI>();
+            // tiles kt of both rings have landed; what may still fly was issued after the later of the two: AX = 0 the
+            // NST-2 steps since; AX = 1 the A tile issued right behind W(kt) plus those steps
+            wait_vmcnt_h<(NST - 2) * NI + AX * A_INST>();
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ablate != 3 && ablate < 5) {
-            const int nt = kt + NST - 1;
-            issue(nt < nk ? nt : nk - 1, nt % NST);
-        }
+        if (ablate != 3 && ablate < 5) issue_step(kt);
         if (ablate == 2) continue;
-        const char* st = smemh + (kt % NST) * STAGE;
+        const char* sta = smemh + (kt % NSTA) * A_STAGE;
+        const char* stw = smemh + W_RING + (kt % NST) * W_STAGE;
         // all fragment reads of the stage are issued up front: the second 16-k step's reads land under the first
         // step's MFMAs (LDS returns in order, so the compiler waits with a counted lgkmcnt for the first half only)
         f16x8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
@@ -142,13 +160,13 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ah[s][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_hi[s]);
-                al[s][i] = *reinterpret_cast<const f16x8*>(st + a_row + i * 32 * 128 + off_lo[s]);
+                ah[s][i] = *reinterpret_cast<const f16x8*>(sta + a_row + i * 32 * 128 + off_hi[s]);
+                al[s][i] = *reinterpret_cast<const f16x8*>(sta + a_row + i * 32 * 128 + off_lo[s]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                wh[s][j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_hi[s]);
-                wl[s][j] = *reinterpret_cast<const f16x8*>(st + w_row + j * 32 * 128 + off_lo[s]);
+                wh[s][j] = *reinterpret_cast<const f16x8*>(stw + w_row + j * 32 * 128 + off_hi[s]);
+                wl[s][j] = *reinterpret_cast<const f16x8*>(stw + w_row + j * 32 * 128 + off_lo[s]);
             }
         }
 #pragma unroll
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
     // rows are read the same way.  Same arithmetic, same order: bit-identical results.
     constexpr int EPLD = WTN * 4 + 16;            // bytes per staged row (+16: conflict-free b128 column writes)
     constexpr int PIECES = WTN / 4;               // 16-B pieces per row
-    static_assert(NW * 32 * EPLD <= NST * STAGE, "epilogue staging must fit in the ring");
+    static_assert(NW * 32 * EPLD <= RING_BYTES, "epilogue staging must fit in the ring");
     __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring
     char* ep = smemh + wave * (32 * EPLD);
 
@@ -288,18 +306,18 @@ __global__ __launch_bounds__(256) void split_f16x2_kernel(const float* __restric
     }
 }
 
-template <int BM, int BN, int NST, int NWM = 2, int NWN = 2, int MINB = 1>
+template <int BM, int BN, int NST, int NWM = 2, int NWN = 2, int MINB = 1, int AX = 0>
 static int launch_gemm_h(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : g.batch);
-    constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
+    constexpr size_t lds = (size_t)((NST + AX) * BM + NST * BN) * 128;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB, AX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB>), grid, dim3(NWM * NWN * 64), lds, st, g);
+    hipLaunchKernelGGL((gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB, AX>), grid, dim3(NWM * NWN * 64), lds, st, g);
     return check_launch("sm_gemm_f16x2");
 }
 
@@ -348,8 +366,9 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     const int nst = env ? atoi(env) : 0;
     if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
     if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
+    if (bm == 128 && bn == 128 && nst == 7) return sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);  // A ring 3 deep (80 KiB): -1 % end to end
     if (bm == 128 && bn == 128 && nst == 8) return sm::launch_gemm_h<128, 128, 2, 2, 4, 2>(a, st);  // 8 waves of 64x32
-    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2>(a, st);
+    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);
     if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2, 2, 2, 3>(a, st);
     if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 2 ? sm::launch_gemm_h<64, 64, 2, 2, 2, 5>(a, st) : sm::launch_gemm_h<64, 64, 3, 2, 2, 3>(a, st);
     sm::set_error("sm_gemm_f16x2_tile: unsupported tile %dx%d", bm, bn);
