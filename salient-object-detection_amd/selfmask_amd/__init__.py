@@ -10,7 +10,13 @@ from .streams import StreamRing  # noqa: F401
 from .graphs import GraphedForward  # noqa: F401
 from .bilateral_solver import (bilateral_solver_output, bilateral_solver_output_device,  # noqa: F401
                                bilateral_solver_batch_device)
-from .evaluator import Evaluator  # noqa: F401
 from .state_layout import state_shapes, synthetic_state_dict, synthetic_images  # noqa: F401
 
 __version__ = "0.1.0"
+
+
+def __getattr__(name):  # lazy: `python -m selfmask_amd.evaluator` must not find the module pre-imported
+    if name == "Evaluator":
+        from .evaluator import Evaluator
+        return Evaluator
+    raise AttributeError(name)
