@@ -47,6 +47,9 @@ const char* sm_last_error(void);
 #define SM_EPI_RESIDUAL 3  /* C = R + (A W^T + bias)                             vision_transformer.py:168-169   */
 #define SM_EPI_SIGMOID2 4  /* C = A W^T (+bias); C2 = sigmoid(C)                 maskformer.py:223               */
 #define SM_EPI_PATCH 5     /* patch-embed: row m -> token (m/n)*(n+1)+1+m%n, + pos_embed[1+m%n]   v_t.py:184-188,280 */
+#define SM_EPI_RESIDUAL_LN 6 /* C = R + (A W^T + bias); C2 = LayerNorm(C) * ln_gamma + ln_beta in F16X2: the residual add and
+                               the NEXT block's pre-norm in one launch (vision_transformer.py:168-169 followed by :165 /
+                               :169).  sm_gemm_f16x2 only, N == 384, the 64 x 384 full-row tile                       */
 
 typedef struct sm_gemm_args {
     const float* A;      /* [batch][M][lda]   activations, K contiguous                                         */
@@ -68,6 +71,9 @@ typedef struct sm_gemm_args {
                             C + s*strideC (batch must be 1, epilogue SM_EPI_BIAS with bias == NULL, K/32 % S == 0);
                             the consumer sums the slices in a fixed order (sm_layernorm_rows_f32 partials)          */
     int32_t patch_n;     /* SM_EPI_PATCH: patches per image n                                                    */
+    const float* ln_gamma; /* SM_EPI_RESIDUAL_LN: weight / bias (384) and eps of the fused LayerNorm; its F16X2 output */
+    const float* ln_beta;  /* goes to C2 (row stride ldc)                                                              */
+    float ln_eps;
 } sm_gemm_args;
 
 /* C = epilogue(A W^T): replaces every F.linear / conv-as-GEMM / bmm on the path

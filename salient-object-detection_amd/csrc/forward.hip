@@ -8,6 +8,7 @@
 //      produced directly in the F16X2 format by its producer (LayerNorm, attention, GELU/ReLU epilogues, im2col,
 //      up-sample); tensors that are also residuals / outputs exist in fp32 as well.  "(S)" marks them below.
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -132,6 +133,17 @@ static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s) {
     TapScope tap(c.st, gemm_name(c, g), 2.0 * g.M * g.N * g.K * (g.batch > 0 ? g.batch : 1), 0.0);
     return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
 }
+// split mode, N = 384: C = R + (A W^T + b) in place on the residual stream AND the next pre-norm of it (F16X2) in one
+// launch on the 64 x 384 full-row tile (SM_EPI_RESIDUAL_LN)
+static int linear_residual_ln(const Ctx& c, const float* A, int lda, const float* W, const float* b, float* X, int64_t M, int K,
+                              const float* ln_w, const float* ln_b, float eps, float* Xn) {
+    sm_gemm_args g = {};
+    g.A = A; g.W = W; g.bias = b; g.C = X; g.R = X; g.C2 = Xn;
+    g.M = (int)M; g.N = SM_EMBED; g.K = K; g.lda = lda; g.ldw = K; g.ldc = SM_EMBED; g.ldr = SM_EMBED;
+    g.batch = 1; g.epilogue = SM_EPI_RESIDUAL_LN; g.ln_gamma = ln_w; g.ln_beta = ln_b; g.ln_eps = eps;
+    TapScope tap(c.st, "gemm_f16x2_kernel<64, 384, 2, 2, 4, 1, 0>", 2.0 * g.M * g.N * g.K, 0.0);
+    return sm_gemm_f16x2_tile(&g, 0, 64, 384, c.st);
+}
 // in split mode Q, K and V are F16X2 (written so by the projection GEMMs) and the f16 matrix cores do the work
 static int attn(const Ctx& c, sm_attn_args& a) {
     TapScope tap(c.st, c.S ? "attention_f16x2_kernel<4>" : "attention_f32_kernel", 4.0 * a.batch * a.heads * a.n_q * (double)a.n_k * SM_HEAD_DIM,
@@ -219,11 +231,18 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     }
 
     // ---- 12 pre-norm blocks (vision_transformer.py:164-170) -----------------------------------------------------
+    // Optional (split mode): the two pre-norms of a block ride on the GEMM that produces their input (proj -> norm2,
+    // fc2 -> the next block's norm1); only the first norm1 is then a launch of its own.
+    // SM_FUSED_LN (tuning knob, default 0): 1 = proj and fc2, 2 = proj only.  Measured with three batches in flight:
+    // 17.3k images/s against 18.0k unfused - the full-row tile needs 112 KiB of LDS (one workgroup per CU, 197 of them).
+    static const int fused_ln_env = getenv("SM_FUSED_LN") ? atoi(getenv("SM_FUSED_LN")) : 0;
+    const bool fuse_proj = S && fused_ln_env >= 1, fuse_fc2 = S && fused_ln_env == 1;
+    LnOpt xs;
+    xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
+    if (fuse_fc2) TRY(ln(c, ws.X, w->enc[0].norm1_w, w->enc[0].norm1_b, nullptr, s.M, 1e-6f, xs));
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
-        LnOpt xs;
-        xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
-        TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        if (!fuse_fc2) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
         sm_attn_args a = {};
         a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
@@ -231,10 +250,19 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         a.sOb = (int64_t)s.N * D; a.sOr = D;
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
         TRY(attn(c, a));
-        TRY(linear(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
-        TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        if (fuse_proj) {
+            TRY(linear_residual_ln(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, s.M, D, e.norm2_w, e.norm2_b, 1e-6f, ws.Xn));
+        } else {
+            TRY(linear(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
+            TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        }
         TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
-        TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D));
+        if (fuse_fc2 && i + 1 < SM_ENC_DEPTH) {
+            const sm_enc_layer& nx = w->enc[i + 1];
+            TRY(linear_residual_ln(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, s.M, SM_MLP, nx.norm1_w, nx.norm1_b, 1e-6f, ws.Xn));
+        } else {
+            TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D));
+        }
     }
     // final norm on the last layer only (the other 11 per-layer norms of :299 are dead work when
     // lateral_connection=False), dropping the cls row on the way (maskformer.py:107-108,177)

@@ -203,6 +203,99 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
     __builtin_amdgcn_s_barrier();                 // every wave is done reading the ring
     char* ep = smemh + wave * (32 * EPLD);
 
+    if constexpr (BN == SM_EMBED) {
+        // ---- residual + LayerNorm epilogue (SM_EPI_RESIDUAL_LN): the tile spans whole rows (N = BN = 384), so the
+        // pre-norm of the NEXT block runs here instead of in its own launch.  All waves stage their fp32 blocks
+        // (A W^T + bias) row-major in the idle ring, then every 16 lanes take one row exactly as layernorm384_kernel
+        // does (three 8-element groups per lane, two-pass variance, 4-step butterflies): x = R + value goes to C
+        // (fp32 residual stream), LayerNorm(x) to C2 in F16X2 - bit-identical to the unfused pair of launches.
+        if (g.epilogue == SM_EPI_RESIDUAL_LN) {
+            constexpr int LNLD = BN * 4 + 16;
+            static_assert(BM * LNLD <= RING_BYTES, "row staging must fit in the ring");
+            static_assert(TM == 1, "one 32-row block per wave");
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int nl = wn * WTN + j * 32 + 8 * q + 4 * h;
+                    float4 val;
+                    float* vp = &val.x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        vp[e] = (acc[0][j][4 * q + e] + crs[0][j][4 * q + e] * (1.0f / 2048.0f)) + (g.bias ? g.bias[nl + e] : 0.f);
+                    *reinterpret_cast<float4*>(smemh + (wm * WTM + r) * LNLD + nl * 4) = val;
+                }
+            __syncthreads();
+            const int l16 = lane & 15;
+#pragma unroll 1
+            for (int it = 0; it < BM / (NW * 4); ++it) {
+                const int row = (it * NW + wave) * 4 + (lane >> 4);
+                const int m = m0 + row;
+                const bool live = m < M;
+                const int mm = live ? m : M - 1;  // dead groups shadow the last row (they join the shuffles, never store)
+                const char* sr = smemh + row * LNLD;
+                const float* rr = (g.R + bz * g.strideR) + (int64_t)mm * g.ldr;
+                float v[3][8];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int k = (l16 + 16 * i) * 8;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const float4 p = *reinterpret_cast<const float4*>(sr + (k + 4 * hh) * 4);
+                        const float4 t = *reinterpret_cast<const float4*>(rr + k + 4 * hh);
+                        v[i][4 * hh + 0] = t.x + p.x; v[i][4 * hh + 1] = t.y + p.y;
+                        v[i][4 * hh + 2] = t.z + p.z; v[i][4 * hh + 3] = t.w + p.w;
+                    }
+                }
+                float* cr = C + (int64_t)mm * g.ldc;
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int k = (l16 + 16 * i) * 8;
+                        *reinterpret_cast<float4*>(cr + k) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                        *reinterpret_cast<float4*>(cr + k + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+                    }
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) sum += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+                const float mean = sum * (1.0f / 384.0f);
+                float qv = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v[i][e] -= mean;
+                        qv += v[i][e] * v[i][e];
+                    }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) qv += __shfl_xor(qv, o, 16);
+                const float rstd = 1.0f / sqrtf(qv * (1.0f / 384.0f) + g.ln_eps);
+                if (live) {
+                    float* yr = (g.C2 + bz * g.strideC) + (int64_t)m * g.ldc;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const int k = (l16 + 16 * i) * 8;
+                        float o[8];
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const float4 gm = *reinterpret_cast<const float4*>(g.ln_gamma + k + 4 * hh);
+                            const float4 bt = *reinterpret_cast<const float4*>(g.ln_beta + k + 4 * hh);
+                            o[4 * hh + 0] = v[i][4 * hh + 0] * rstd * gm.x + bt.x; o[4 * hh + 1] = v[i][4 * hh + 1] * rstd * gm.y + bt.y;
+                            o[4 * hh + 2] = v[i][4 * hh + 2] * rstd * gm.z + bt.z; o[4 * hh + 3] = v[i][4 * hh + 3] * rstd * gm.w + bt.w;
+                        }
+                        const float (&o0)[4] = *reinterpret_cast<const float (*)[4]>(&o[0]);
+                        const float (&o1)[4] = *reinterpret_cast<const float (*)[4]>(&o[4]);
+                        store_f16x2_8(yr, k, o0, o1);
+                    }
+                }
+            }
+            return;
+        }
+    }
+
     auto run = [&](auto epi_tag, auto fmt_tag) {
         constexpr int EPI = decltype(epi_tag)::value;
         constexpr bool F = decltype(fmt_tag)::value;
@@ -342,7 +435,11 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     SM_REQUIRE(g->N % 4 == 0 && g->ldc % 4 == 0 && ((uintptr_t)g->C % 16 == 0), "sm_gemm_f16x2: N, ldc must be multiples of 4");
     SM_REQUIRE(g->lda % 8 == 0 && g->ldw % 8 == 0 && ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->W % 16 == 0),
                "sm_gemm_f16x2: lda/ldw must be multiples of 8, pointers 16-B aligned");
-    SM_REQUIRE(g->epilogue >= 0 && g->epilogue <= SM_EPI_PATCH, "sm_gemm_f16x2: bad epilogue");
+    SM_REQUIRE(g->epilogue >= 0 && g->epilogue <= SM_EPI_RESIDUAL_LN, "sm_gemm_f16x2: bad epilogue");
+    if (g->epilogue == SM_EPI_RESIDUAL_LN)
+        SM_REQUIRE(bm == 64 && bn == 384 && g->N == SM_EMBED && g->R && g->C2 && g->ln_gamma && g->ln_beta && !out_f16x2 &&
+                       g->ldr % 4 == 0 && g->ldc % 8 == 0 && !(g->split_k > 1),
+                   "sm_gemm_f16x2: RESIDUAL_LN needs the 64x384 tile, N == 384, R, C2, ln_gamma, ln_beta");
     if (out_f16x2)
         SM_REQUIRE(g->N % 8 == 0 && g->ldc % 8 == 0 && (g->epilogue == SM_EPI_BIAS || g->epilogue == SM_EPI_GELU ||
                                                       g->epilogue == SM_EPI_RELU) && !(g->split_k > 1),
@@ -364,6 +461,7 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     // (left alone hipcc spends 109 VGPR + 64 AGPR on the 128x64 tile = two per CU, and the kernel is 25 % slower).
     const char* env = getenv("SM_F16X2_NST");  // tuning knob
     const int nst = env ? atoi(env) : 0;
+    if (bm == 64 && bn == 384) return sm::launch_gemm_h<64, 384, 2, 2, 4, 1, 0>(a, st);  // full-row tile (LayerNorm epilogue)
     if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
     if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
     if (bm == 128 && bn == 128 && nst == 7) return sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);  // A ring 3 deep (80 KiB): -1 % end to end

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libselfmask_hip.so"))
 
 EMBED, HEADS, HEAD_DIM, MLP, ENC_DEPTH, MAX_DEC_LAYERS = 384, 6, 64, 1536, 12, 8
-EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID2, EPI_PATCH = range(6)
+EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID2, EPI_PATCH, EPI_RESIDUAL_LN = range(7)
 
 fp = C.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -20,7 +20,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("batch", C.c_int32), ("epilogue", C.c_int32), ("alt_from_n", C.c_int32), ("split_k", C.c_int32),
-                ("patch_n", C.c_int32)]
+                ("patch_n", C.c_int32), ("ln_gamma", fp), ("ln_beta", fp), ("ln_eps", C.c_float)]
 
 
 class RowMap(C.Structure):

@@ -81,8 +81,15 @@ def split_f16x2(x: torch.Tensor) -> torch.Tensor:
     return out.view(x.shape)
 
 
+def unsplit_f16x2(t: torch.Tensor) -> torch.Tensor:
+    """F16X2 (..., K) -> the fp32 values it stands for (hi + lo / 2048); inverse of split_f16x2 up to the format's 22 bits."""
+    k = t.shape[-1]
+    h = t.contiguous().view(torch.float16).reshape(*t.shape[:-1], k // 8, 2, 8).float()
+    return (h[..., 0, :] + h[..., 1, :] / 2048.0).reshape(t.shape)
+
+
 def gemm_f16x2(a_split: torch.Tensor, w_split: torch.Tensor, bias=None, epilogue: int = N.EPI_BIAS, residual=None,
-               tile=(128, 128), out=None, out_f16x2: bool = False, split_k: int = 1):
+               tile=(128, 128), out=None, out_f16x2: bool = False, split_k: int = 1, ln=None):
     """C = epilogue(A W^T + bias) with A, W in F16X2 format (see split_f16x2).  2-D operands, or 3-D (batch, rows, K)
     for a batched launch (no split_k then).  Test / tuning entry: the forward drives the kernel from C."""
     _dev(a_split, w_split, bias, residual)
@@ -103,8 +110,14 @@ def gemm_f16x2(a_split: torch.Tensor, w_split: torch.Tensor, bias=None, epilogue
     if residual is not None:
         r3 = residual if residual.dim() == 3 else residual.unsqueeze(0)
         g.R, g.ldr, g.strideR = r3.data_ptr(), r3.stride(1), r3.stride(0)
+    xn = None
+    if ln is not None:  # (gamma, beta, eps): C = R + A W^T + bias and C2 = LayerNorm(C) in F16X2 (64x384 tile, N = 384)
+        gamma, beta, eps = ln
+        xn = torch.empty_like(c3)
+        g.epilogue, g.C2, g.ln_gamma, g.ln_beta, g.ln_eps = N.EPI_RESIDUAL_LN, xn.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps
     N.check(N.load().sm_gemm_f16x2_tile(g, 1 if out_f16x2 else 0, tile[0], tile[1], _stream()), "sm_gemm_f16x2_tile")
-    return c if (out is not None or split_k > 1 or batched) else c[0]
+    res = c if (out is not None or split_k > 1 or batched) else c[0]
+    return (res, xn if batched else xn[0]) if ln is not None else res
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
