@@ -18,6 +18,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace sm {
 
@@ -43,7 +44,7 @@ __device__ __forceinline__ void wait_vmcnt_h() {
 // L2; activation panels come from HBM / the Infinity Cache with several times the latency, so the LDS that two
 // workgroups per CU leave free (2 x 80 of 160 KiB with the 128x128 tile) can buy the A stream one more K-tile of
 // run-ahead.  Measured with three batches in flight: 1 % SLOWER than AX = 0 (a CU whose LDS is full takes no workgroup
-// of another stream's kernel), so the shipped shapes use AX = 0; SM_F16X2_NST=7 selects the AX = 1 variant.
+// of another stream's kernel), so the shipped shapes use AX = 0; SM_F16X2_VARIANT=a3 selects the AX = 1 variant.
 template <int BM, int BN, int NST, int NWM, int NWN, int MINB, int AX>
 __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gemm_args g) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
@@ -459,13 +460,17 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     // epilogue of one workgroup only overlap with those of OTHER workgroups on the CU, so the default shapes are the
     // ones that fit three workgroups per CU - 48 KiB of LDS and, via __launch_bounds__(256, 3), <= 168 registers
     // (left alone hipcc spends 109 VGPR + 64 AGPR on the 128x64 tile = two per CU, and the kernel is 25 % slower).
-    const char* env = getenv("SM_F16X2_NST");  // tuning knob
+    // tuning knobs: SM_F16X2_NST = ring depth (2..5 where instantiated), SM_F16X2_VARIANT = "a3" (128x128 with the A ring
+    // one tile deeper) or "w8" (128x128 as 8 waves of 64x32)
+    const char* env = getenv("SM_F16X2_NST");
     const int nst = env ? atoi(env) : 0;
+    const char* var = getenv("SM_F16X2_VARIANT");
+    const bool var_a3 = var && !strcmp(var, "a3"), var_w8 = var && !strcmp(var, "w8");
     if (bm == 64 && bn == 384) return sm::launch_gemm_h<64, 384, 2, 2, 4, 1, 0>(a, st);  // full-row tile (LayerNorm epilogue)
     if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
     if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
-    if (bm == 128 && bn == 128 && nst == 7) return sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);  // A ring 3 deep (80 KiB): -1 % end to end
-    if (bm == 128 && bn == 128 && nst == 8) return sm::launch_gemm_h<128, 128, 2, 2, 4, 2>(a, st);  // 8 waves of 64x32
+    if (bm == 128 && bn == 128 && var_a3) return sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 1>(a, st);  // 80 KiB: -1 % end to end
+    if (bm == 128 && bn == 128 && var_w8) return sm::launch_gemm_h<128, 128, 2, 2, 4, 2>(a, st);     // neutral end to end
     if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);
     if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2, 2, 2, 3>(a, st);
     if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 2 ? sm::launch_gemm_h<64, 64, 2, 2, 2, 5>(a, st) : sm::launch_gemm_h<64, 64, 3, 2, 2, 3>(a, st);
