@@ -122,7 +122,7 @@ static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
     int bm = 0, bn = 0, nst = 0;
     if (c.S) {
         sm_gemm_f16x2_pick_tile(&g, &bm, &bn, &nst);
-        snprintf(buf, sizeof buf, "gemm_f16x2_kernel<%d, %d, %d, 2, 2, %d, %d>", bm, bn, nst, bn == 128 ? 2 : 3, 0);
+        snprintf(buf, sizeof buf, "gemm_f16x2_kernel<%d, %d, %d, 2, %d, %d, 0>", bm, bn, nst, bn == 128 ? 4 : 2, bn == 128 ? 2 : 3);
     } else {
         sm_gemm_f32_pick_tile(&g, &bm, &bn);
         snprintf(buf, sizeof buf, "gemm_f32_kernel<%d, %d, %d>", bm, bn, bm == 128 ? (bn == 128 ? 2 : 3) : 4);

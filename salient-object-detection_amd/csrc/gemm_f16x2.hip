@@ -459,18 +459,19 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     // epilogue of one workgroup only overlap with those of OTHER workgroups on the CU, so the default shapes are the
     // ones that fit three workgroups per CU - 48 KiB of LDS and, via __launch_bounds__(256, 3), <= 168 registers
     // (left alone hipcc spends 109 VGPR + 64 AGPR on the 128x64 tile = two per CU, and the kernel is 25 % slower).
-    // tuning knobs: SM_F16X2_NST = ring depth (2..5 where instantiated), SM_F16X2_VARIANT = "a3" (128x128 with the A ring
-    // one tile deeper) or "w8" (128x128 as 8 waves of 64x32)
+    // tuning knobs: SM_F16X2_NST = ring depth (2..5 where instantiated), SM_F16X2_VARIANT = "a3" (128x128, four waves,
+    // the A ring one tile deeper), "w4" (128x128 as four waves of 64x64), "w16" (256x128 as sixteen waves of 64x32)
     const char* env = getenv("SM_F16X2_NST");
     const int nst = env ? atoi(env) : 0;
     const char* var = getenv("SM_F16X2_VARIANT");
-    const bool var_a3 = var && !strcmp(var, "a3"), var_w8 = var && !strcmp(var, "w8");
+    const bool var_a3 = var && !strcmp(var, "a3"), var_w4 = var && !strcmp(var, "w4");
     if (bm == 64 && bn == 384) return sm::launch_gemm_h<64, 384, 2, 2, 4, 1, 0>(a, st);  // full-row tile (LayerNorm epilogue)
+    if (bm == 256 && bn == 128 && var && !strcmp(var, "w16")) return sm::launch_gemm_h<256, 128, 2, 4, 4, 1, 0>(a, st);  // 16 waves of 64x32
     if (bm == 256 && bn == 128) return nst == 2 ? sm::launch_gemm_h<256, 128, 2, 4, 2>(a, st) : sm::launch_gemm_h<256, 128, 3, 4, 2>(a, st);
     if (bm == 256 && bn == 64) return nst == 3 ? sm::launch_gemm_h<256, 64, 3, 4, 1>(a, st) : sm::launch_gemm_h<256, 64, 2, 4, 1>(a, st);
     if (bm == 128 && bn == 128 && var_a3) return sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 1>(a, st);  // 80 KiB: -1 % end to end
-    if (bm == 128 && bn == 128 && var_w8) return sm::launch_gemm_h<128, 128, 2, 2, 4, 2>(a, st);     // neutral end to end
-    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);
+    if (bm == 128 && bn == 128 && var_w4) return sm::launch_gemm_h<128, 128, 2, 2, 2, 2, 0>(a, st);  // -2.7 % end to end
+    if (bm == 128 && bn == 128) return nst == 3 ? sm::launch_gemm_h<128, 128, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 128, 4>(a, st) : sm::launch_gemm_h<128, 128, 2, 2, 4, 2, 0>(a, st);
     if (bm == 128 && bn == 64) return nst == 3 ? sm::launch_gemm_h<128, 64, 3>(a, st) : nst == 4 ? sm::launch_gemm_h<128, 64, 4>(a, st) : sm::launch_gemm_h<128, 64, 2, 2, 2, 3>(a, st);
     if (bm == 64 && bn == 64) return nst == 4 ? sm::launch_gemm_h<64, 64, 4>(a, st) : nst == 5 ? sm::launch_gemm_h<64, 64, 5>(a, st) : nst == 2 ? sm::launch_gemm_h<64, 64, 2, 2, 2, 5>(a, st) : sm::launch_gemm_h<64, 64, 3, 2, 2, 3>(a, st);
     sm::set_error("sm_gemm_f16x2_tile: unsupported tile %dx%d", bm, bn);
@@ -482,7 +483,9 @@ extern "C" int sm_gemm_f16x2_pick_tile(const sm_gemm_args* g, int* bm, int* bn, 
     // Measured on MI355X (B=64 ViT-S/16 shapes).  A GEMM alone on the GPU is fastest as 128x64 tiles (three workgroups
     // per CU hide each other's prologue / epilogue), but the evaluator keeps three batches in flight on three streams
     // (streams.py), other kernels fill those gaps, and what counts is DMA instructions per FLOP: 128x128 tiles (two
-    // workgroups per CU, 64 KiB of LDS each) gave +5 % end to end over 128x64, 256x128 +3 %, 64x64 -8 %.
+    // workgroups per CU, 64 KiB of LDS each) gave +5 % end to end over 128x64, 256x128 +3 %, 64x64 -8 %.  The 128x128
+    // tile runs as EIGHT waves of 64x32 (101 registers: both workgroups of a CU = 16 waves, four per SIMD): +2.7 % over
+    // four waves of 64x64 - more waves to cover the DMA issue and the epilogue, although each re-reads more LDS per MFMA.
     const long nb = g->split_k > 1 ? g->split_k : g->batch;
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * nb;
     const long wg128x128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
