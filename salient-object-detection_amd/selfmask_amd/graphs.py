@@ -15,9 +15,10 @@ import torch
 
 
 class GraphedForward:
-    def __init__(self, model, enabled: bool = True):
+    def __init__(self, model, enabled: bool = True, max_graphs: int = 8):
         self.model = model
         self.enabled = enabled
+        self.max_graphs = max_graphs  # each graph owns a workspace + outputs: native-resolution runs meet many shapes
         self._seen: Dict[tuple, int] = {}
         self._graphs: Dict[tuple, object] = {}
         self.captures = 0
@@ -58,6 +59,9 @@ class GraphedForward:
         except Exception as e:  # capture unsupported here: keep the eager HIP path, say why once
             self.failed = f"{type(e).__name__}: {e}"
             return None
+        if len(self._graphs) >= self.max_graphs:  # drop the oldest capture (dicts keep insertion order)
+            torch.cuda.synchronize(x.device)
+            self._graphs.pop(next(iter(self._graphs)))
         self._graphs[key] = (graph, static_x, out, ws)
         self.captures += 1
         return self._graphs[key]
