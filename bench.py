@@ -96,6 +96,65 @@ def cpu_baseline(P, S, budget_s=15.0):
             "sample": f"{n} images (batches of {Bc}, ViT-S/{P} {S}x{S}, fp32 torch-CPU oracle) in {dt:.1f}s"}
 
 
+def spawn_ranks(n: int, argv) -> int:
+    """Start `n` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and
+    wait for them.  The parent never touches the GPU: ranks are fresh processes, nothing is exec'ed after HIP init."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launcher_selftest(a, world: int, rank: int) -> None:
+    """The launch / timing / gather skeleton of main() on CPU with gloo: K steps of a trivial per-rank "evaluation"
+    (rank-strided rows), barrier on both sides, one all-gather inside the timed region, MAX over ranks."""
+    import numpy as np
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus
+    B = a.batch
+    rows = torch.zeros((a.steps * B, 16))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        torch.ones(8).sum()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(a.steps):  # row i of rank r stands for global image (k*B + i) * world + r
+        rows[k * B:(k + 1) * B, 0] = torch.arange(k * B, (k + 1) * B, dtype=torch.float32) * world + rank
+    gathered = rows
+    if world > 1:
+        gathered = torch.empty((world * rows.shape[0], 16))
+        dist.all_gather_into_tensor(gathered, rows)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ids = np.sort(gathered[:, 0].numpy())
+    ok = bool((ids == np.arange(world * a.steps * B)).all())  # every global image exactly once after the gather
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest (gloo, CPU)", "value": world * a.steps * B / dt, "unit": "rows/sec",
+                          "n_gpus": world, "rccl_ranks": 0, "gloo_ranks": world, "steps": a.steps, "warmup": a.warmup,
+                          "gather_complete": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,16 +174,30 @@ def main():
                          "the metric keeps inputs resident in HBM)")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: skip the evaluator kernels (not the metric)")
     ap.add_argument("--gemm-mode", default=None, choices=["f16x2", "fp32"], help="GEMM back end (default f16x2)")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU rehearsal of the N-rank launch path (gloo, no GPU): same spawn, barrier, gather and "
+                         "max-over-ranks timing around a trivial step; used by tests/test_bench_launcher_cpu.py")
     a = ap.parse_args()
 
+    # ---- N ranks: one process per GPU ------------------------------------------------------------------------------
+    # `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself, as FRESH child
+    # processes (torch.distributed.run), before this process has made any GPU call; it relays rank 0's JSON line and
+    # exits with the children's status.  Launched by torch.distributed.run directly (the driver's form) it is a rank.
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report n_gpus != requested")
+    if a.launcher_selftest:
+        return launcher_selftest(a, world, rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -230,7 +303,7 @@ def main():
 
         res = {
             "metric": "images/sec (224^2, nq=20)", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if model.gemm_mode == "fp32" else "f32 (GEMM operands split into two f16 halves, f16 MFMA, f32 accumulate)",
