@@ -12,6 +12,7 @@
 // never goes through LDS.  The N x N score matrix never touches HBM (the reference materialises it: 59.6 MB
 // per layer at B=64).
 #include "common.h"
+#include <mutex>
 #include <math.h>
 
 namespace sm {
@@ -178,13 +179,12 @@ template <int NW>
 static int launch_attn(const sm_attn_args& a, int nqb, hipStream_t st) {
     const int kc_rows = min(((a.n_k + 31) / 32) * 32, ATT_KCH);
     const size_t lds = (size_t)kc_rows * (ATT_KLD + ATT_VLD) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel<NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, ATT_KCH * (ATT_KLD + ATT_VLD) * 4);
         (void)hipGetLastError();
-        attr_set = true;
-    }
+    });
     dim3 grid((nqb + NW - 1) / NW, a.heads, a.batch);
     hipLaunchKernelGGL((attention_f32_kernel<NW>), grid, dim3(NW * 64), lds, st, a, kc_rows);
     return check_launch("sm_attention_f32");

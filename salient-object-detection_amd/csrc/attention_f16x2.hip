@@ -19,6 +19,7 @@
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace sm {
 
@@ -36,6 +37,9 @@ __device__ __forceinline__ int hat_swz(int r) { return (r & 1) | ((r & 2) << 2) 
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_args a, int groups, int ablate) {
+#ifndef SM_TUNING
+    ablate = 0;  // the timing-only ablations exist only in the tuning build (build.py --tuning)
+#endif
     extern __shared__ __attribute__((aligned(16))) char smema[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smema;
 
@@ -255,14 +259,17 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
 
 template <int NW>
 static int launch_attn_h(const sm_attn_args& a, int groups, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<NW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HAT_SLOT);
         (void)hipGetLastError();
-        attr_set = true;
-    }
+    });
+#ifdef SM_TUNING
     static const int ablate = getenv("SM_ATTN_ABLATE") ? atoi(getenv("SM_ATTN_ABLATE")) : 0;  // timing-only: 1 = no compute, 2 = first chunk only
+#else
+    constexpr int ablate = 0;
+#endif
     dim3 grid(groups * a.heads * a.batch);
     hipLaunchKernelGGL((attention_f16x2_kernel<NW>), grid, dim3(NW * 64), 2 * HAT_SLOT, st, a, groups, ablate);
     return check_launch("sm_attention_f16x2");

@@ -75,12 +75,14 @@ __device__ __forceinline__ void split_idx(int idx, int W, float inv_w, int& y, i
 constexpr int EV_QS = 32;  // query stride of the transposed mask copy (floats): one 128-B line per low-res pixel
 
 // K0: maskT[b][p][q] = mask_pred[b][q][p] (q padded to 32) so the nq queries of one bilinear tap are one cache line
+// (models with more than 32 queries - the reference constructor's default is 100, maskformer.py:13 - take one pass of
+// the query kernel per group of 32: blockIdx.z, copy [pass][b][p][32])
 __global__ __launch_bounds__(256) void eval_transpose_kernel(sm_eval_args a, float* __restrict__ maskT) {
-    const int b = blockIdx.y, plane = a.mh * a.mw;
+    const int b = blockIdx.y, plane = a.mh * a.mw, qbase = blockIdx.z * EV_MAXQ;
     const float* __restrict__ m0 = a.mask_pred + (int64_t)b * a.mask_stride_b;
-    float* out = maskT + (int64_t)b * plane * EV_QS;
+    float* out = maskT + ((int64_t)blockIdx.z * a.B + b) * plane * EV_QS;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < plane * EV_QS; t += gridDim.x * 256) {
-        const int p = t / EV_QS, q = t - p * EV_QS;
+        const int p = t / EV_QS, q = qbase + (t - p * EV_QS);
         out[t] = q < a.nq ? m0[(int64_t)q * plane + p] : 0.f;
     }
 }
@@ -92,21 +94,24 @@ __global__ __launch_bounds__(256) void eval_transpose_kernel(sm_eval_args a, flo
 // batch, TA-bound); ds_read_b128 from LDS is an order of magnitude cheaper.  Integer counts go to global memory with
 // integer atomics (deterministic).
 constexpr int EV_LDS_ROWS = 8;  // low-res rows staged per chunk (falls back to global loads if the chunk needs more)
+constexpr int EV_LDS_BYTES = 64 * 1024;  // staging budget: wide masks stage fewer rows (lds_rows = budget / row bytes)
 
-__global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, const float* __restrict__ maskT,
-                                                                QueryStats* qpart, GtStats* gpart, int nchunk) {
+__global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, const float* __restrict__ maskT_all,
+                                                                QueryStats* qpart, GtStats* gpart, int nchunk, int lds_rows) {
     extern __shared__ __attribute__((aligned(16))) float taps[];  // [rows][mw][EV_QS]
     __shared__ unsigned red_u[EV_THREADS / 64][2 * EV_MAXQ];
     __shared__ unsigned long long red_g[EV_THREADS / 64][3];
     const int b = blockIdx.y;
+    const int qbase = blockIdx.z * EV_MAXQ, nqp = min(EV_MAXQ, a.nq - qbase);  // this pass: queries qbase .. qbase+nqp-1
+    const float* __restrict__ maskT = maskT_all + (int64_t)blockIdx.z * a.B * a.mh * a.mw * EV_QS;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W;
     const int base = blockIdx.x * EV_CHUNK;
-    QueryStats* qslot = qpart + ((int64_t)b * nchunk + blockIdx.x) * a.nq;  // per-chunk partials: no atomics (thousands
-    GtStats* gslot = gpart + (int64_t)b * nchunk + blockIdx.x;              // of adds on two cache lines serialise in L2)
+    QueryStats* qslot = qpart + ((int64_t)b * nchunk + blockIdx.x) * a.nq + qbase;  // per-chunk partials: no atomics (thousands
+    GtStats* gslot = gpart + (int64_t)b * nchunk + blockIdx.x;                      // of adds on two cache lines serialise in L2)
     if (base >= npx) {
-        if (threadIdx.x < a.nq) { QueryStats z; z.inter = 0; z.uni = 0; qslot[threadIdx.x] = z; }
-        if (threadIdx.x == 0) { GtStats z; z.sum_g = 0; z.sum_gx = 0; z.sum_gy = 0; *gslot = z; }
+        if (threadIdx.x < nqp) { QueryStats z; z.inter = 0; z.uni = 0; qslot[threadIdx.x] = z; }
+        if (threadIdx.x == 0 && qbase == 0) { GtStats z; z.sum_g = 0; z.sum_gx = 0; z.sum_gy = 0; *gslot = z; }
         return;
     }
     const unsigned char* __restrict__ gt = a.gt + im.gt_off;
@@ -114,11 +119,11 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
     const float inv_w = 1.0f / (float)im.W;
-    const int nq4 = (a.nq + 3) >> 2;
+    const int nq4 = (nqp + 3) >> 2;
     // low-res rows touched by this chunk
     const int last = min(base + EV_CHUNK, npx) - 1;
     const int r_lo = up_index(base / im.W, sy, a.mh).i0, r_hi = up_index(last / im.W, sy, a.mh).i1;
-    const bool staged = (r_hi - r_lo + 1) <= EV_LDS_ROWS;
+    const bool staged = (r_hi - r_lo + 1) <= lds_rows;
     if (staged) {
         const int n4 = (r_hi - r_lo + 1) * a.mw * (EV_QS / 4);
         const float4* src = reinterpret_cast<const float4*>(mt + (int64_t)r_lo * a.mw * EV_QS);
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int q = 0; q < EV_MAXQ; ++q) {
-        if (q < a.nq) {
+        if (q < nqp) {
             const unsigned i = wave_total(inter[q]), u = wave_total(uni[q]);
             if (lane == 0) { red_u[wv][2 * q] = i; red_u[wv][2 * q + 1] = u; }
         }
@@ -175,14 +180,14 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
     sg = wave_total(sg); sgx = wave_total(sgx); sgy = wave_total(sgy);
     if (lane == 0) { red_g[wv][0] = sg; red_g[wv][1] = sgx; red_g[wv][2] = sgy; }
     __syncthreads();
-    if (threadIdx.x < a.nq) {
+    if (threadIdx.x < nqp) {
         const int q = threadIdx.x;
         QueryStats o;
         o.inter = red_u[0][2 * q] + red_u[1][2 * q] + red_u[2][2 * q] + red_u[3][2 * q];
         o.uni = red_u[0][2 * q + 1] + red_u[1][2 * q + 1] + red_u[2][2 * q + 1] + red_u[3][2 * q + 1];
         qslot[q] = o;
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && qbase == 0) {  // the ground-truth sums do not depend on the query pass
         GtStats o;
         o.sum_g = red_g[0][0] + red_g[1][0] + red_g[2][0] + red_g[3][0];
         o.sum_gx = red_g[0][1] + red_g[1][1] + red_g[2][1] + red_g[3][1];
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
 // K1b: sum the per-chunk partials of an image (one thread per query)
 __device__ int select_query(const sm_eval_args& a, const QueryStats* qs, int b, int which, bool write_ious);
 
-__global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
+__global__ __launch_bounds__(1024) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
                                                                QueryStats* qs, GtStats* gs, int* sel, int nchunk) {
     const int b = blockIdx.x, t = threadIdx.x;
     if (t < a.nq) {
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64) void eval_reduce_query_kernel(sm_eval_args a, c
         }
         qs[b * a.nq + t] = o;
     }
-    if (t == 63) {
+    if (t == (int)blockDim.x - 1) {  // blockDim.x = nq + 1 rounded up to whole waves: the last lane is always spare
         GtStats o; o.sum_g = 0; o.sum_gx = 0; o.sum_gy = 0;
         #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) {
@@ -512,7 +517,7 @@ static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
     w.gpart = (GtStats*)take((size_t)B * nchunk * sizeof(GtStats));
     w.cnt = (MetricCounts*)take((size_t)B * 2 * nchunk * sizeof(MetricCounts));
     w.part = (double*)take((size_t)B * 2 * nchunk * EV_NACC * sizeof(double));
-    w.maskT = (float*)take((size_t)B * plane * EV_QS * sizeof(float));
+    w.maskT = (float*)take((size_t)((nq + EV_MAXQ - 1) / EV_MAXQ) * B * plane * EV_QS * sizeof(float));
     w.sel = (int*)take((size_t)B * 2 * sizeof(int));
     w.thr_adapt = (float*)take((size_t)B * 2 * sizeof(float));
     w.total = off;
@@ -522,18 +527,18 @@ static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
 }  // namespace sm
 
 static const int SM_EVAL_MAX_PIXELS = 1 << 22;
+static const int SM_EVAL_MAX_QUERIES = 960;  // one thread per query in the reduce kernel (a workgroup is <= 1024 threads)
 
 extern "C" size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq, int32_t mh, int32_t mw, int32_t max_pixels) {
-    if (B <= 0 || nq <= 0 || nq > sm::EV_MAXQ || mh <= 0 || mw <= 0 || max_pixels <= 0 || max_pixels > SM_EVAL_MAX_PIXELS) return 0;
+    if (B <= 0 || nq <= 0 || nq > SM_EVAL_MAX_QUERIES || mh <= 0 || mw <= 0 || max_pixels <= 0 || max_pixels > SM_EVAL_MAX_PIXELS) return 0;
     return sm::carve_eval(B, nq, (max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK, mh * mw, nullptr).total;
 }
 
 extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
     SM_REQUIRE(a && a->mask_pred && a->objectness && a->gt && a->images && a->thresholds && a->rows && a->workspace,
                "sm_evaluate_masks_f32: null pointer");
-    SM_REQUIRE(a->B > 0 && a->nq > 0 && a->nq <= sm::EV_MAXQ && a->mh > 0 && a->mw > 0 && a->scale >= 0.f,
-               "sm_evaluate_masks_f32: bad shape (nq <= %d)", sm::EV_MAXQ);
-    SM_REQUIRE(a->mw <= 128, "sm_evaluate_masks_f32: mask width %d > 128 (LDS tap staging)", a->mw);
+    SM_REQUIRE(a->B > 0 && a->nq > 0 && a->nq <= SM_EVAL_MAX_QUERIES && a->mh > 0 && a->mw > 0 && a->scale >= 0.f,
+               "sm_evaluate_masks_f32: bad shape (B=%d nq=%d (<= %d) mask %dx%d)", a->B, a->nq, SM_EVAL_MAX_QUERIES, a->mh, a->mw);
     SM_REQUIRE(a->max_pixels > 0 && a->max_pixels <= SM_EVAL_MAX_PIXELS,
                "sm_evaluate_masks_f32: max_pixels=%d (largest H*W of the batch, <= %d)", a->max_pixels, SM_EVAL_MAX_PIXELS);
     SM_REQUIRE(a->workspace_bytes >= sm_evaluate_workspace_bytes(a->B, a->nq, a->mh, a->mw, a->max_pixels) &&
@@ -542,10 +547,16 @@ extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = (a->max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK;
     const sm::EvalWs w = sm::carve_eval(a->B, a->nq, nchunk, a->mh * a->mw, (char*)a->workspace);
-    hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B), dim3(256), 0, st, *a, w.maskT);
-    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B), dim3(sm::EV_THREADS),
-                       (size_t)sm::EV_LDS_ROWS * a->mw * sm::EV_QS * sizeof(float), st, *a, w.maskT, w.qpart, w.gpart, nchunk);
-    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(64), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, w.sel, nchunk);
+    const int npass = (a->nq + sm::EV_MAXQ - 1) / sm::EV_MAXQ;
+    // tap staging: up to EV_LDS_ROWS low-res rows of [mw][32 queries] floats inside a 64-KiB budget; masks too wide for
+    // even one row (mw > 512) read their taps from global memory (the kernel's fallback path)
+    const size_t row_bytes = (size_t)a->mw * sm::EV_QS * sizeof(float);
+    const int lds_rows = (int)(sm::EV_LDS_BYTES / row_bytes) < sm::EV_LDS_ROWS ? (int)(sm::EV_LDS_BYTES / row_bytes) : sm::EV_LDS_ROWS;
+    const int red_threads = ((a->nq + 1 + 63) / 64) * 64;  // one thread per query + a spare last lane for the GT sums
+    hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B, npass), dim3(256), 0, st, *a, w.maskT);
+    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B, npass), dim3(sm::EV_THREADS), lds_rows * row_bytes, st, *a,
+                       w.maskT, w.qpart, w.gpart, nchunk, lds_rows);
+    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(red_threads), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, w.sel, nchunk);
     hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.part, nchunk);
     hipLaunchKernelGGL(sm::eval_adapt_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.part, w.thr_adapt, nchunk);
     hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.thr_adapt, w.gs,

@@ -16,6 +16,7 @@
 //   * two-level summation: the MFMA chain runs over 128 k, then is folded into a second accumulator with VALU
 //     adds (a single 1536-long chain measured 5x torch-CPU's error against fp64).
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 
 namespace sm {
@@ -225,12 +226,13 @@ template <int BM, int BN, int NST>
 static int launch_gemm(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : g.batch);
     constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, NST>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipGetLastError();
-        attr_set = true;
+    if (lds > 64 * 1024) {
+        static std::once_flag attr_once;  // per instantiation; safe from several host threads
+        std::call_once(attr_once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, NST>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipGetLastError();
+        });
     }
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, NST>), grid, dim3(256), lds, st, g);
     return check_launch("sm_gemm_f32");

@@ -23,6 +23,7 @@
 // (__launch_bounds__) and the tile's DMA bytes per FLOP decide the default shapes.
 #include "common.h"
 #include <type_traits>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -140,7 +141,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
 #pragma unroll
     for (int v = -(NSTA - 1); v < 0; ++v) issue_step(v);  // prologue = the virtual steps before kt = 0
 
-    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // timing-only runs: 2 = no MFMA, 3 = no DMA in the loop, 4 = no epilogue, 5 = 3 + 4, 6 = 5 without the barrier
+#ifdef SM_TUNING  // timing-only ablations exist only in the tuning build (build.py --tuning), never in the product library
+    const int ablate = g.patch_n <= -2 ? -g.patch_n : 0;  // 2 = no MFMA, 3 = no DMA in the loop, 4 = no epilogue, 5 = 3 + 4, 6 = 5 without the barrier
+#else
+    constexpr int ablate = 0;
+#endif
     for (int kt = 0; kt < nk; ++kt) {
         if (ablate != 6) {
             // tiles kt of both rings have landed; what may still fly was issued after the later of the two: AX = 0 the
@@ -403,12 +408,13 @@ template <int BM, int BN, int NST, int NWM = 2, int NWN = 2, int MINB = 1, int A
 static int launch_gemm_h(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : g.batch);
     constexpr size_t lds = (size_t)((NST + AX) * BM + NST * BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB, AX>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipGetLastError();
-        attr_set = true;
+    if (lds > 64 * 1024) {
+        static std::once_flag attr_once;  // per instantiation; safe from several host threads
+        std::call_once(attr_once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB, AX>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipGetLastError();
+        });
     }
     hipLaunchKernelGGL((gemm_f16x2_kernel<BM, BN, NST, NWM, NWN, MINB, AX>), grid, dim3(NWM * NWN * 64), lds, st, g);
     return check_launch("sm_gemm_f16x2");
@@ -453,7 +459,9 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
                    "sm_gemm_f16x2: bad split_k");
     sm_gemm_args a = *g;
     if (out_f16x2) a.patch_n = -1;
-    if (const char* ab = getenv("SM_F16X2_ABLATE")) a.patch_n = -atoi(ab);  // timing-only (wrong results)
+#ifdef SM_TUNING
+    if (const char* ab = getenv("SM_F16X2_ABLATE")) a.patch_n = -atoi(ab);  // timing-only (wrong results): tuning build only
+#endif
     hipStream_t st = (hipStream_t)stream;
     // Occupancy is what this kernel lives on (scripts/gemm_f16x2_ablate.py): the DMA stream, the MFMA stream and the
     // epilogue of one workgroup only overlap with those of OTHER workgroups on the CU, so the default shapes are the

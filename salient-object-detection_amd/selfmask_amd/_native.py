@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "lib", "libselfmask_hip.so"))
+# SM_HIP_LIB points the binding at another build of the same ABI - the tuning build with the timing-only ablation
+# switches (build.py --tuning -> lib/libselfmask_hip_tuning.so), used by scripts/*_ablate.py only
+LIB_PATH = os.environ.get("SM_HIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "lib", "libselfmask_hip.so"))
 
 EMBED, HEADS, HEAD_DIM, MLP, ENC_DEPTH, MAX_DEC_LAYERS = 384, 6, 64, 1536, 12, 8
 EPI_BIAS, EPI_GELU, EPI_RELU, EPI_RESIDUAL, EPI_SIGMOID2, EPI_PATCH, EPI_RESIDUAL_LN = range(7)

@@ -53,7 +53,9 @@ class Evaluator(BaseStructure):
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
         # recurring batch shapes replay one captured hipGraph per stream instead of 171 launches (graphs.py)
-        self._graphed = GraphedForward(self.model, enabled=hip_graph and isinstance(self.model, torch.nn.Module))
+        # native-resolution mode meets a new shape with almost every image: graphs would only thrash there
+        self._graphed = GraphedForward(self.model, enabled=hip_graph and img_size is not None and
+                                       isinstance(self.model, torch.nn.Module))
         for s in range(0, len(mine), batch_size):
             items = [dataset[i] for i in mine[s:s + batch_size]]
             x = torch.stack([it["x"] for it in items])

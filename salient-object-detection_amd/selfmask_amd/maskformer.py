@@ -156,6 +156,8 @@ class MaskFormer(nn.Module):
             raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'f16x2' or 'fp32'")
         self._table = None       # (Weights struct, key) cache
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
+        self.weights_generation = 0  # bumped whenever the packed weights are dropped: captured hipGraphs hold raw
+                                     # pointers into them, graphs.GraphedForward destroys its graphs when this changes
         self._workspace = {}     # (device, B, H, W, stream) -> uint8 tensor
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_packed())
         self.eval()
@@ -165,6 +167,7 @@ class MaskFormer(nn.Module):
         self._table = None
         self._packed = None
         self._workspace = {}
+        self.weights_generation = getattr(self, "weights_generation", 0) + 1
         return super()._apply(fn, *a, **kw)
 
     def refresh_packed(self):
@@ -172,6 +175,7 @@ class MaskFormer(nn.Module):
         ``load_state_dict`` and ``.to()`` do it automatically."""
         self._table = None
         self._packed = None
+        self.weights_generation += 1
 
     def _weights(self) -> N.Weights:
         key = (self.query_embed.data_ptr(), self.ffn.layers[2].bias.data_ptr(), self.encoder.pos_embed.data_ptr(),
@@ -239,6 +243,9 @@ class MaskFormer(nn.Module):
         w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))
         w.n_queries = self.n_queries
         w.n_dec_layers = self.n_decoder_layers
+        # the ~90 split kernels above ran on the current stream; forwards on OTHER streams (streams.StreamRing) reuse this
+        # table without an event dependency on it, so finish the packing here, once per weight generation
+        torch.cuda.current_stream(self.query_embed.device).synchronize()
         self._table = (w, key)
         return w
 

@@ -5,6 +5,9 @@ import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(REPO, "salient-object-detection_amd"), REPO]
 import torch
+# the ablation switches are compiled into the tuning build only (python salient-object-detection_amd/build.py --tuning)
+os.environ.setdefault("SM_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                                                "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so"))
 from selfmask_amd import ops, _native as N
 
 def t(fn, it=20):

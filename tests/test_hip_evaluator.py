@@ -98,7 +98,7 @@ def test_batched_mode_224_patch16_and_two_virtual_ranks(tmp_path):
 def test_batches_in_flight_on_several_streams_give_identical_rows(tmp_path):
     """streams.StreamRing: 1, 2 and 3 batches in flight run the same kernels per batch -> bit-identical result rows
     (different batch shapes share the model: each (shape, stream) pair has its own workspace)."""
-    DS.write_synthetic_dataset(str(tmp_path), "duts", 13, seed=10, size_range=(120, 230))
+    DS.write_synthetic_dataset(str(tmp_path), "duts", 22, seed=10, size_range=(120, 230))
     model, _ = _model(16, 23)
     ev = Evaluator(network=model, dir_dataset=str(tmp_path))
     ev.device = DEV
@@ -106,7 +106,7 @@ def test_batches_in_flight_on_several_streams_give_identical_rows(tmp_path):
     for n in (1, 2, 3):
         ev("duts", dir_ckpt=str(tmp_path / f"s{n}"), img_size=224, batch_size=3, device=DEV, streams=n)
         rows.append(ev.last_rows.copy())
-        # 13 images in batches of 3 = 4 full batches + 1 ragged: every stream that sees the full shape twice captures it
+        # 22 images in batches of 3 = 7 full batches + 1 ragged: a stream that sees the full shape three times captures it
         assert ev.graph_stats["failed"] is None and ev.graph_stats["replays"] >= 1
     assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows[0], rows[2])
     ev("duts", dir_ckpt=str(tmp_path / "eager"), img_size=224, batch_size=3, device=DEV, streams=2, hip_graph=False)

@@ -134,11 +134,11 @@ def test_full_bench_batch_64_properties(mode):
 
 
 def test_hip_graph_replay_gives_the_eager_bits():
-    """graphs.GraphedForward: first call eager, second captures + replays, later ones replay; a new batch through the
-    captured graph equals the eager forward bit for bit, on the default stream and on a side stream."""
+    """graphs.GraphedForward: the first two calls are eager, the third captures + replays, later ones replay; a new
+    batch through the captured graph equals the eager forward bit for bit, on the default stream and on a side stream."""
     from selfmask_amd import GraphedForward
     m = _model(16, 3, "soft")
-    xs = [torch.from_numpy(synthetic_images(200 + i, (3, 3, 224, 224))).to(DEV) for i in range(4)]
+    xs = [torch.from_numpy(synthetic_images(200 + i, (3, 3, 224, 224))).to(DEV) for i in range(5)]
     eager = [{k: v.clone() for k, v in m(x).items()} for x in xs]
     for stream in (None, torch.cuda.Stream()):
         g = GraphedForward(m)
@@ -150,18 +150,37 @@ def test_hip_graph_replay_gives_the_eager_bits():
                     assert torch.equal(out[k], e[k]), k
         torch.cuda.synchronize()
         assert g.failed is None and g.captures == 1 and g.replays == 3
-    # a shape seen once stays eager
+    # a shape seen once or twice stays eager
     g = GraphedForward(m)
+    g(xs[0][:2])
     g(xs[0][:2])
     assert g.captures == 0 and g.replays == 0
     # bounded number of live graphs: two shapes alternating through a one-graph cache keep giving the eager bits
-    g = GraphedForward(m, max_graphs=1)
-    for rep in range(3):
+    g = GraphedForward(m, max_graphs=1, admit_after=1)
+    for rep in range(4):
         for x, e in ((xs[0], eager[0]), (xs[1][:2], None)):
             out = g(x)
             if e is not None:
                 assert torch.equal(out["mask_pred"], e["mask_pred"])
-    assert g.failed is None and g.captures >= 2 and len(g._graphs) == 1
+    assert g.failed is None and g.captures >= 2 and len(g.policy) == 1
+
+
+def test_hip_graph_follows_new_weights():
+    """A captured graph holds raw pointers to the packed (split) weight copies; load_state_dict rebuilds those.  The
+    next call through GraphedForward must give the NEW weights' eager result, not replay stale pointers."""
+    from selfmask_amd import GraphedForward
+    m = _model(16, 3, "soft")
+    x = torch.from_numpy(synthetic_images(321, (2, 3, 224, 224))).to(DEV)
+    g = GraphedForward(m, admit_after=0)
+    first = {k: v.clone() for k, v in g(x).items()}
+    assert g.captures == 1
+    m.load_state_dict(synthetic_state_dict(8, "calib", patch_size=16), strict=True)
+    eager_new = {k: v.clone() for k, v in m(x).items()}
+    assert not torch.equal(eager_new["mask_pred"], first["mask_pred"])
+    out = g(x)   # generation changed: old graph destroyed, this call re-captures under the new weights
+    for k in eager_new:
+        assert torch.equal(out[k], eager_new[k]), k
+    assert g.captures == 2 and g.failed is None
 
 
 @pytest.mark.parametrize("patch,B,H,W,nq,L,seed", [
