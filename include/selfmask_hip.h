@@ -74,6 +74,8 @@ typedef struct sm_gemm_args {
     const float* ln_gamma; /* SM_EPI_RESIDUAL_LN: weight / bias (384) and eps of the fused LayerNorm; its F16X2 output */
     const float* ln_beta;  /* goes to C2 (row stride ldc)                                                              */
     float ln_eps;
+    float w_scale;         /* sm_gemm_w16 only: 2^-s of the W16 weight tensor (sm_split_w16 scale = 2^s); the accumulator
+                              is multiplied by it before the bias                                                       */
 } sm_gemm_args;
 
 /* C = epilogue(A W^T): replaces every F.linear / conv-as-GEMM / bmm on the path
@@ -97,6 +99,21 @@ int sm_gemm_f16x2_tile(const sm_gemm_args* args, int out_f16x2, int bm, int bn, 
 /* tile / pipeline depth chosen per shape */
 int sm_gemm_f16x2(const sm_gemm_args* args, int out_f16x2, void* stream);
 int sm_gemm_f16x2_pick_tile(const sm_gemm_args* args, int* bm, int* bn, int* nst);
+
+/* ---- weight GEMMs with ONE accumulator (W16 weights) ------------------------------------------------------------
+ * W16 format of a weight row: the tensor is scaled by a power of two 2^s chosen by the host so that max|W * 2^s| lies in
+ * [2^13, 2^14); per group of 8 k, 16 B of wh = f16(w') then 16 B of wl = f16(w' - wh) - NOT scaled by 2^11, the scaled
+ * tensor keeps wl a normal f16.  a*w' = ah*wh + ah*wl + al'*(wh*2^-11) then sums in one fp32 accumulator (A stays in the
+ * F16X2 format): half the accumulator registers of sm_gemm_f16x2, which buys 256 x 128 workgroup tiles (fewer staged
+ * bytes per MFMA).  Same F.linear call sites as sm_gemm_f32 (vision_transformer.py:113,131,89-93,186;
+ * transformer_decoder.py:271-293; maskformer.py:265-268); W must be a weight (batch 1). */
+int sm_split_w16(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t K, float scale,
+                 void* stream);
+/* variant: 0 = 256x128 (8 waves, 16-k stages x3), 1 = 256x128 (16 waves, 32-k x2), 2 = 128x128 (8 waves), 3 = 128x128
+ * (4 waves, 16-k x3), 4 = 64x64, 6 = 256x128 (8 waves, 32-k x2), 7 = 128x64 */
+int sm_gemm_w16_tile(const sm_gemm_args* args, int out_f16x2, int variant, void* stream);
+int sm_gemm_w16(const sm_gemm_args* args, int out_f16x2, void* stream);
+int sm_gemm_w16_pick(const sm_gemm_args* args); /* the variant sm_gemm_w16 launches for this shape */
 
 /* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
  * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */

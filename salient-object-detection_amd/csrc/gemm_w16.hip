@@ -1,0 +1,385 @@
+// fp32-grade GEMM against a WEIGHT matrix on the f16 matrix cores with ONE fp32 accumulator: C = epilogue(A W^T + bias),
+// A in the F16X2 split format (hi = f16(a), lo' = f16((a - hi) * 2^11), as every producer writes it), W in the
+// "W16" format prepared once per checkpoint.
+//
+// Why a second weight format.  gemm_f16x2.hip evaluates a*w as hi*hi + 2^-11 (hi*lo' + lo'*hi) and therefore needs TWO
+// accumulators (main, cross): 32 accumulator registers per 32x32 block.  That caps the tile a workgroup can own, and
+// the kernel is fed through the texture path (LDS-DMA: ~16 cycles of the CU's single address unit per 1-KiB piece):
+// at 128 x 128 the staging of both operands takes two thirds of the MFMA time and any stall shows.
+// Weights are static, so they can be pre-scaled: W' = W * 2^s with s chosen per tensor so that max|W'| lies in
+// [2^13, 2^14).  Then wl = f16(W' - f16(W')) is a NORMAL f16 number without its own 2^11 factor (or, for tiny weights,
+// a subnormal whose absolute error is 2^-39 of the tensor's maximum), and
+//     a * w' = ah*wh + ah*wl + al'*(wh * 2^-11)            (dropping al*wl, 2^-22 relative, as before)
+// all three products in the SAME scale: one accumulator, three MFMAs.  whs = wh * 2^-11 is exact (wh >= 2^-3 after the
+// scaling, far above the f16 subnormal range) and costs four v_pk_mul_f16 per weight fragment, hidden under the MFMAs.
+// The epilogue multiplies the accumulator by 2^-s (exact) before the bias.  Half the accumulator registers buy a
+// 256 x 128 tile per workgroup: 3/4 of the staged bytes per MFMA of the 128 x 128 tile at the same occupancy.
+//
+// Everything else follows gemm_f16x2.hip: LDS-DMA ring with counted vmcnt + one raw barrier per K-tile, XOR swizzle on
+// the DMA source address and the fragment reads, weights as the MFMA A operand (a lane owns one output row), epilogue
+// turned through the idle ring so global accesses are contiguous row segments, XCD-aware tile order.
+#include "common.h"
+#include <type_traits>
+#include <mutex>
+#include <stdlib.h>
+#include <string.h>
+
+namespace sm {
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_w() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// KT = k per ring stage (16 or 32): a stage row is KT*4 bytes = CH 16-B chunks (per 8-k group: hi chunk, lo chunk).
+// A 1-KiB LDS-DMA piece covers 1024 / (KT*4) rows.  Chunk c of row r sits at slot c ^ swz(r): with 128-B rows two rows
+// share a 256-B bank row (swz = (r >> 1) & 7), with 64-B rows four do (swz = (r >> 2) & 3) - either way the 16 lanes of
+// a ds_read_b128 group (distinct rows, one logical chunk) land on 16 different 16-B slots.
+template <int KT>
+__device__ __forceinline__ int stage_swz(int row) {
+    if constexpr (KT == 32) return (row >> 1) & 7;
+    else return (row >> 2) & 3;
+}
+
+// WPS = waves per SIMD the register allocation must leave room for (second __launch_bounds__ argument)
+template <int BM, int BN, int KT, int NST, int NWM, int NWN, int WPS>
+__global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_args g) {
+    constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWB = KT * 4, CH = KT / 4, RPP = 1024 / ROWB;       // bytes / chunks per stage row, rows per DMA piece
+    constexpr int KS = KT / 16;                                          // 16-deep MFMA steps per stage
+    constexpr int A_INST = BM / RPP / NW, W_INST = BN / RPP / NW;        // 1-KiB pieces per wave and stage
+    static_assert(KT == 16 || KT == 32, "stage depth");
+    static_assert(A_INST * RPP * NW == BM && W_INST * RPP * NW == BN && TM * 32 * NWM == BM && TN * 32 * NWN == BN, "tile split");
+    static_assert(A_INST >= 1 && W_INST >= 1, "every wave issues at least one piece per operand");
+    constexpr int NI = A_INST + W_INST;
+    constexpr int A_STAGE = BM * ROWB, W_STAGE = BN * ROWB;
+    constexpr int W_RING = NST * A_STAGE;
+    constexpr int RING_BYTES = NST * (A_STAGE + W_STAGE);
+    extern __shared__ __attribute__((aligned(16))) char smemw[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r = lane & 31, h = lane >> 5;
+    // XCD-aware 1-D tile order: every XCD (id % 8) gets a contiguous range of logical tiles, m-tile major
+    int tile_id = blockIdx.x;
+    const int ntn = (g.N + BN - 1) / BN;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int n0 = (tile_id % ntn) * BN, m0 = (tile_id / ntn) * BM;
+    const int M = g.M, N = g.N;
+    const int split = g.split_k > 1 ? g.split_k : 1;
+    const int nk = g.K / KT / split;
+    const int k_begin = split > 1 ? (int)blockIdx.z * nk * KT : 0;
+    const char* A = reinterpret_cast<const char*>(((g.alt_from_n > 0 && n0 >= g.alt_from_n) ? g.A_alt : g.A) + k_begin);
+    const char* W = reinterpret_cast<const char*>(g.W + k_begin);
+
+    const char* a_src[A_INST];
+    const char* w_src[W_INST];
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = (wave * A_INST + i) * RPP + lane / CH;
+        const int c = (lane % CH) ^ stage_swz<KT>(row);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        a_src[i] = A + ((int64_t)gm * g.lda) * 4 + c * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_INST; ++i) {
+        const int row = (wave * W_INST + i) * RPP + lane / CH;
+        const int c = (lane % CH) ^ stage_swz<KT>(row);
+        int gn = n0 + row;
+        gn = gn < N ? gn : N - 1;
+        w_src[i] = W + ((int64_t)gn * g.ldw) * 4 + c * 16;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smemw;
+    auto issue_step = [&](int kt) {  // the tile NST-1 ahead of kt: W pieces, then A pieces (tiles past the end re-fetch the last)
+        const int t = kt + NST - 1;
+        if (t < 0) return;
+        const int tt = t < nk ? t : nk - 1, slot = t % NST;
+        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + wave * W_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < W_INST; ++i) lds_dma16(w_src[i] + tt * ROWB, sw + i * 1024);
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + wave * A_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) lds_dma16(a_src[i] + tt * ROWB, sa + i * 1024);
+    };
+
+    // fragment byte offsets inside a stage row: 16-deep step s, lane half h -> k-group KS==2 ? 2s+h : h
+    const int swz = stage_swz<KT>(r);
+    int off_hi[KS], off_lo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        off_hi[s] = ((2 * (2 * s + h)) ^ swz) * 16;
+        off_lo[s] = ((2 * (2 * s + h) + 1) ^ swz) * 16;
+    }
+    const int a_row = (wm * WTM + r) * ROWB;
+    const int w_row = (wn * WTN + r) * ROWB;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+#pragma unroll
+    for (int v = -(NST - 1); v < 0; ++v) issue_step(v);
+
+    const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                        (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt_w<(NST - 2) * NI>();   // tile kt has landed (this wave's pieces); younger tiles may still fly
+        __builtin_amdgcn_s_barrier();     // ... for every wave, and every wave is done reading the slot refilled next
+        __builtin_amdgcn_sched_barrier(0);
+        issue_step(kt);
+        const char* sta = smemw + (kt % NST) * A_STAGE;
+        const char* stw = smemw + W_RING + (kt % NST) * W_STAGE;
+        f16x8 ah[KS][TM], al[KS][TM], wh[KS][TN], wl[KS][TN];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                wh[s][j] = *reinterpret_cast<const f16x8*>(stw + w_row + j * 32 * ROWB + off_hi[s]);
+                wl[s][j] = *reinterpret_cast<const f16x8*>(stw + w_row + j * 32 * ROWB + off_lo[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[s][i] = *reinterpret_cast<const f16x8*>(sta + a_row + i * 32 * ROWB + off_hi[s]);
+                al[s][i] = *reinterpret_cast<const f16x8*>(sta + a_row + i * 32 * ROWB + off_lo[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f16x8 whs = wh[s][j] * down;  // exact: |wh| >= 2^-3 after the per-tensor scaling (v_pk_mul_f16 x 4)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    // D[n][m]: weights are the MFMA A operand (rows = n), activations the B operand (cols = m)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s][j], ah[s][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s][j], ah[s][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whs, al[s][i], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_vmcnt_w<0>();
+
+    float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : 0) * g.strideC;
+    const bool out_split = g.patch_n < 0;  // out-format flag travels in the sign of patch_n for non-PATCH epilogues
+    const float ws = g.w_scale;            // 2^-s of the weight tensor (exact power of two)
+
+    // ---- epilogue: each wave turns its 32 x WTN blocks through a private piece of the idle ring, so global accesses are
+    // contiguous row segments (see gemm_f16x2.hip) ---------------------------------------------------------------------
+    constexpr int EPLD = WTN * 4 + 16;
+    constexpr int PIECES = WTN / 4;
+    static_assert(NW * 32 * EPLD <= RING_BYTES, "epilogue staging must fit in the ring");
+    __builtin_amdgcn_s_barrier();
+    char* ep = smemw + wave * (32 * EPLD);
+
+    auto run = [&](auto epi_tag, auto fmt_tag) {
+        constexpr int EPI = decltype(epi_tag)::value;
+        constexpr bool F = decltype(fmt_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if constexpr (F) {
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        float x[4], y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int nx = n0 + wn * WTN + j * 32 + 8 * q + 4 * h + e, ny = nx + 8;
+                            x[e] = acc[i][j][4 * q + e] * ws + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
+                            y[e] = acc[i][j][4 * q + 4 + e] * ws + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
+                            if constexpr (EPI == SM_EPI_GELU) {
+                                x[e] = 0.5f * x[e] * (1.0f + fast_erff(x[e] * 0.70710678118654752440f));
+                                y[e] = 0.5f * y[e] * (1.0f + fast_erff(y[e] * 0.70710678118654752440f));
+                            } else if constexpr (EPI == SM_EPI_RELU) {
+                                x[e] = fmaxf(x[e], 0.f);
+                                y[e] = fmaxf(y[e], 0.f);
+                            }
+                        }
+                        pair_groups(x, y);
+                        store_f16x2_8(ep + r * EPLD, j * 32 + 8 * (q + h), x, y);
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nl = j * 32 + 8 * q + 4 * h, n = n0 + wn * WTN + nl;
+                        float4 val;
+                        float* vp = &val.x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float b = (g.bias && n < N) ? g.bias[n + e] : 0.f;
+                            float t = acc[i][j][4 * q + e] * ws + b;
+                            if constexpr (EPI == SM_EPI_GELU) t = 0.5f * t * (1.0f + fast_erff(t * 0.70710678118654752440f));
+                            else if constexpr (EPI == SM_EPI_RELU) t = fmaxf(t, 0.f);
+                            vp[e] = t;
+                        }
+                        *reinterpret_cast<float4*>(ep + r * EPLD + nl * 4) = val;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 32 * PIECES / 64; ++it) {
+                const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
+                int m = m0 + wm * WTM + i * 32 + row;
+                const int n = n0 + wn * WTN + pc * 4;
+                if (m < M && n < N) {
+                    float4 v = *reinterpret_cast<const float4*>(ep + row * EPLD + pc * 16);
+                    if constexpr (EPI == SM_EPI_RESIDUAL) {
+                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)m * g.ldr + n);
+                        v.x = rr.x + v.x; v.y = rr.y + v.y; v.z = rr.z + v.z; v.w = rr.w + v.w;
+                    } else if constexpr (EPI == SM_EPI_PATCH) {
+                        const int img = m / g.patch_n, p = m - img * g.patch_n;
+                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                        m = img * (g.patch_n + 1) + 1 + p;
+                    }
+                    *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    using T = std::true_type;
+    using Fa = std::false_type;
+    switch (g.epilogue) {
+        case SM_EPI_GELU: out_split ? run(std::integral_constant<int, SM_EPI_GELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_GELU>{}, Fa{}); break;
+        case SM_EPI_RELU: out_split ? run(std::integral_constant<int, SM_EPI_RELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_RELU>{}, Fa{}); break;
+        case SM_EPI_RESIDUAL: run(std::integral_constant<int, SM_EPI_RESIDUAL>{}, Fa{}); break;
+        case SM_EPI_PATCH: run(std::integral_constant<int, SM_EPI_PATCH>{}, Fa{}); break;
+        default: out_split ? run(std::integral_constant<int, SM_EPI_BIAS>{}, T{}) : run(std::integral_constant<int, SM_EPI_BIAS>{}, Fa{}); break;
+    }
+}
+
+// fp32 weights (rows, K) -> W16: per group of 8 k, 16 B of wh = f16(w * scale) then 16 B of wl = f16(w * scale - wh)
+__global__ __launch_bounds__(256) void split_w16_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
+                                                        int64_t ldd, int K, int64_t total_groups, float scale) {
+    const int gpr = K / 8;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total_groups; t += (int64_t)gridDim.x * 256) {
+        const int64_t row = t / gpr;
+        const int gidx = (int)(t - row * gpr);
+        const float4 a = *reinterpret_cast<const float4*>(src + row * lds_ + gidx * 8);
+        const float4 b = *reinterpret_cast<const float4*>(src + row * lds_ + gidx * 8 + 4);
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = x[e] * scale;  // exact: scale is a power of two
+            _Float16 hh;
+            float hf;
+            asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hh) : "v"(v));
+            asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(hh));
+            hi[e] = hh;
+            lo[e] = (_Float16)(v - hf);
+        }
+        char* p = reinterpret_cast<char*>(dst + row * ldd) + gidx * 32;
+        *reinterpret_cast<f16x8*>(p) = hi;
+        *reinterpret_cast<f16x8*>(p + 16) = lo;
+    }
+}
+
+template <int BM, int BN, int KT, int NST, int NWM, int NWN, int MINB>
+static int launch_gemm_w(const sm_gemm_args& g, hipStream_t st) {
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : 1);
+    constexpr size_t lds = (size_t)NST * (BM + BN) * KT * 4;
+    if (lds > 64 * 1024) {
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipGetLastError();
+        });
+    }
+    hipLaunchKernelGGL((gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB>), grid, dim3(NWM * NWN * 64), lds, st, g);
+    return check_launch("sm_gemm_w16");
+}
+
+}  // namespace sm
+
+extern "C" int sm_split_w16(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int32_t K, float scale,
+                            void* stream) {
+    SM_REQUIRE(src && dst && rows > 0 && K > 0 && K % 8 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= K &&
+                   ld_dst >= K,
+               "sm_split_w16: bad arguments (K %% 8 == 0, strides %% 4 == 0)");
+    int ex = 0;
+    SM_REQUIRE(scale > 0.f && frexpf(scale, &ex) == 0.5f, "sm_split_w16: scale must be a power of two");
+    const int64_t groups = rows * (K / 8);
+    int64_t grid = (groups + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sm::split_w16_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, K,
+                       groups, scale);
+    return sm::check_launch("sm_split_w16");
+}
+
+// variants: 0 = 256x128, 8 waves of 64x64, 16-k stages x 3 (72 KiB: two workgroups per CU)
+//           1 = 256x128, 16 waves of 64x32, 32-k stages x 2 (96 KiB: one workgroup per CU)
+//           2 = 128x128, 8 waves of 64x32, 32-k stages x 2 (64 KiB: two per CU)        [the f16x2 default shape]
+//           3 = 128x128, 4 waves of 64x64, 16-k stages x 3 (48 KiB: three per CU)
+//           4 = 64x64, 4 waves of 32x32, 32-k stages x 3 (48 KiB)                        [small decoder GEMMs]
+//           6 = 256x128, 8 waves of 64x64, 32-k stages x 2 (96 KiB: one per CU)
+//           7 = 128x64, 4 waves of 64x32, 32-k stages x 2 (48 KiB: three per CU)
+//           8 = 128x128, 8 waves of 64x32, 16-k stages x 3 (48 KiB: three per CU)
+extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int variant, void* stream) {
+    SM_REQUIRE(g && g->A && g->W && g->C, "sm_gemm_w16: null pointer");
+    SM_REQUIRE(g->M > 0 && g->N > 0 && g->K > 0 && g->K % 32 == 0 && g->batch <= 1, "sm_gemm_w16: bad shape (K %% 32, batch 1)");
+    SM_REQUIRE(g->N % 4 == 0 && g->ldc % 4 == 0 && ((uintptr_t)g->C % 16 == 0), "sm_gemm_w16: N, ldc must be multiples of 4");
+    SM_REQUIRE(g->lda % 8 == 0 && g->ldw % 8 == 0 && ((uintptr_t)g->A % 16 == 0) && ((uintptr_t)g->W % 16 == 0),
+               "sm_gemm_w16: lda/ldw must be multiples of 8, pointers 16-B aligned");
+    SM_REQUIRE(g->epilogue == SM_EPI_BIAS || g->epilogue == SM_EPI_GELU || g->epilogue == SM_EPI_RELU ||
+                   g->epilogue == SM_EPI_RESIDUAL || g->epilogue == SM_EPI_PATCH, "sm_gemm_w16: unsupported epilogue");
+    int ex = 0;
+    SM_REQUIRE(g->w_scale > 0.f && frexpf(g->w_scale, &ex) == 0.5f, "sm_gemm_w16: w_scale must be the weight tensor's 2^-s");
+    if (out_f16x2)
+        SM_REQUIRE(g->N % 8 == 0 && g->ldc % 8 == 0 && (g->epilogue == SM_EPI_BIAS || g->epilogue == SM_EPI_GELU ||
+                                                      g->epilogue == SM_EPI_RELU) && !(g->split_k > 1),
+                   "sm_gemm_w16: F16X2 output needs N %% 8 == 0 and a BIAS/GELU/RELU epilogue");
+    if (g->epilogue == SM_EPI_RESIDUAL) SM_REQUIRE(g->R && g->ldr % 4 == 0, "sm_gemm_w16: residual needs R, ldr %% 4 == 0");
+    if (g->epilogue == SM_EPI_PATCH) SM_REQUIRE(g->R && g->patch_n > 0, "sm_gemm_w16: PATCH needs R/patch_n");
+    if (g->alt_from_n > 0) SM_REQUIRE(g->A_alt && g->alt_from_n % 256 == 0, "sm_gemm_w16: bad A_alt (multiple of 256)");
+    if (g->split_k > 1)
+        SM_REQUIRE(g->epilogue == SM_EPI_BIAS && !g->bias && (g->K / 32) % g->split_k == 0, "sm_gemm_w16: bad split_k");
+    sm_gemm_args a = *g;
+    if (out_f16x2) a.patch_n = -1;
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0: return sm::launch_gemm_w<256, 128, 16, 3, 4, 2, 4>(a, st);
+        case 1: return sm::launch_gemm_w<256, 128, 32, 2, 4, 4, 4>(a, st);
+        case 2: return sm::launch_gemm_w<128, 128, 32, 2, 2, 4, 4>(a, st);
+        case 3: return sm::launch_gemm_w<128, 128, 16, 3, 2, 2, 3>(a, st);
+        case 4: return sm::launch_gemm_w<64, 64, 32, 3, 2, 2, 3>(a, st);
+        case 6: return sm::launch_gemm_w<256, 128, 32, 2, 4, 2, 2>(a, st);
+        case 7: return sm::launch_gemm_w<128, 64, 32, 2, 2, 2, 3>(a, st);
+        case 8: return sm::launch_gemm_w<128, 128, 16, 3, 2, 4, 6>(a, st);
+    }
+    sm::set_error("sm_gemm_w16_tile: unknown variant %d", variant);
+    return SM_EINVAL;
+}
+
+extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
+    if (!g) return -1;
+    static const int forced = getenv("SM_W16_VARIANT") ? atoi(getenv("SM_W16_VARIANT")) : -1;  // tuning knob (results unchanged)
+    const long nb = g->split_k > 1 ? g->split_k : 1;
+    const long wg256 = (long)((g->M + 255) / 256) * ((g->N + 127) / 128) * nb;
+    const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
+    if (forced >= 0 && wg128 >= 256) return forced;
+    if (wg256 >= 256) return 0;
+    if (wg128 >= 256) return 2;
+    return 4;
+}
+
+extern "C" int sm_gemm_w16(const sm_gemm_args* g, int out_f16x2, void* stream) {
+    const int v = sm_gemm_w16_pick(g);
+    if (v < 0) { sm::set_error("sm_gemm_w16: null arguments"); return SM_EINVAL; }
+    return sm_gemm_w16_tile(g, out_f16x2, v, stream);
+}

@@ -22,7 +22,7 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("batch", C.c_int32), ("epilogue", C.c_int32), ("alt_from_n", C.c_int32), ("split_k", C.c_int32),
-                ("patch_n", C.c_int32), ("ln_gamma", fp), ("ln_beta", fp), ("ln_eps", C.c_float)]
+                ("patch_n", C.c_int32), ("ln_gamma", fp), ("ln_beta", fp), ("ln_eps", C.c_float), ("w_scale", C.c_float)]
 
 
 class RowMap(C.Structure):
@@ -108,6 +108,10 @@ SYMBOLS = {
     "sm_gemm_f16x2_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, C.c_int, fp]),
     "sm_gemm_f16x2": (C.c_int, [C.POINTER(GemmArgs), C.c_int, fp]),
     "sm_gemm_f16x2_pick_tile": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sm_split_w16": (C.c_int, [fp, C.c_int64, fp, C.c_int64, C.c_int64, C.c_int32, C.c_float, fp]),
+    "sm_gemm_w16_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, fp]),
+    "sm_gemm_w16": (C.c_int, [C.POINTER(GemmArgs), C.c_int, fp]),
+    "sm_gemm_w16_pick": (C.c_int, [C.POINTER(GemmArgs)]),
     "sm_im2col_patches_f16x2": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_upsample2x_tokens_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),

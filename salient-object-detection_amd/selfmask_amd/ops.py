@@ -120,6 +120,58 @@ def gemm_f16x2(a_split: torch.Tensor, w_split: torch.Tensor, bias=None, epilogue
     return (res, xn if batched else xn[0]) if ln is not None else res
 
 
+def w16_scale_exponent(w: torch.Tensor) -> int:
+    """s such that max|w| * 2^s lies in [2^13, 2^14): the per-tensor scaling of the W16 weight format."""
+    import math
+    m = float(w.detach().abs().max())
+    if not math.isfinite(m):
+        raise ValueError("weight tensor holds non-finite values")
+    if m == 0.0:
+        return 0
+    return 13 - math.floor(math.log2(m))
+
+
+def split_w16(w: torch.Tensor):
+    """fp32 weight (rows, K) -> (W16 tensor, w_scale = 2^-s): scaled hi / UNSCALED lo halves (gemm_w16.hip)."""
+    _dev(w)
+    w2 = w.reshape(w.shape[0], -1).contiguous()
+    s = w16_scale_exponent(w2)
+    out = torch.empty_like(w2)
+    N.check(N.load().sm_split_w16(w2.data_ptr(), w2.stride(0), out.data_ptr(), out.stride(0), w2.shape[0], w2.shape[1],
+                                  float(2.0 ** s), _stream()), "sm_split_w16")
+    return out, float(2.0 ** -s)
+
+
+def gemm_w16(a_split: torch.Tensor, w16: torch.Tensor, w_scale: float, bias=None, epilogue: int = N.EPI_BIAS, residual=None,
+             variant: Optional[int] = None, out=None, out_f16x2: bool = False, split_k: int = 1, a_alt=None, alt_from_n: int = 0,
+             patch_n: int = 0):
+    """C = epilogue(A W^T + bias), A in F16X2, W in W16 (split_w16); single-accumulator kernel.  variant None = the
+    library's pick for the shape.  Test / tuning entry: the forward drives the kernel from C."""
+    _dev(a_split, w16, bias, residual, a_alt)
+    M, K = a_split.shape
+    Nn = w16.shape[0]
+    c = out if out is not None else torch.empty((max(1, split_k), M, Nn), device=a_split.device, dtype=torch.float32)
+    c3 = c if c.dim() == 3 else c.unsqueeze(0)
+    g = N.GemmArgs()
+    g.A, g.W, g.bias, g.C = a_split.data_ptr(), w16.data_ptr(), _ptr(bias), c3.data_ptr()
+    g.strideC = c3.stride(0)
+    g.M, g.N, g.K = M, Nn, K
+    g.lda, g.ldw, g.ldc = a_split.stride(0), w16.stride(0), c3.stride(1)
+    g.batch, g.epilogue, g.split_k, g.w_scale = 1, epilogue, split_k if split_k > 1 else 0, w_scale
+    if a_alt is not None:
+        g.A_alt, g.alt_from_n = a_alt.data_ptr(), alt_from_n
+    if residual is not None:
+        g.R, g.ldr = residual.data_ptr(), residual.stride(0)
+    if epilogue == N.EPI_PATCH:
+        g.patch_n = patch_n
+    lib = N.load()
+    if variant is None:
+        N.check(lib.sm_gemm_w16(g, 1 if out_f16x2 else 0, _stream()), "sm_gemm_w16")
+    else:
+        N.check(lib.sm_gemm_w16_tile(g, 1 if out_f16x2 else 0, variant, _stream()), "sm_gemm_w16_tile")
+    return c if (out is not None or split_k > 1) else c[0]
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
               add: Optional[torch.Tensor] = None, in_map=(0, 0, 0), out_map=(0, 0, 0), rows: Optional[int] = None,
               out_rows: Optional[int] = None):

@@ -1,0 +1,107 @@
+"""The single-accumulator weight GEMM (W16 weights, F16X2 activations; gemm_w16.hip) through the C ABI against fp64:
+every tile variant, epilogue and output format, ragged M / N, split-K, the second A operand, the patch-embed row map,
+weight tensors with outliers / tiny values (the per-tensor power-of-two scaling), and agreement with the two-accumulator
+kernel it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from selfmask_amd import ops, _native as N  # noqa: E402
+
+DEV = "cuda:0"
+VARIANTS = [0, 1, 2, 3, 4, 6, 7, 8]
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _ref(a, w, b, epi, r):
+    y = a.double() @ w.double().T + (b.double() if b is not None else 0.0)
+    if epi == N.EPI_GELU:
+        y = F.gelu(y)
+    elif epi == N.EPI_RELU:
+        y = F.relu(y)
+    elif epi == N.EPI_RESIDUAL:
+        y = y + r.double()
+    return y
+
+
+def test_w16_format_round_trip():
+    w = _rand(50, 384, seed=1, scale=0.02)
+    w[3, 7] = 1.9          # outlier sets the scale
+    w[5, :8] = 1e-6        # tiny weights: lo becomes subnormal, absolute error stays ~2^-39 of the maximum
+    t, ws = ops.split_w16(w.to(DEV))
+    h = t.view(torch.float16).reshape(50, 384 // 8, 2, 8).double().cpu()
+    back = (h[:, :, 0, :] + h[:, :, 1, :]).reshape(50, 384) * ws
+    assert ws == 2.0 ** -13 and h[:, :, 0, :].abs().max() < 2 ** 14
+    assert ((back - w.double()).abs() <= w.double().abs() * 2.0 ** -21 + 1.9 * 2.0 ** -36).all()
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("M,Nn,K,epi,osplit", [
+    (197 * 3, 384, 384, N.EPI_RESIDUAL, False),   # proj-like, ragged M
+    (197 * 3, 1536, 384, N.EPI_GELU, True),       # fc1: GELU + F16X2 output
+    (300, 384, 1536, N.EPI_RESIDUAL, False),      # fc2: long K
+    (130, 1152, 384, N.EPI_BIAS, True),           # qkv, F16X2 output
+    (61, 200, 64, N.EPI_RELU, False),             # N not a multiple of any tile, short K
+    (20, 384, 384, N.EPI_BIAS, False),            # one partial tile
+    (1000, 384, 768, N.EPI_BIAS, False),          # several 256-row tiles
+])
+def test_variants_epilogues_formats(variant, M, Nn, K, epi, osplit):
+    a, w, b = _rand(M, K, seed=2), _rand(Nn, K, seed=3, scale=0.05), _rand(Nn, seed=4)
+    r = _rand(M, Nn, seed=5) if epi == N.EPI_RESIDUAL else None
+    w16, ws = ops.split_w16(w.to(DEV))
+    c = ops.gemm_w16(ops.split_f16x2(a.to(DEV)), w16, ws, b.to(DEV), epilogue=epi,
+                     residual=None if r is None else r.to(DEV), variant=variant, out_f16x2=osplit)
+    got = ops.unsplit_f16x2(c) if osplit else c
+    ref = _ref(a, w, b, epi, r)
+    err = (got.double().cpu() - ref).abs().max().item()
+    assert err <= 4e-6 * max(1.0, ref.abs().max().item()), err  # fp32-grade (a torch fp32 GEMM is at 2-7e-6 here)
+
+
+@pytest.mark.parametrize("variant", [0, 2, 4])
+def test_split_k_second_operand_and_patch_rows(variant):
+    # split-K: raw partial sums per slice, no bias
+    a, w = _rand(140, 1536, seed=6), _rand(384, 1536, seed=7, scale=0.03)
+    w16, ws = ops.split_w16(w.to(DEV))
+    parts = ops.gemm_w16(ops.split_f16x2(a.to(DEV)), w16, ws, None, variant=variant, split_k=4)
+    ref = a.double() @ w.double().T
+    assert (parts.double().sum(0).cpu() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    # second A operand for output columns >= 768 (decoder self-attention q|k from tgt+pos, v from tgt)
+    a1, a2, w = _rand(90, 384, seed=8), _rand(90, 384, seed=9), _rand(1152, 384, seed=10, scale=0.05)
+    w16, ws = ops.split_w16(w.to(DEV))
+    c = ops.gemm_w16(ops.split_f16x2(a1.to(DEV)), w16, ws, None, variant=variant, a_alt=ops.split_f16x2(a2.to(DEV)),
+                     alt_from_n=768)
+    ref = torch.cat([a1.double() @ w[:768].double().T, a2.double() @ w[768:].double().T], 1)
+    assert (c.double().cpu() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    # patch-embed epilogue: row m of image i goes to token row i*(n+1)+1+m%n, plus pos_embed[1 + m%n]
+    n, B = 49, 3
+    cols, wp, bp, pos = _rand(B * n, 192, seed=11), _rand(384, 192, seed=12, scale=0.05), _rand(384, seed=13), _rand(n + 1, 384, seed=14)
+    w16, ws = ops.split_w16(wp.to(DEV))
+    X = torch.zeros(B * (n + 1), 384, device=DEV)
+    ops.gemm_w16(ops.split_f16x2(cols.to(DEV)), w16, ws, bp.to(DEV), epilogue=N.EPI_PATCH, residual=pos.to(DEV),
+                 variant=variant, out=X, patch_n=n)
+    ref = (cols.double() @ wp.double().T + bp.double()).reshape(B, n, 384) + pos[1:].double()
+    got = X.reshape(B, n + 1, 384)[:, 1:].double().cpu()
+    assert (got - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert X.reshape(B, n + 1, 384)[:, 0].abs().max().item() == 0.0  # cls rows untouched
+
+
+def test_weight_outliers_and_agreement_with_two_accumulator_kernel():
+    """A weight tensor whose maximum is 100x its typical value (the scale follows the maximum) still gives fp32-grade
+    results, and the two kernels agree to the rounding of their different accumulation orders."""
+    a, w, b = _rand(512, 1536, seed=20).clamp_min(0) * 1.5, _rand(384, 1536, seed=21, scale=0.02), _rand(384, seed=22)
+    w[0, 0], w[17, 100] = 2.5, -3.0
+    a_s = ops.split_f16x2(a.to(DEV))
+    w16, ws = ops.split_w16(w.to(DEV))
+    c1 = ops.gemm_w16(a_s, w16, ws, b.to(DEV)).double().cpu()
+    c2 = ops.gemm_f16x2(a_s, ops.split_f16x2(w.to(DEV)), b.to(DEV)).double().cpu()
+    ref = _ref(a, w, b, N.EPI_BIAS, None)
+    ref32 = (a @ w.T + b).double()
+    e1, e2, e32 = [(x - ref).abs().max().item() for x in (c1, c2, ref32)]
+    print(f"\nK=1536 outlier weights: w16 {e1:.2e}  f16x2 {e2:.2e}  torch-fp32 {e32:.2e}  (max|ref| {ref.abs().max():.1f})")
+    assert e1 <= 4e-6 * ref.abs().max().item() and e1 <= 3.0 * max(e2, e32)
