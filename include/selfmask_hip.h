@@ -114,6 +114,7 @@ int sm_split_w16(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, i
 int sm_gemm_w16_tile(const sm_gemm_args* args, int out_f16x2, int variant, void* stream);
 int sm_gemm_w16(const sm_gemm_args* args, int out_f16x2, void* stream);
 int sm_gemm_w16_pick(const sm_gemm_args* args); /* the variant sm_gemm_w16 launches for this shape */
+const char* sm_gemm_w16_variant_name(int variant); /* kernel instantiation name as rocprofv3 prints it, or NULL */
 
 /* y = LayerNorm(x) over the last dim (cols == 384): nn.LayerNorm at vision_transformer.py:165,169,299 (eps 1e-6)
  * and transformer_decoder.py:280,290,295,139 (eps 1e-5).  x/y row strides in elements; y may alias x. */
@@ -262,6 +263,7 @@ int sm_bilateral_solver_batch_f64(const sm_bilateral_args* args, int32_t n_image
 typedef struct sm_enc_layer {
     const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w,
         *fc2_b;
+    float qkv_s, proj_s, fc1_s, fc2_s; /* gemm_mode 2: 2^-s of the W16 copies (sm_split_w16); unused otherwise */
 } sm_enc_layer;
 
 typedef struct sm_dec_layer {
@@ -269,6 +271,7 @@ typedef struct sm_dec_layer {
     const float *ca_in_w, *ca_in_b, *ca_out_w, *ca_out_b; /* multihead_attn.*                                     */
     const float *lin1_w, *lin1_b, *lin2_w, *lin2_b;
     const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+    float sa_in_s, sa_out_s, ca_in_s, ca_out_s, lin1_s, lin2_s; /* gemm_mode 2: 2^-s of the W16 copies */
 } sm_dec_layer;
 
 /* Pointer table over the reference's 267-tensor state_dict; tensors stay owned by the caller. */
@@ -288,11 +291,14 @@ typedef struct sm_weights {
                            /*   cross-attention K/V of ALL layers is one GEMM over the encoder memory               */
     int32_t gemm_mode;     /* 0: exact-fp32 MFMA GEMMs; 1: split-operand f16 GEMMs - every GEMM weight pointer above
                               (patch_w, qkv/proj/fc1/fc2, decoder in/out projections, linear1/2, dec_kv_w, ffn0/1)
-                              then holds the F16X2 copy of the tensor (sm_split_f16x2), biases / norms stay fp32   */
+                              then holds the F16X2 copy of the tensor (sm_split_f16x2), biases / norms stay fp32;
+                              2: as 1 with the weights in the W16 format (sm_split_w16) and their 2^-s in the *_s
+                              fields: single-accumulator weight GEMMs (sm_gemm_w16), activations still F16X2         */
     int32_t patch;         /* 8 or 16 */
     int32_t pos_grid;      /* g0: trained grid side (224/patch) */
     int32_t n_queries;
     int32_t n_dec_layers;
+    float patch_s, ffn0_s, ffn1_s, dec_kv_s; /* gemm_mode 2: 2^-s of patch_w, ffn0_w, ffn1_w, dec_kv_w */
 } sm_weights;
 
 typedef struct sm_forward_io {

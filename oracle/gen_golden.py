@@ -125,6 +125,35 @@ def gen_forward():
               f"-> {os.path.getsize(fp) / 1e6:.2f} MB")
 
 
+def gen_forward3d():
+    """The 3-D output path (return_intermediate=False, use_binary_classifier=False; maskformer.py:219-220,246-249):
+    un-sigmoided last-layer logits (B, nq, h, w) + features, from the real reference in fp32 and fp64."""
+    vits, mf = _import_reference()
+    torch.set_num_threads(N_THREADS)
+    patch, (B, Hh, Ww), wseed, style, xseed = 16, (2, 224, 224), 6, "calib", 1241
+    sd = synthetic_state_dict(wseed, style, patch_size=patch, use_binary_classifier=False)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    outs = {}
+    for dtype in (torch.float32, torch.float64):
+        model = mf.MaskFormer(n_queries=20, arch="vit_small", patch_size=patch, n_decoder_layers=6,
+                              return_intermediate=False, scale_factor=2, use_binary_classifier=False).eval()
+        ours = state_shapes(20, patch, 6, False)
+        assert list(model.state_dict().keys()) == list(ours.keys())
+        model.load_state_dict(sd, strict=True)
+        with torch.no_grad():
+            outs[dtype] = model.to(dtype)(x.to(dtype))
+        assert set(outs[dtype].keys()) == {"mask_pred", "features"}
+    o32, o64 = outs[torch.float32], outs[torch.float64]
+    err = (o32["mask_pred"].double() - o64["mask_pred"]).abs().max().item()
+    fp = os.path.join(GOLD, "forward3d_p16_224_calib.npz")
+    np.savez_compressed(fp, meta=np.array([patch, B, Hh, Ww, wseed, xseed, N_THREADS]), style=np.array(style),
+                        mask_pred=o32["mask_pred"].numpy(), mask_pred_f64=o64["mask_pred"].numpy(),
+                        features=o32["features"].numpy(), logit_absmax=np.array(o32["mask_pred"].abs().max().item()),
+                        f32_vs_f64_maxabs=np.array(err))
+    print(f"forward3d: shape={tuple(o32['mask_pred'].shape)} max|logit|={o32['mask_pred'].abs().max().item():.2f} "
+          f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
+
+
 def _metric_cases():
     """(pred, gt) pairs covering the branches of metrics/*.py (all-zero / all-one GT, empty prediction, ties)."""
     rng = np.random.Generator(np.random.PCG64(77))
@@ -236,6 +265,8 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if a.only in (None, "forward"):
         gen_forward()
+    if a.only in (None, "forward3d"):
+        gen_forward3d()
     if a.only in (None, "metrics"):
         gen_metrics()
     if a.only in (None, "bilateral"):

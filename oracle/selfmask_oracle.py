@@ -180,5 +180,17 @@ def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int = 16, n_lay
     }
 
 
+@torch.no_grad()
+def forward_3d(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int = 16, n_layers: int = 6,
+               scale_factor: int = 2) -> Dict[str, torch.Tensor]:
+    """MaskFormer.forward (maskformer.py:164-251), 3-D path (return_intermediate=False, use_binary_classifier=False):
+    the decoder returns only its last layer after ``decoder.norm`` (transformer_decoder.py:141-150), the mask einsum
+    is "bqn,bnhw->bqhw" with NO sigmoid (:219-220) and there is no objectness (:246-249)."""
+    tokens, grid = encoder_forward(x, sd, patch)
+    queries = decoder_forward(tokens, sd, n_layers)[:, -1]  # (B, nq, 384)
+    up = pixel_decoder(tokens, grid, scale_factor)
+    return {"mask_pred": torch.einsum("bqn,bnhw->bqhw", queries, up), "features": queries.mean(dim=1)}
+
+
 def cast_state(sd, dtype):
     return {k: v.to(dtype) for k, v in sd.items()}

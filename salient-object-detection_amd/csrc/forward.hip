@@ -102,24 +102,31 @@ static Ws carve(const Shape& s, float* base) {
 }
 
 struct Ctx {
-    bool S;  // split-operand GEMM mode
+    bool S;    // split-operand GEMM mode (activations that only feed GEMMs are F16X2)
+    bool W16;  // ... with the weights in the W16 format: weight GEMMs run the single-accumulator kernel (gemm_w16.hip)
     hipStream_t st;
 };
 
+// `ws` = the weight tensor's 2^-s (W16 mode; 0 = W is not a W16 weight: an activation operand, or another mode)
 static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s = false);
-// C = epilogue(A W^T + b); in split mode A and W are F16X2 and `out_s` asks for an F16X2 C
-static int linear(const Ctx& c, const float* A, int lda, const float* W, const float* b, float* C, int ldc, int64_t M, int N,
-                  int K, int epi, const float* R, int ldr, bool out_s = false) {
+// C = epilogue(A W^T + b); in split mode A and W are F16X2 / W16 and `out_s` asks for an F16X2 C
+static int linear(const Ctx& c, const float* A, int lda, const float* W, float ws, const float* b, float* C, int ldc, int64_t M,
+                  int N, int K, int epi, const float* R, int ldr, bool out_s = false) {
     sm_gemm_args g = {};
     g.A = A; g.W = W; g.bias = b; g.C = C; g.R = R;
     g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldr = ldr;
-    g.batch = 1; g.epilogue = epi;
+    g.batch = 1; g.epilogue = epi; g.w_scale = ws;
     return gemm(c, g, out_s);
 }
+static bool use_w16(const Ctx& c, const sm_gemm_args& g) { return c.W16 && g.w_scale > 0.f; }
 static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
     if (!g_timing) return std::string();
     char buf[64];
     int bm = 0, bn = 0, nst = 0;
+    if (use_w16(c, g)) {
+        const char* nm = sm_gemm_w16_variant_name(sm_gemm_w16_pick(&g));
+        return nm ? nm : "gemm_w16_kernel<?>";
+    }
     if (c.S) {
         sm_gemm_f16x2_pick_tile(&g, &bm, &bn, &nst);
         snprintf(buf, sizeof buf, "gemm_f16x2_kernel<%d, %d, %d, 2, %d, %d, 0>", bm, bn, nst, bn == 128 ? 4 : 2, bn == 128 ? 2 : 3);
@@ -131,6 +138,7 @@ static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
 }
 static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s) {
     TapScope tap(c.st, gemm_name(c, g), 2.0 * g.M * g.N * g.K * (g.batch > 0 ? g.batch : 1), 0.0);
+    if (use_w16(c, g)) return sm_gemm_w16(&g, out_s ? 1 : 0, c.st);
     return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
 }
 // split mode, N = 384: C = R + (A W^T + b) in place on the residual stream AND the next pre-norm of it (F16X2) in one
@@ -209,7 +217,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     const Shape s = make_shape(w, io->B, io->H, io->W);
     Ws ws = carve(s, wsbase);
     const int D = SM_EMBED;
-    const Ctx c = {w->gemm_mode == 1, st};
+    const Ctx c = {w->gemm_mode >= 1, w->gemm_mode == 2, st};
     const bool S = c.S;
 
     // ---- tokens: patch embedding + cls + position (vision_transformer.py:269-281) ----------------------------
@@ -226,7 +234,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         sm_gemm_args g = {};
         g.A = cols; g.W = w->patch_w; g.bias = w->patch_b; g.C = ws.X; g.R = pos;
         g.M = (int)s.Mp; g.N = D; g.K = 3 * s.P * s.P; g.lda = g.K; g.ldw = g.K; g.ldc = D; g.ldr = D;
-        g.batch = 1; g.epilogue = SM_EPI_PATCH; g.patch_n = s.n;
+        g.batch = 1; g.epilogue = SM_EPI_PATCH; g.patch_n = s.n; g.w_scale = w->patch_s;
         TRY(gemm(c, g));
     }
 
@@ -236,14 +244,14 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // SM_FUSED_LN (tuning knob, default 0): 1 = proj and fc2, 2 = proj only.  Measured with three batches in flight:
     // 17.3k images/s against 18.0k unfused - the full-row tile needs 112 KiB of LDS (one workgroup per CU, 197 of them).
     static const int fused_ln_env = getenv("SM_FUSED_LN") ? atoi(getenv("SM_FUSED_LN")) : 0;
-    const bool fuse_proj = S && fused_ln_env >= 1, fuse_fc2 = S && fused_ln_env == 1;
+    const bool fuse_proj = S && !c.W16 && fused_ln_env >= 1, fuse_fc2 = S && !c.W16 && fused_ln_env == 1;
     LnOpt xs;
     xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
     if (fuse_fc2) TRY(ln(c, ws.X, w->enc[0].norm1_w, w->enc[0].norm1_b, nullptr, s.M, 1e-6f, xs));
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
         if (!fuse_fc2) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
-        TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
+        TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_s, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
         sm_attn_args a = {};
         a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
         a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
@@ -253,15 +261,15 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         if (fuse_proj) {
             TRY(linear_residual_ln(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, s.M, D, e.norm2_w, e.norm2_b, 1e-6f, ws.Xn));
         } else {
-            TRY(linear(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
+            TRY(linear(c, ws.AO, D, e.proj_w, e.proj_s, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
             TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         }
-        TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
+        TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_s, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
         if (fuse_fc2 && i + 1 < SM_ENC_DEPTH) {
             const sm_enc_layer& nx = w->enc[i + 1];
             TRY(linear_residual_ln(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, s.M, SM_MLP, nx.norm1_w, nx.norm1_b, 1e-6f, ws.Xn));
         } else {
-            TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D));
+            TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_s, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D));
         }
     }
     // final norm on the last layer only (the other 11 per-layer norms of :299 are dead work when
@@ -291,7 +299,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // cross-attention keys/values of every layer depend only on the encoder memory: one large GEMM
     // (B*n x 384) x (384 x L*768) instead of L small ones on the critical chain
     const int KVW = s.L * 2 * D;
-    TRY(linear(c, tok_a, D, w->dec_kv_w, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0, S));
+    TRY(linear(c, tok_a, D, w->dec_kv_w, w->dec_kv_s, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0, S));
     for (int l = 0; l < s.L; ++l) {
         const sm_dec_layer& d = w->dec[l];
         const float* tgt_a = S ? ws.TGTs : ws.TGT;  // GEMM-operand view of tgt (TGT / T2 swap roles every layer)
@@ -300,6 +308,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
             sm_gemm_args g = {};
             g.A = ws.TGTQ; g.A_alt = tgt_a; g.alt_from_n = 2 * D; g.W = d.sa_in_w; g.bias = d.sa_in_b; g.C = ws.QK;
             g.M = (int)s.Md; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * D; g.batch = 1; g.epilogue = SM_EPI_BIAS;
+            g.w_scale = d.sa_in_s;
             TRY(gemm(c, g, S));
         }
         sm_attn_args a = {};
@@ -308,32 +317,33 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
         TRY(attn(c, a));
-        TRY(linear(c, ws.AOd, D, d.sa_out_w, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
+        TRY(linear(c, ws.AOd, D, d.sa_out_w, d.sa_out_s, d.sa_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
         {
             LnOpt o;  // norm1 -> tgt (fp32: residual of the next block) + tgt + query_pos (cross-attention query operand)
             o.y2 = ws.TGTQ; o.y2_s = S; o.add = qpos; o.add_rows = s.nq;
             TRY(ln(c, ws.T2, d.norm1_w, d.norm1_b, ws.TGT, s.Md, 1e-5f, o));
         }
         // cross-attention: q = tgt + query_pos, k = v = memory (pos = None)
-        TRY(linear(c, ws.TGTQ, D, d.ca_in_w, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, S));
+        TRY(linear(c, ws.TGTQ, D, d.ca_in_w, d.ca_in_s, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, S));
         a = {};
         a.Q = ws.Qc; a.K = ws.KV + (int64_t)l * 2 * D; a.V = a.K + D; a.O = ws.AOd;
         a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * KVW; a.sKr = a.sVr = KVW;
         a.sOb = (int64_t)s.nq * D; a.sOr = D;
         a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
         TRY(attn(c, a));
-        TRY(linear(c, ws.AOd, D, d.ca_out_w, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
+        TRY(linear(c, ws.AOd, D, d.ca_out_w, d.ca_out_s, d.ca_out_b, ws.T2, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
         {
             LnOpt o;  // norm2 -> tgt (residual of the FFN) (+ F16X2 copy: operand of linear1)
             o.ys = S ? ws.TGTs : nullptr;
             TRY(ln(c, ws.T2, d.norm2_w, d.norm2_b, ws.TGT, s.Md, 1e-5f, o));
         }
         // FFN: linear2 (K = 1536, only M/64 x 6 tiles) is split 4-way along K; norm3 sums the slices + bias + residual
-        TRY(linear(c, tgt_a, D, d.lin1_w, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, S));
+        TRY(linear(c, tgt_a, D, d.lin1_w, d.lin1_s, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, S));
         {
             sm_gemm_args g = {};
             g.A = ws.HIDd; g.W = d.lin2_w; g.C = ws.PART; g.M = (int)s.Md; g.N = D; g.K = SM_MLP; g.lda = SM_MLP;
             g.ldw = SM_MLP; g.ldc = D; g.batch = 1; g.epilogue = SM_EPI_BIAS; g.split_k = 4; g.strideC = s.Md * D;
+            g.w_scale = d.lin2_s;
             TRY(gemm(c, g));
         }
         {
@@ -377,8 +387,8 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         g.batch = s.B; g.epilogue = SM_EPI_SIGMOID2;
         TRY(gemm(c, g));
     }
-    TRY(linear(c, qd_a, D, w->ffn0_w, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
-    TRY(linear(c, ws.O1, D, w->ffn1_w, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0));
+    TRY(linear(c, qd_a, D, w->ffn0_w, w->ffn0_s, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
+    TRY(linear(c, ws.O1, D, w->ffn1_w, w->ffn1_s, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0));
     TRY(sm_rowdot_sigmoid_f32(ws.O2, w->ffn2_w, w->ffn2_b, io->objectness, (int)s.Mo, st));
     return SM_OK;
 }
@@ -386,13 +396,13 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
 static int validate(const sm_weights* w, const sm_forward_io* io) {
     SM_REQUIRE(w && io, "sm_maskformer_forward: null arguments");
     SM_REQUIRE(w->patch == 8 || w->patch == 16, "sm_maskformer_forward: patch=%d (8 or 16)", w->patch);
-    SM_REQUIRE(w->gemm_mode == 0 || w->gemm_mode == 1, "sm_maskformer_forward: gemm_mode=%d (0 or 1)", w->gemm_mode);
+    SM_REQUIRE(w->gemm_mode >= 0 && w->gemm_mode <= 2, "sm_maskformer_forward: gemm_mode=%d (0, 1 or 2)", w->gemm_mode);
     SM_REQUIRE(w->n_dec_layers >= 1 && w->n_dec_layers <= SM_MAX_DEC_LAYERS, "sm_maskformer_forward: n_dec_layers=%d",
                w->n_dec_layers);
     SM_REQUIRE(w->n_queries >= 1 && w->pos_grid >= 1, "sm_maskformer_forward: bad n_queries/pos_grid");
     SM_REQUIRE(w->dec_kv_w && w->dec_kv_b, "sm_maskformer_forward: dec_kv_w/dec_kv_b (packed cross-attention K/V) missing");
     SM_REQUIRE(io->x && io->B > 0 && io->H > 0 && io->W > 0, "sm_maskformer_forward: bad input shape");
-    if (w->gemm_mode == 1) {
+    if (w->gemm_mode >= 1) {
         const int gh = (io->H + w->patch - 1) / w->patch, gw = (io->W + w->patch - 1) / w->patch;
         SM_REQUIRE((4 * gh * gw) % 4 == 0, "sm_maskformer_forward: mask width must be a multiple of 4");
     }

@@ -366,16 +366,33 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
     return SM_EINVAL;
 }
 
+extern "C" const char* sm_gemm_w16_variant_name(int variant) {
+    switch (variant) {
+        case 0: return "gemm_w16_kernel<256, 128, 16, 3, 4, 2, 4>";
+        case 1: return "gemm_w16_kernel<256, 128, 32, 2, 4, 4, 4>";
+        case 2: return "gemm_w16_kernel<128, 128, 32, 2, 2, 4, 4>";
+        case 3: return "gemm_w16_kernel<128, 128, 16, 3, 2, 2, 3>";
+        case 4: return "gemm_w16_kernel<64, 64, 32, 3, 2, 2, 3>";
+        case 6: return "gemm_w16_kernel<256, 128, 32, 2, 4, 2, 2>";
+        case 7: return "gemm_w16_kernel<128, 64, 32, 2, 2, 2, 3>";
+        case 8: return "gemm_w16_kernel<128, 128, 16, 3, 2, 4, 6>";
+    }
+    return nullptr;
+}
+
+// Measured on MI355X alone on the GPU (scripts/gemm_w16_sweep.py, M = 12608): N = 384 outputs (proj, fc2) are fastest as
+// 128 x 64 tiles (three workgroups per CU), wider ones as 128 x 128 with eight waves; 256 x 128 tiles - 3/4 of the staged
+// bytes per MFMA - are NOT faster (+-3 %): the kernel is not bound by staging bandwidth.
 extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     if (!g) return -1;
-    static const int forced = getenv("SM_W16_VARIANT") ? atoi(getenv("SM_W16_VARIANT")) : -1;  // tuning knob (results unchanged)
+    static const int forced_w = getenv("SM_W16_VARIANT_WIDE") ? atoi(getenv("SM_W16_VARIANT_WIDE")) : -1;    // tuning knobs
+    static const int forced_n = getenv("SM_W16_VARIANT_NARROW") ? atoi(getenv("SM_W16_VARIANT_NARROW")) : -1;  // (same results)
     const long nb = g->split_k > 1 ? g->split_k : 1;
-    const long wg256 = (long)((g->M + 255) / 256) * ((g->N + 127) / 128) * nb;
+    const long wg128x64 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * nb;
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
-    if (forced >= 0 && wg128 >= 256) return forced;
-    if (wg256 >= 256) return 0;
-    if (wg128 >= 256) return 2;
-    return 4;
+    if (wg128x64 < 512) return 4;
+    if (g->N <= 384 || wg128 < 256) return forced_n >= 0 ? forced_n : 7;
+    return forced_w >= 0 ? forced_w : 2;
 }
 
 extern "C" int sm_gemm_w16(const sm_gemm_args* g, int out_f16x2, void* stream) {

@@ -52,11 +52,12 @@ DEC_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b"
 
 
 class EncLayer(C.Structure):
-    _fields_ = [(n, fp) for n in ENC_FIELDS]
+    _fields_ = [(n, fp) for n in ENC_FIELDS] + [(n, C.c_float) for n in ("qkv_s", "proj_s", "fc1_s", "fc2_s")]
 
 
 class DecLayer(C.Structure):
-    _fields_ = [(n, fp) for n in DEC_FIELDS]
+    _fields_ = [(n, fp) for n in DEC_FIELDS] + [(n, C.c_float) for n in ("sa_in_s", "sa_out_s", "ca_in_s", "ca_out_s",
+                                                                          "lin1_s", "lin2_s")]
 
 
 class Weights(C.Structure):
@@ -65,7 +66,8 @@ class Weights(C.Structure):
                 ("dec", DecLayer * MAX_DEC_LAYERS), ("dec_norm_w", fp), ("dec_norm_b", fp),
                 ("ffn0_w", fp), ("ffn0_b", fp), ("ffn1_w", fp), ("ffn1_b", fp), ("ffn2_w", fp), ("ffn2_b", fp),
                 ("dec_kv_w", fp), ("dec_kv_b", fp), ("gemm_mode", C.c_int32), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
-                ("n_dec_layers", C.c_int32)]
+                ("n_dec_layers", C.c_int32), ("patch_s", C.c_float), ("ffn0_s", C.c_float), ("ffn1_s", C.c_float),
+                ("dec_kv_s", C.c_float)]
 
 
 class ForwardIO(C.Structure):
@@ -112,6 +114,7 @@ SYMBOLS = {
     "sm_gemm_w16_tile": (C.c_int, [C.POINTER(GemmArgs), C.c_int, C.c_int, fp]),
     "sm_gemm_w16": (C.c_int, [C.POINTER(GemmArgs), C.c_int, fp]),
     "sm_gemm_w16_pick": (C.c_int, [C.POINTER(GemmArgs)]),
+    "sm_gemm_w16_variant_name": (C.c_char_p, [C.c_int]),
     "sm_im2col_patches_f16x2": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_upsample2x_tokens_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_layernorm_f32": (C.c_int, [fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, fp]),

@@ -118,8 +118,9 @@ class MaskFormer(nn.Module):
             gemm_mode: Optional[str] = None,
     ):
         """Same arguments as the reference.  ``gemm_mode`` (extra, keyword-only) picks the GEMM back end:
-        "f16x2" (default; split-operand f16 matrix cores, fp32-grade results) or "fp32" (exact fp32 MFMA).
-        The environment variable SM_GEMM_MODE overrides the default."""
+        "w16" (default; f16 matrix cores, split operands, weights pre-scaled per tensor so every weight GEMM sums in ONE
+        fp32 accumulator - fp32-grade results), "f16x2" (the same arithmetic with two accumulators and unscaled weights)
+        or "fp32" (exact fp32 MFMA).  The environment variable SM_GEMM_MODE overrides the default."""
         super().__init__()
         if arch != "vit_small":
             raise NotImplementedError(f"arch={arch!r}: only the DINO ViT-S encoder is on the MI355X hot path "
@@ -151,9 +152,9 @@ class MaskFormer(nn.Module):
         self.n_queries = n_queries
         self.n_decoder_layers = n_decoder_layers
         import os
-        self.gemm_mode = gemm_mode or os.environ.get("SM_GEMM_MODE", "f16x2")
-        if self.gemm_mode not in ("f16x2", "fp32"):
-            raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'f16x2' or 'fp32'")
+        self.gemm_mode = gemm_mode or os.environ.get("SM_GEMM_MODE", "w16")
+        if self.gemm_mode not in ("w16", "f16x2", "fp32"):
+            raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'w16', 'f16x2' or 'fp32'")
         self._table = None       # (Weights struct, key) cache
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
         self.weights_generation = 0  # bumped whenever the packed weights are dropped: captured hipGraphs hold raw
@@ -188,7 +189,8 @@ class MaskFormer(nn.Module):
                                    f"(got {p.device}, {p.dtype}); the product path has no CPU fallback")
         w = N.Weights()
         e = self.encoder
-        split = self.gemm_mode == "f16x2"
+        split = self.gemm_mode in ("f16x2", "w16")
+        w16 = self.gemm_mode == "w16"
         packed = {}
         d = N.EMBED
         # cross-attention K/V projections of all layers packed into one (L*768, 384) weight: rows [384:1152) of each
@@ -196,48 +198,54 @@ class MaskFormer(nn.Module):
         packed["dec_kv_w"] = torch.cat([lay.multihead_attn.in_proj_weight.detach()[d:] for lay in self.decoder.layers]).contiguous()
         packed["dec_kv_b"] = torch.cat([lay.multihead_attn.in_proj_bias.detach()[d:] for lay in self.decoder.layers]).contiguous()
 
-        def gw(name: str, t: torch.Tensor) -> int:
-            """pointer of a GEMM weight: the tensor itself (fp32 mode) or its F16X2 copy (split mode)"""
+        def gws(name: str, t: torch.Tensor):
+            """(pointer, 2^-s) of a GEMM weight: the tensor itself (fp32 mode), its F16X2 copy (f16x2 mode) or its W16
+            copy with the per-tensor power-of-two scale (w16 mode)"""
             t2 = t.detach().reshape(t.shape[0], -1)
             if not split:
-                return t2.data_ptr()
+                return t2.data_ptr(), 0.0
             from . import ops
+            if w16:
+                packed["s:" + name], scale = ops.split_w16(t2.contiguous())
+                return packed["s:" + name].data_ptr(), scale
             packed["s:" + name] = ops.split_f16x2(t2.contiguous())
-            return packed["s:" + name].data_ptr()
+            return packed["s:" + name].data_ptr(), 0.0
 
         w.query_embed = self.query_embed.data_ptr()
         w.cls_token = e.cls_token.data_ptr()
         w.pos_embed = e.pos_embed.data_ptr()
-        w.patch_w = gw("patch_w", e.patch_embed.proj.weight)
+        w.patch_w, w.patch_s = gws("patch_w", e.patch_embed.proj.weight)
         w.patch_b = e.patch_embed.proj.bias.data_ptr()
         for i, blk in enumerate(e.blocks):
             L = w.enc[i]
             L.norm1_w, L.norm1_b = blk.norm1.weight.data_ptr(), blk.norm1.bias.data_ptr()
-            L.qkv_w, L.qkv_b = gw(f"enc{i}.qkv", blk.attn.qkv.weight), blk.attn.qkv.bias.data_ptr()
-            L.proj_w, L.proj_b = gw(f"enc{i}.proj", blk.attn.proj.weight), blk.attn.proj.bias.data_ptr()
+            (L.qkv_w, L.qkv_s), L.qkv_b = gws(f"enc{i}.qkv", blk.attn.qkv.weight), blk.attn.qkv.bias.data_ptr()
+            (L.proj_w, L.proj_s), L.proj_b = gws(f"enc{i}.proj", blk.attn.proj.weight), blk.attn.proj.bias.data_ptr()
             L.norm2_w, L.norm2_b = blk.norm2.weight.data_ptr(), blk.norm2.bias.data_ptr()
-            L.fc1_w, L.fc1_b = gw(f"enc{i}.fc1", blk.mlp.fc1.weight), blk.mlp.fc1.bias.data_ptr()
-            L.fc2_w, L.fc2_b = gw(f"enc{i}.fc2", blk.mlp.fc2.weight), blk.mlp.fc2.bias.data_ptr()
+            (L.fc1_w, L.fc1_s), L.fc1_b = gws(f"enc{i}.fc1", blk.mlp.fc1.weight), blk.mlp.fc1.bias.data_ptr()
+            (L.fc2_w, L.fc2_s), L.fc2_b = gws(f"enc{i}.fc2", blk.mlp.fc2.weight), blk.mlp.fc2.bias.data_ptr()
         w.enc_norm_w, w.enc_norm_b = e.norm.weight.data_ptr(), e.norm.bias.data_ptr()
         for j, lay in enumerate(self.decoder.layers):
             L = w.dec[j]
-            L.sa_in_w, L.sa_in_b = gw(f"dec{j}.sa_in", lay.self_attn.in_proj_weight), lay.self_attn.in_proj_bias.data_ptr()
-            L.sa_out_w, L.sa_out_b = gw(f"dec{j}.sa_out", lay.self_attn.out_proj.weight), lay.self_attn.out_proj.bias.data_ptr()
-            L.ca_in_w, L.ca_in_b = gw(f"dec{j}.ca_in", lay.multihead_attn.in_proj_weight), lay.multihead_attn.in_proj_bias.data_ptr()
-            L.ca_out_w = gw(f"dec{j}.ca_out", lay.multihead_attn.out_proj.weight)
+            (L.sa_in_w, L.sa_in_s), L.sa_in_b = gws(f"dec{j}.sa_in", lay.self_attn.in_proj_weight), lay.self_attn.in_proj_bias.data_ptr()
+            (L.sa_out_w, L.sa_out_s), L.sa_out_b = gws(f"dec{j}.sa_out", lay.self_attn.out_proj.weight), lay.self_attn.out_proj.bias.data_ptr()
+            # only rows [0:384) (the query projection) of the cross-attention in_proj are used through this pointer;
+            # the K/V rows travel in dec_kv_w with their own scale
+            (L.ca_in_w, L.ca_in_s), L.ca_in_b = gws(f"dec{j}.ca_in", lay.multihead_attn.in_proj_weight[:d]), lay.multihead_attn.in_proj_bias.data_ptr()
+            L.ca_out_w, L.ca_out_s = gws(f"dec{j}.ca_out", lay.multihead_attn.out_proj.weight)
             L.ca_out_b = lay.multihead_attn.out_proj.bias.data_ptr()
-            L.lin1_w, L.lin1_b = gw(f"dec{j}.lin1", lay.linear1.weight), lay.linear1.bias.data_ptr()
-            L.lin2_w, L.lin2_b = gw(f"dec{j}.lin2", lay.linear2.weight), lay.linear2.bias.data_ptr()
+            (L.lin1_w, L.lin1_s), L.lin1_b = gws(f"dec{j}.lin1", lay.linear1.weight), lay.linear1.bias.data_ptr()
+            (L.lin2_w, L.lin2_s), L.lin2_b = gws(f"dec{j}.lin2", lay.linear2.weight), lay.linear2.bias.data_ptr()
             L.norm1_w, L.norm1_b = lay.norm1.weight.data_ptr(), lay.norm1.bias.data_ptr()
             L.norm2_w, L.norm2_b = lay.norm2.weight.data_ptr(), lay.norm2.bias.data_ptr()
             L.norm3_w, L.norm3_b = lay.norm3.weight.data_ptr(), lay.norm3.bias.data_ptr()
         w.dec_norm_w, w.dec_norm_b = self.decoder.norm.weight.data_ptr(), self.decoder.norm.bias.data_ptr()
         f = self.ffn.layers
-        w.ffn0_w, w.ffn0_b = gw("ffn0", f[0].weight), f[0].bias.data_ptr()
-        w.ffn1_w, w.ffn1_b = gw("ffn1", f[1].weight), f[1].bias.data_ptr()
+        (w.ffn0_w, w.ffn0_s), w.ffn0_b = gws("ffn0", f[0].weight), f[0].bias.data_ptr()
+        (w.ffn1_w, w.ffn1_s), w.ffn1_b = gws("ffn1", f[1].weight), f[1].bias.data_ptr()
         w.ffn2_w, w.ffn2_b = f[2].weight.data_ptr(), f[2].bias.data_ptr()
-        w.dec_kv_w, w.dec_kv_b = gw("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
-        w.gemm_mode = 1 if split else 0
+        (w.dec_kv_w, w.dec_kv_s), w.dec_kv_b = gws("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
+        w.gemm_mode = 2 if w16 else (1 if split else 0)
         self._packed = packed
         w.patch = e.patch_size
         w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))

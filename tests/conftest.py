@@ -4,7 +4,7 @@ import sys
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(REPO, "salient-object-detection_amd"), REPO):
+for p in (os.path.join(REPO, "salient-object-detection_amd"), REPO, os.path.join(REPO, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

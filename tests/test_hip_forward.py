@@ -11,26 +11,33 @@ pytestmark = pytest.mark.gpu
 
 from oracle import selfmask_oracle as O  # noqa: E402  (checker only)
 from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images  # noqa: E402
+import _ledger as ledger  # noqa: E402
 
 DEV = "cuda:0"
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(glob.glob(os.path.join(GOLD, "forward_*.npz")))
 
-# BASELINE.json north_star: "within 1e-4 max-abs on logits".  With unit decoder.norm gain the synthetic checkpoints
-# give |logit| up to 65 where the fp32 reference itself is 0.8-1.6e-4 from its own fp64 evaluation
-# (f32_vs_f64_maxabs in the fixtures), so the absolute gate is applied on the "calib" checkpoints (|logit| <= 16,
-# fp32 floor 2e-5) and scaled with the logit range elsewhere (1e-4 at |logit| = 16).
+# BASELINE.json north_star: "within 1e-4 max-abs on logits".  The gate, as asserted here:
+#   * fixtures whose fp32 reference is itself within 5e-5 of its own fp64 evaluation (the "calib" checkpoints,
+#     |logit| <= 16): |hip - ref32| <= 1e-4, flat;
+#   * the others (unit decoder.norm gain: |logit| up to 66, where the REFERENCE's fp32 result is 0.8-1.6e-4 away from
+#     its fp64 evaluation, f32_vs_f64_maxabs in the fixtures): |hip - ref64| <= |ref32 - ref64| - the HIP path must be
+#     at least as close to the fp64 truth as the reference's own fp32 arithmetic is, no slack - and therefore
+#     |hip - ref32| <= 2 |ref32 - ref64| by the triangle inequality.
+# Every case records |logit|max, hip-ref32, hip-ref64, ref32-ref64, the bound used, thresholded-pixel flips and
+# arg-max agreement in gpurun_out/parity_ledger.json (committed as profiles/r02_parity.json).
 ABS_TOL = 1e-4
+STRICT_BELOW = 5e-5
 
 
 def _tol(scale):
     return ABS_TOL * max(1.0, scale / 16.0)
 
 
-MODES = ["f16x2", "fp32"]  # split-operand f16 matrix cores (default) / exact fp32 MFMA
+MODES = ["w16", "f16x2", "fp32"]  # single-accumulator W16 weights (default) / two-accumulator split / exact fp32 MFMA
 
 
-def _model(patch, wseed, style, mode="f16x2"):
+def _model(patch, wseed, style, mode="w16"):
     m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True,
                    use_binary_classifier=True, gemm_mode=mode)
     m.load_state_dict(synthetic_state_dict(wseed, style, patch_size=patch), strict=True)
@@ -51,20 +58,32 @@ def test_forward_matches_reference_vectors(fp, mode):
     d32 = np.abs(logits - g["logits_last"]).max()
     d64 = np.abs(logits - g["logits_last_f64"]).max()
     ref64 = float(g["f32_vs_f64_maxabs"])
-    print(f"\n[{mode}] {os.path.basename(fp)}: |logit|max={scale:.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e} tol={tol:.1e}")
-    assert d32 <= tol
-    assert d64 <= max(2.0 * ref64, 0.5 * tol)  # as close to the fp64 truth as the fp32 reference is (x2 slack)
+    strict = ref64 <= STRICT_BELOW
+    print(f"\n[{mode}] {os.path.basename(fp)}: |logit|max={scale:.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e} "
+          f"rule={'strict 1e-4' if strict else 'hip-ref64 <= ref32-ref64'}")
+    obj_ref = g["objectness"][:, -1, :, 0]
+    obj = out["objectness"][:, -1, :, 0].cpu().numpy()
+    mp = out["mask_pred"][:, -1].cpu().numpy()
+    ref_bin = (1 / (1 + np.exp(-g["logits_last"].astype(np.float64)))) > 0.5
+    flips = float(((mp > 0.5) != ref_bin).mean())
+    ledger.record("forward_fixtures", f"{os.path.basename(fp)[8:-4]}|{mode}", {
+        "logit_absmax": scale, "hip_minus_ref32": float(d32), "hip_minus_ref64": float(d64), "ref32_minus_ref64": ref64,
+        "rule": "hip-ref32 <= 1e-4" if strict else "hip-ref64 <= ref32-ref64", "bound": ABS_TOL if strict else ref64,
+        "pixel_flips": flips, "argmax_objectness_equal": bool((obj.argmax(1) == obj_ref.argmax(1)).all()),
+        "objectness_maxabs": float(np.abs(out["objectness"].cpu().numpy() - g["objectness"]).max()),
+        "queries_maxabs": float(np.abs(out["queries"].cpu().numpy() - g["queries"]).max())})
+    if strict:
+        assert d32 <= ABS_TOL
+        assert d64 <= max(ref64, 0.5 * ABS_TOL)
+    else:
+        assert d64 <= ref64      # at least as close to the fp64 truth as the reference's fp32 result is
+        assert d32 <= 2.0 * ref64
     assert out["mask_pred"].shape == (B, 6, 20, 2 * int(g["grid"][0]), 2 * int(g["grid"][1]))
     assert np.abs(out["objectness"].cpu().numpy() - g["objectness"]).max() <= 2e-5
     assert np.abs(out["features"].cpu().numpy() - g["features"]).max() <= 5e-5
     assert np.abs(out["queries"].cpu().numpy() - g["queries"]).max() <= 5e-5
-    # selection parity: arg-max objectness query and the IoU of its thresholded mask vs the reference's
-    obj_ref = g["objectness"][:, -1, :, 0]
-    obj = out["objectness"][:, -1, :, 0].cpu().numpy()
+    # selection parity: arg-max objectness query and the thresholded masks vs the reference's
     assert (obj.argmax(1) == obj_ref.argmax(1)).all()
-    mp = out["mask_pred"][:, -1].cpu().numpy()
-    ref_bin = (1 / (1 + np.exp(-g["logits_last"].astype(np.float64)))) > 0.5
-    flips = ((mp > 0.5) != ref_bin).mean()
     assert flips <= 2e-5, flips
     if "logits_all" in g:
         assert np.abs(out["mask_logits"].cpu().numpy() - g["logits_all"]).max() <= tol
@@ -87,8 +106,10 @@ def test_forward_vs_oracle_batch8_and_fp64_truth(mode):
     r64 = (o32["mask_logits"].double() - o64["mask_logits"]).abs().max().item()
     print(f"\n[{mode}] B=8 calib: |logit|max={o32['mask_logits'].abs().max():.1f} hip-oracle32={d32:.2e} hip-truth64={d64:.2e} "
           f"oracle32-truth64={r64:.2e}")
+    ledger.record("forward_oracle_b8_calib", mode, {"logit_absmax": float(o32["mask_logits"].abs().max()), "hip_minus_ref32": d32,
+                                                    "hip_minus_ref64": d64, "ref32_minus_ref64": r64, "rule": "hip-ref32 <= 1e-4"})
     assert d32 <= ABS_TOL
-    assert d64 <= max(2 * r64, 0.5 * ABS_TOL)
+    assert d64 <= max(r64, 0.5 * ABS_TOL)
     assert (out["mask_pred"].cpu() - o32["mask_pred"]).abs().max().item() <= 0.25 * ABS_TOL + 1e-6
     assert (out["objectness"].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
     assert (out["features"].cpu() - o32["features"]).abs().max().item() <= 5e-5
@@ -129,6 +150,7 @@ def test_full_bench_batch_64_properties(mode):
     o32 = O.forward(x[pick], sd, patch)
     d = (out["mask_logits"][pick].cpu() - o32["mask_logits"]).abs().max().item()
     print(f"\n[{mode}] B=64 calib, images {pick}: hip-oracle32={d:.2e}")
+    ledger.record("forward_b64_calib_images_0_29_63", mode, {"hip_minus_ref32": d, "rule": "hip-ref32 <= 1e-4"})
     assert d <= ABS_TOL
     assert (out["objectness"][pick].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
 
@@ -202,8 +224,10 @@ def test_forward_other_shapes_and_model_sizes_vs_oracle(patch, B, H, W, nq, L, s
     scale = ref["mask_logits"].abs().max().item()
     d = (out["mask_logits"].cpu() - ref["mask_logits"]).abs().max().item()
     print(f"\n P{patch} B={B} {H}x{W} nq={nq} L={L}: |logit|max={scale:.1f} hip-oracle32={d:.2e}")
+    ledger.record("forward_edge_shapes_calib", f"P{patch}_B{B}_{H}x{W}_nq{nq}_L{L}", {"logit_absmax": scale, "hip_minus_ref32": d,
+                                                                                   "rule": "hip-ref32 <= 1e-4"})
     assert out["mask_pred"].shape == ref["mask_pred"].shape
-    assert d <= _tol(scale)
+    assert scale <= 16.0 and d <= ABS_TOL
     assert (out["objectness"].cpu() - ref["objectness"]).abs().max().item() <= 2e-5
     assert (out["features"].cpu() - ref["features"]).abs().max().item() <= 5e-5
 
@@ -221,6 +245,32 @@ def test_encoder_only_and_3d_path():
     m3.load_state_dict(sd, strict=True)
     o3 = m3.to(DEV)(x)
     assert set(o3.keys()) == {"mask_pred", "features"} and o3["mask_pred"].shape == (2, 20, 28, 28)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_3d_path_values_match_reference_vectors(mode):
+    """return_intermediate=False, use_binary_classifier=False (maskformer.py:219-220,246-249): un-sigmoided last-layer
+    logits + features against the REAL reference's output (tests/golden/forward3d_*.npz, oracle/gen_golden.py) and
+    against the oracle's restatement of that path - values, not just shapes (VERDICT r1 weak #2)."""
+    g = np.load(os.path.join(GOLD, "forward3d_p16_224_calib.npz"))
+    patch, B, Hh, Ww, wseed, xseed, _ = [int(v) for v in g["meta"]]
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch, use_binary_classifier=False)
+    m3 = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=False,
+                    use_binary_classifier=False, gemm_mode=mode)
+    m3.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    o3 = m3.to(DEV)(x.to(DEV))
+    assert set(o3.keys()) == {"mask_pred", "features"}
+    got = o3["mask_pred"].cpu().numpy()
+    d32, d64 = np.abs(got - g["mask_pred"]).max(), np.abs(got - g["mask_pred_f64"]).max()
+    ref64 = float(g["f32_vs_f64_maxabs"])
+    ora = O.forward_3d(x, sd, patch)
+    dora = (o3["mask_pred"].cpu() - ora["mask_pred"]).abs().max().item()
+    print(f"\n[{mode}] 3-D path: |logit|max={float(g['logit_absmax']):.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e} hip-oracle={dora:.2e}")
+    ledger.record("forward_3d_path", mode, {"logit_absmax": float(g["logit_absmax"]), "hip_minus_ref32": float(d32),
+                                            "hip_minus_ref64": float(d64), "ref32_minus_ref64": ref64, "rule": "hip-ref32 <= 1e-4"})
+    assert ref64 <= STRICT_BELOW and d32 <= ABS_TOL and d64 <= max(ref64, 0.5 * ABS_TOL) and dora <= ABS_TOL
+    assert np.abs(o3["features"].cpu().numpy() - g["features"]).max() <= 5e-5
 
 
 def test_cpu_input_is_refused():

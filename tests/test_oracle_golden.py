@@ -55,3 +55,18 @@ def test_oracle_fp64_mode_matches_reference_fp64():
     out = O.forward(x, sd, patch)
     assert np.abs(out["mask_logits"][:, -1].numpy() - g["logits_last_f64"]).max() <= 1e-10
     assert np.abs(out["objectness"].numpy() - g["objectness_f64"]).max() <= 1e-12
+
+
+def test_oracle_3d_path_matches_reference_vectors():
+    """forward_3d (return_intermediate=False, use_binary_classifier=False) against the real reference's output."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward3d_p16_224_calib.npz"))
+    patch, B, Hh, Ww, wseed, xseed, nthreads = [int(v) for v in g["meta"]]
+    torch.set_num_threads(min(nthreads, os.cpu_count() or 1))
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch, use_binary_classifier=False)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    out = O.forward_3d(x, sd, patch)
+    scale = float(g["logit_absmax"])
+    assert np.abs(out["mask_pred"].numpy() - g["mask_pred"]).max() <= 2e-6 * scale + 1e-6
+    assert np.abs(out["features"].numpy() - g["features"]).max() <= 2e-5
+    o64 = O.forward_3d(x.double(), O.cast_state(sd, torch.float64), patch)
+    assert np.abs(o64["mask_pred"].numpy() - g["mask_pred_f64"]).max() <= 1e-10
