@@ -173,7 +173,7 @@ def main():
                     help="diagnostic: every step copies its batch from pinned host memory first (PCIe-inclusive rate; "
                          "the metric keeps inputs resident in HBM)")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: skip the evaluator kernels (not the metric)")
-    ap.add_argument("--gemm-mode", default=None, choices=["f16x2", "fp32"], help="GEMM back end (default f16x2)")
+    ap.add_argument("--gemm-mode", default=None, choices=["w16", "f16x2", "fp32"], help="GEMM back end (default w16)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, no GPU): same spawn, barrier, gather and "
                          "max-over-ranks timing around a trivial step; used by tests/test_bench_launcher_cpu.py")
@@ -288,7 +288,7 @@ def main():
             pass
         gemm = "gemm" in dom_name or "attention" in dom_name
         peak = F32_MFMA_PEAK_TFLOPS if model.gemm_mode == "fp32" else F16_MFMA_PEAK_TFLOPS
-        issue = 3.0 if model.gemm_mode == "f16x2" else 1.0  # MFMA FLOPs issued per algorithmic FLOP (hi*hi, hi*lo, lo*hi)
+        issue = 3.0 if model.gemm_mode in ("w16", "f16x2") else 1.0  # MFMA FLOPs issued per algorithmic FLOP (hi*hi, hi*lo, lo*hi)
 
         def roof(v, name):
             if "layernorm" in name:

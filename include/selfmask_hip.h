@@ -168,6 +168,26 @@ int sm_attention_f32(const sm_attn_args* args, void* stream);
  * times the fp32 MFMA rate. Strides/pointers in float units, multiples of 8 (one F16X2 group), 32-B aligned. */
 int sm_attention_f16x2(const sm_attn_args* args, void* stream);
 
+/* Fused QKV projection + attention of one encoder block - Attention.forward up to (excluding) the output projection
+ * (vision_transformer.py:113-131: self.qkv(x) -> reshape/permute -> (q @ k^T) * scale -> softmax -> @ v -> merge heads).
+ * One workgroup per (image, head): K and V of the head are produced into LDS, Q into registers; the (B*N, 1152) QKV
+ * tensor is never written.  Xn = the block's LayerNorm output in F16X2, Wqkv = the (1152, 384) qkv weight in W16 with its
+ * 2^-s, bias (1152) fp32; O (B*N, 384) head-major columns, fp32 or F16X2.  N <= sm_qkv_attention_max_tokens() (208:
+ * the ViT-S/16 224^2 shape, 197 tokens); larger grids use sm_gemm_w16 + sm_attention_f16x2. */
+typedef struct sm_qkv_attn_args {
+    const float* Xn;    /* [B*N][ldx] F16X2 */
+    const float* Wqkv;  /* [1152][384] W16 (sm_split_w16) */
+    const float* bias;  /* [1152] */
+    float* O;           /* [B*N][ldo] */
+    int64_t ldx, ldo;   /* row strides in elements, multiples of 8 */
+    int32_t B, N;
+    float w_scale;      /* 2^-s of Wqkv */
+    float scale;        /* softmax scale: head_dim ** -0.5 = 0.125 (vision_transformer.py:104) */
+    int32_t out_f16x2;
+} sm_qkv_attn_args;
+int sm_qkv_attention_w16(const sm_qkv_attn_args* args, void* stream);
+int sm_qkv_attention_max_tokens(void);
+
 /* im2col of non-overlapping PxP patches with zero padding to a multiple of P (make_input_divisible,
  * vision_transformer.py:260-267; PatchEmbed conv :182-188): img (B,3,H,W) -> cols (B*gh*gw, 3*P*P), k=(c,i,j). */
 int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream);

@@ -245,19 +245,33 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // 17.3k images/s against 18.0k unfused - the full-row tile needs 112 KiB of LDS (one workgroup per CU, 197 of them).
     static const int fused_ln_env = getenv("SM_FUSED_LN") ? atoi(getenv("SM_FUSED_LN")) : 0;
     const bool fuse_proj = S && !c.W16 && fused_ln_env >= 1, fuse_fc2 = S && !c.W16 && fused_ln_env == 1;
+    // W16 mode, token grids of <= 208 (ViT-S/16 at 224^2): the qkv projection and the attention are ONE launch
+    // (qkv_attention.hip); SM_FUSED_QKV=0 keeps the two-launch path (tuning knob, same results to rounding)
+    static const int fused_qkv_env = getenv("SM_FUSED_QKV") ? atoi(getenv("SM_FUSED_QKV")) : 1;
+    const bool fused_qkv = c.W16 && fused_qkv_env != 0 && s.N <= sm_qkv_attention_max_tokens();
     LnOpt xs;
     xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
     if (fuse_fc2) TRY(ln(c, ws.X, w->enc[0].norm1_w, w->enc[0].norm1_b, nullptr, s.M, 1e-6f, xs));
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
         if (!fuse_fc2) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
-        TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_s, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
-        sm_attn_args a = {};
-        a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
-        a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
-        a.sOb = (int64_t)s.N * D; a.sOr = D;
-        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
-        TRY(attn(c, a));
+        if (fused_qkv) {
+            sm_qkv_attn_args q = {};
+            q.Xn = ws.Xn; q.Wqkv = e.qkv_w; q.bias = e.qkv_b; q.O = ws.AO; q.ldx = D; q.ldo = D;
+            q.B = s.B; q.N = s.N; q.w_scale = e.qkv_s; q.scale = 0.125f; q.out_f16x2 = 1;
+            // algorithmic work of SURVEY.md 8d: 2 N 384 1152 + 4 N^2 384 FLOPs, x in + o out bytes per image
+            TapScope tap(c.st, "qkv_attention_kernel", (double)s.B * (2.0 * s.N * D * 3 * D + 4.0 * s.N * s.N * D),
+                         2.0 * s.M * D * 4);
+            TRY(sm_qkv_attention_w16(&q, c.st));
+        } else {
+            TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_s, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
+            sm_attn_args a = {};
+            a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
+            a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
+            a.sOb = (int64_t)s.N * D; a.sOr = D;
+            a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.N; a.n_k = s.N; a.scale = 0.125f;
+            TRY(attn(c, a));
+        }
         if (fuse_proj) {
             TRY(linear_residual_ln(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, s.M, D, e.norm2_w, e.norm2_b, 1e-6f, ws.Xn));
         } else {

@@ -41,8 +41,19 @@ __device__ __forceinline__ int stage_swz(int row) {
     else return (row >> 2) & 3;
 }
 
-// WPS = waves per SIMD the register allocation must leave room for (second __launch_bounds__ argument)
-template <int BM, int BN, int KT, int NST, int NWM, int NWN, int WPS>
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// WPS = waves per SIMD the register allocation must leave room for (second __launch_bounds__ argument).
+// PIPE = 1: software-pipelined K loop - the fragments of stage kt+1 are read into a second register set and the next
+// LDS-DMA pieces are issued BETWEEN the MFMA blocks of stage kt, so a wave's LDS latency and DMA issue time run under its
+// own MFMAs instead of in front of them (needs NST >= 3: the slot refilled in iteration kt was consumed in kt-1).
+template <int BM, int BN, int KT, int NST, int NWM, int NWN, int WPS, int PIPE = 0>
 __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_args g) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -132,6 +143,65 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
 
     const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
+    if constexpr (PIPE) {
+        static_assert(NST >= 3, "the pipelined loop refills the slot consumed one iteration earlier");
+        struct Frag { f16x8 ah[KS][TM], al[KS][TM], wh[KS][TN], wl[KS][TN]; };
+        constexpr int NB = KS * TN * TM;           // MFMA blocks (3 MFMAs each) per stage
+        constexpr int NRD = KS * (TN + TM);        // hi/lo fragment pairs to read per stage
+        constexpr int NITEM = NRD + NI;            // side work per stage: fragment pairs of the next stage, then DMA pieces
+        constexpr int IPB = (NITEM + NB - 1) / NB; // side items placed behind each MFMA block
+        auto read_pair = [&](Frag& f, int kt, auto item_tag) {
+            constexpr int item = decltype(item_tag)::value;
+            constexpr int s = item / (TN + TM), q = item % (TN + TM);
+            if constexpr (q < TN) {
+                const char* stw = smemw + W_RING + (kt % NST) * W_STAGE + w_row + q * 32 * ROWB;
+                f.wh[s][q] = *reinterpret_cast<const f16x8*>(stw + off_hi[s]);
+                f.wl[s][q] = *reinterpret_cast<const f16x8*>(stw + off_lo[s]);
+            } else {
+                const char* sta = smemw + (kt % NST) * A_STAGE + a_row + (q - TN) * 32 * ROWB;
+                f.ah[s][q - TN] = *reinterpret_cast<const f16x8*>(sta + off_hi[s]);
+                f.al[s][q - TN] = *reinterpret_cast<const f16x8*>(sta + off_lo[s]);
+            }
+        };
+        auto issue_piece = [&](int kt, auto piece_tag) {  // piece p of the tile NST-1 ahead of kt: W pieces first
+            constexpr int p = decltype(piece_tag)::value;
+            const int t = kt + NST - 1, tt = t < nk ? t : nk - 1, slot = t % NST;
+            if constexpr (p < W_INST)
+                lds_dma16(w_src[p] + tt * ROWB, __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + (wave * W_INST + p) * 1024));
+            else
+                lds_dma16(a_src[p - W_INST] + tt * ROWB, __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + (wave * A_INST + p - W_INST) * 1024));
+        };
+        auto body = [&](int kt, Frag& cur, Frag& nxt) {
+            wait_vmcnt_w<(NST - 3) * NI>();  // tile kt+1 has landed (this wave's pieces)
+            __builtin_amdgcn_s_barrier();    // ... for every wave; every wave has consumed tile kt-1 (its slot is refilled below)
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<NB>([&](auto blk) {
+                constexpr int b = decltype(blk)::value;
+                constexpr int s = b / (TN * TM), j = (b / TM) % TN, i = b % TM;
+                const f16x8 whs = cur.wh[s][j] * down;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wh[s][j], cur.ah[s][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.wl[s][j], cur.ah[s][i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whs, cur.al[s][i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<IPB>([&](auto sub) {
+                    constexpr int item = b * IPB + decltype(sub)::value;
+                    if constexpr (item < NRD) read_pair(nxt, kt + 1, std::integral_constant<int, item>{});
+                    else if constexpr (item < NITEM) issue_piece(kt, std::integral_constant<int, item - NRD>{});
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        Frag fa, fb;
+        wait_vmcnt_w<(NST - 2) * NI>();  // tile 0 has landed
+        __builtin_amdgcn_s_barrier();
+        static_for<NRD>([&](auto it) { read_pair(fa, 0, it); });
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            body(kt, fa, fb);
+            body(kt + 1, fb, fa);
+        }
+        if (kt < nk) body(kt, fa, fb);
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         wait_vmcnt_w<(NST - 2) * NI>();   // tile kt has landed (this wave's pieces); younger tiles may still fly
         __builtin_amdgcn_s_barrier();     // ... for every wave, and every wave is done reading the slot refilled next
@@ -289,19 +359,19 @@ __global__ __launch_bounds__(256) void split_w16_kernel(const float* __restrict_
     }
 }
 
-template <int BM, int BN, int KT, int NST, int NWM, int NWN, int MINB>
+template <int BM, int BN, int KT, int NST, int NWM, int NWN, int MINB, int PIPE = 0>
 static int launch_gemm_w(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : 1);
     constexpr size_t lds = (size_t)NST * (BM + BN) * KT * 4;
     if (lds > 64 * 1024) {
         static std::once_flag attr_once;
         std::call_once(attr_once, [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB, PIPE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipGetLastError();
         });
     }
-    hipLaunchKernelGGL((gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB>), grid, dim3(NWM * NWN * 64), lds, st, g);
+    hipLaunchKernelGGL((gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB, PIPE>), grid, dim3(NWM * NWN * 64), lds, st, g);
     return check_launch("sm_gemm_w16");
 }
 
@@ -361,6 +431,13 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 6: return sm::launch_gemm_w<256, 128, 32, 2, 4, 2, 2>(a, st);
         case 7: return sm::launch_gemm_w<128, 64, 32, 2, 2, 2, 3>(a, st);
         case 8: return sm::launch_gemm_w<128, 128, 16, 3, 2, 4, 6>(a, st);
+        // software-pipelined K loop (PIPE = 1)
+        case 10: return sm::launch_gemm_w<128, 128, 16, 3, 2, 2, 3, 1>(a, st);  // 4 waves of 64x64, 48 KiB: three per CU
+        case 11: return sm::launch_gemm_w<128, 128, 16, 4, 2, 2, 2, 1>(a, st);  // ... ring of 4, 64 KiB: two per CU
+        case 12: return sm::launch_gemm_w<128, 128, 16, 4, 2, 4, 4, 1>(a, st);  // 8 waves of 64x32, 64 KiB: two per CU
+        case 13: return sm::launch_gemm_w<256, 128, 16, 4, 4, 2, 2, 1>(a, st);  // 8 waves of 64x64, 96 KiB: one per CU
+        case 14: return sm::launch_gemm_w<128, 64, 16, 4, 2, 2, 4, 1>(a, st);   // 4 waves of 64x32, 48 KiB: three per CU
+        case 15: return sm::launch_gemm_w<128, 128, 32, 3, 2, 2, 2, 1>(a, st);  // 4 waves of 64x64, 32-k stages x 3, 96 KiB: one per CU
     }
     sm::set_error("sm_gemm_w16_tile: unknown variant %d", variant);
     return SM_EINVAL;
@@ -376,6 +453,12 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 6: return "gemm_w16_kernel<256, 128, 32, 2, 4, 2, 2>";
         case 7: return "gemm_w16_kernel<128, 64, 32, 2, 2, 2, 3>";
         case 8: return "gemm_w16_kernel<128, 128, 16, 3, 2, 4, 6>";
+        case 10: return "gemm_w16_kernel<128, 128, 16, 3, 2, 2, 3, 1>";
+        case 11: return "gemm_w16_kernel<128, 128, 16, 4, 2, 2, 2, 1>";
+        case 12: return "gemm_w16_kernel<128, 128, 16, 4, 2, 4, 4, 1>";
+        case 13: return "gemm_w16_kernel<256, 128, 16, 4, 4, 2, 2, 1>";
+        case 14: return "gemm_w16_kernel<128, 64, 16, 4, 2, 2, 4, 1>";
+        case 15: return "gemm_w16_kernel<128, 128, 32, 3, 2, 2, 2, 1>";
     }
     return nullptr;
 }

@@ -1,0 +1,344 @@
+// Fused QKV projection + softmax attention of one encoder block (vision_transformer.py:110-131: qkv Linear -> split heads
+// -> softmax(q k^T / 8) v), the kernel BASELINE.json's north star names.  One workgroup per (image, head), seven waves,
+// wave w owns tokens 32w .. 32w+31 - as projection rows first, as queries afterwards.  The (B*N, 1152) QKV tensor of
+// the unfused path (58 MB written and read back per layer at B = 64) never exists: K and V of the head live in LDS, Q in
+// registers.
+//
+// Phase 1 - projection.  Xn (the LayerNorm output, F16X2) and the head's 192 rows of the W16 qkv weight stream through a
+// two-slot LDS-DMA ring in 16-k stages (same source-side XOR swizzle as gemm_w16.hip).  Per stage a wave issues 18
+// MFMAs into six single-accumulator 32x32 blocks (gemm_w16.hip's arithmetic: wh*ah + wl*ah + (wh*2^-11)*al'):
+//     Q^T, K^T = W X^T   (weights = MFMA A operand): the token sits on the lane, 16 head-dims in the registers;
+//     V       = X W^T    (weights = MFMA B operand): the head-dim sits on the lane, 16 tokens in the registers.
+// Those are exactly the layouts phase 2 wants (cdna_hip_programming.md section 3, "an accumulator tile as the next
+// MFMA's operand"): registers 8s..8s+7 of a block are the 8 k-elements a lane supplies to step s of the next product,
+// in the permuted order k = 16s + 8(j>>2) + 4h + (j&3) - and because BOTH operands of each later product come from
+// such accumulators (Q and K for S^T, P and V for O^T) the permutation is the same on both sides and nothing has to be
+// transposed: Q stays in registers as the B operand of S^T = K Q^T; every lane writes its key's K fragments and its
+// head-dim's V fragments to LDS as whole 16-B hi / lo pieces in the order the consumer lane (same r, same h) reads them
+// back with ds_read_b128.  No ds_read_b64_tr_b16, no shuffles.
+//
+// Phase 2 - attention, as attention_f16x2.hip: S^T = K Q^T (3 MFMAs per 16 dims), softmax on the lane (keys on the
+// accumulator rows: one cross-half shuffle), lazy running maximum, P split in registers = B operand of O^T = V^T P^T.
+//
+// LDS: K 208 x 256 B + V^T 64 x 848 B (16 B of padding per row: conflict-free b128 reads) + ring 2 x 26 KiB = 157 KiB -
+// one workgroup per CU, so N <= 208 tokens: the ViT-S/16 224^2 headline shape (197).  Other shapes take the unfused path.
+#include "common.h"
+#include <math.h>
+#include <mutex>
+#include <stdlib.h>
+
+namespace sm {
+
+constexpr int QA_WAVES = 7;
+constexpr int QA_TOK = QA_WAVES * 32;        // 224 token rows staged per K-stage (rows past N repeat the last token)
+constexpr int QA_KROWS = 208;                // keys kept in LDS (13 MFMA steps of 16 keys)
+constexpr int QA_K_BYTES = QA_KROWS * 256;   // 53248
+constexpr int QA_VLD = 208 * 4 + 16;         // bytes per head-dim row of V^T (+16: b128 reads of 16 rows hit 16 slots)
+constexpr int QA_V_BYTES = 64 * QA_VLD;      // 54272
+constexpr int QA_XT = QA_TOK * 64;           // 14336 B: Xn stage (16 k = 64 B per row)
+constexpr int QA_WT = 192 * 64;              // 12288 B: weight stage (Q, K, V rows of the head)
+constexpr int QA_STAGE = QA_XT + QA_WT;      // 26624
+constexpr int QA_RING = QA_K_BYTES + QA_V_BYTES;
+constexpr int QA_LDS = QA_RING + 2 * QA_STAGE;  // 160768 <= 163840
+constexpr int QA_XP = QA_XT / 1024, QA_WP = QA_WT / 1024, QA_NP = QA_XP + QA_WP;  // 14 + 12 = 26 one-KiB pieces per stage
+constexpr int QA_PPW = (QA_NP + QA_WAVES - 1) / QA_WAVES;                           // <= 4 pieces per wave
+
+__global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_attn_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smq[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smq;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // (image, head) of this workgroup: ids 8 apart share an XCD (round-robin dispatch), so the six heads of an image run
+    // on one XCD back to back and five of them find the image's Xn rows in that L2
+    int head, b;
+    {
+        const int id = blockIdx.x, pairs = a.B * SM_HEADS;
+        int lin = id;
+        if ((pairs & 7) == 0) lin = (id & 7) * (pairs >> 3) + (id >> 3);
+        b = lin / SM_HEADS;
+        head = lin - b * SM_HEADS;
+    }
+    const int N = a.N;
+    const char* X = reinterpret_cast<const char*>(a.Xn + (int64_t)b * N * a.ldx);
+    const char* W = reinterpret_cast<const char*>(a.Wqkv);
+
+    // ---- ring fill: piece p of a stage = 16 rows x 64 B; p < 14: Xn rows 16p.., else weight rows 16(p-14)..; dealt
+    // round-robin over the waves.  Lane l fetches chunk (l & 3) ^ swz(row) of row l >> 2 (swz = (row >> 2) & 3).
+    const char* src[QA_PPW];
+    unsigned dst[QA_PPW];
+#pragma unroll
+    for (int j = 0; j < QA_PPW; ++j) {
+        const int p = wave + QA_WAVES * j;
+        const int prow = lane >> 2;
+        if (p < QA_XP) {
+            const int row = p * 16 + prow;
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int tok = row < N ? row : N - 1;
+            src[j] = X + (int64_t)tok * a.ldx * 4 + c * 16;
+        } else {
+            const int row = (p - QA_XP) * 16 + prow;  // 0..191: [Q dims | K dims | V dims] of this head
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int wrow = (row >> 6) * SM_EMBED + head * SM_HEAD_DIM + (row & 63);
+            src[j] = W + (int64_t)wrow * SM_EMBED * 4 + c * 16;
+        }
+        dst[j] = p * 1024;
+    }
+    auto issue = [&](int kt, int slot) {
+#pragma unroll
+        for (int j = 0; j < QA_PPW; ++j)
+            if (wave + QA_WAVES * j < QA_NP)
+                lds_dma16(src[j] + kt * 64, __builtin_amdgcn_readfirstlane(lds0 + QA_RING + slot * QA_STAGE + dst[j]));
+    };
+
+    // fragment offsets inside a 64-B stage row: lane half h -> k-group h -> chunks 2h (hi), 2h+1 (lo)
+    const int xrow = wave * 32 + r;
+    const int xoff = xrow * 64, xsw = (xrow >> 2) & 3;
+    const int x_hi = xoff + (((2 * h) ^ xsw) * 16), x_lo = xoff + (((2 * h + 1) ^ xsw) * 16);
+    const int wsw = (r >> 2) & 3;  // weight rows 32 blk + r: (row >> 2) & 3 does not depend on blk
+    const int w_hi = QA_XT + r * 64 + (((2 * h) ^ wsw) * 16), w_lo = QA_XT + r * 64 + (((2 * h + 1) ^ wsw) * 16);
+
+    f32x16 acc[6];  // [Q d0-31, Q d32-63, K d0-31, K d32-63, V d0-31, V d32-63]
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                        (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
+
+    constexpr int NKT = SM_EMBED / 16;  // 24 stages
+    issue(0, 0);
+    for (int kt = 0; kt < NKT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // stage kt has landed for every wave; every wave is done with stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < NKT) issue(kt + 1, (kt + 1) & 1);
+        const char* st = smq + QA_RING + (kt & 1) * QA_STAGE;
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(st + x_hi);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(st + x_lo);
+        f16x8 wh[6], wl[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            wh[i] = *reinterpret_cast<const f16x8*>(st + w_hi + i * 32 * 64);
+            wl[i] = *reinterpret_cast<const f16x8*>(st + w_lo + i * 32 * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {  // Q^T, K^T: D[dim][token]
+            const f16x8 whs = wh[i] * down;
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], ah, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], ah, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whs, al, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 4; i < 6; ++i) {  // V: D[token][dim]
+            const f16x8 whs = wh[i] * down;
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[i], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[i], acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, whs, acc[i], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- accumulators -> Q fragments (registers), K and V^T (LDS) ---------------------------------------------------------
+    const float ws = a.w_scale;
+    const float* bq = a.bias + head * SM_HEAD_DIM;
+    const float* bk = bq + SM_EMBED;
+    const float* bv = bk + SM_EMBED;
+    const int key = wave * 32 + r;  // the token this lane holds as a key (Q^T / K^T blocks) ...
+    f16x8 qh[4], ql[4];             // step t = 2 db + s: dims 32 db + 16 s + 8 (j >> 2) + 4 h + (j & 3)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 kh8, kl8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = db * 32 + acc_row(8 * s + j, h);
+                _Float16 hi, lo;
+                split1(acc[db][8 * s + j] * ws + bq[d], hi, lo);
+                qh[2 * db + s][j] = hi;
+                ql[2 * db + s][j] = lo;
+                split1(acc[2 + db][8 * s + j] * ws + bk[d], hi, lo);
+                kh8[j] = hi;
+                kl8[j] = lo;
+            }
+            if (key < QA_KROWS) {  // K row of this key: chunk 2 (4 db + 2 s + h) (+1 = lo), XOR-ed with key & 15
+                const int c = 2 * (4 * db + 2 * s + h);
+                *reinterpret_cast<f16x8*>(smq + key * 256 + ((c ^ (key & 15)) * 16)) = kh8;
+                *reinterpret_cast<f16x8*>(smq + key * 256 + (((c + 1) ^ (key & 15)) * 16)) = kl8;
+            }
+        }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {  // ... and the head-dim it holds in the V blocks: rows = this wave's 32 tokens
+        const int d = db * 32 + r;
+        const float bias = bv[d];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (wave * 32 + 16 * u < QA_KROWS) {
+                f16x8 vh8, vl8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 hi, lo;
+                    split1(acc[4 + db][8 * u + j] * ws + bias, hi, lo);
+                    vh8[j] = hi;
+                    vl8[j] = lo;
+                }
+                char* p = smq + QA_K_BYTES + d * QA_VLD + wave * 128 + u * 64 + h * 32;
+                *reinterpret_cast<f16x8*>(p) = vh8;
+                *reinterpret_cast<f16x8*>(p + 16) = vl8;
+            }
+        }
+    }
+    __syncthreads();  // K and V^T of the head are complete
+
+    // ---- attention: this wave's 32 queries against all keys --------------------------------------------------------------
+    const int q0 = wave * 32;
+    if (q0 >= N) return;
+    const float cs = a.scale * 1.44269504088896340736f;  // scores in log2 units
+    const int nsteps16 = (N + 15) >> 4;                  // 16-key MFMA steps that hold at least one real key
+    f32x16 om[2], oc[2];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { om[0][v] = 0.f; om[1][v] = 0.f; oc[0][v] = 0.f; oc[1][v] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ksw = r & 15;
+    int k_hi[4], k_lo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        k_hi[t] = ((2 * (2 * t + h)) ^ ksw) * 16;
+        k_lo[t] = ((2 * (2 * t + h) + 1) ^ ksw) * 16;
+    }
+    const char* Vt = smq + QA_K_BYTES + r * QA_VLD + h * 32;  // + db * 32 rows, + kb * 128 + u * 64
+    const int nch = (N + 63) >> 6;
+    for (int c = 0; c < nch; ++c) {
+        const int ck = min(64, N - c * 64);
+        const int nb2 = (ck + 31) >> 5;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s[kb][v] = -INFINITY;
+            if (kb < nb2) {
+                f32x16 mn, cr;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { mn[v] = 0.f; cr[v] = 0.f; }
+                const char* kr = smq + (c * 64 + kb * 32 + r) * 256;
+                f16x8 kh[4], kl[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    kh[t] = *reinterpret_cast<const f16x8*>(kr + k_hi[t]);
+                    kl[t] = *reinterpret_cast<const f16x8*>(kr + k_lo[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    mn = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t], qh[t], mn, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[t], ql[t], cr, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[t], qh[t], cr, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 16; ++v) s[kb][v] = fmaf(cr[v], 1.0f / 2048.0f, mn[v]);
+                if ((kb + 1) * 32 > ck) {  // keys past N: rows >= 208 alias other LDS data, rows 197..207 repeat a token
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+                        if (kb * 32 + acc_row(v, h) >= ck) s[kb][v] = -INFINITY;
+                }
+            }
+        }
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, s[kb][v]);
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float lim = 8.0f / cs;  // lazy running maximum (attention_f16x2.hip): p <= 2^8 between moves
+        if (__builtin_amdgcn_ballot_w64(cmax > m_run + lim) != 0) {
+            const float m_new = fmaxf(m_run, cmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { om[0][v] *= alpha; om[1][v] *= alpha; oc[0][v] *= alpha; oc[1][v] *= alpha; }
+        }
+        const float moff = -m_run * cs;
+        float psum = 0.f;
+        f16x8 ph[2][2], pl[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * u + j], cs, moff));
+                    psum += p;
+                    _Float16 hi, lo;
+                    split1(p, hi, lo);
+                    ph[kb][u][j] = hi;
+                    pl[kb][u][j] = lo;
+                }
+        l_run += psum;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if ((c * 2 + kb) * 2 + u < nsteps16) {  // wave-uniform: steps past the last real key hold no V data
+                    const char* vp = Vt + (c * 2 + kb) * 128 + u * 64;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const f16x8 vh = *reinterpret_cast<const f16x8*>(vp + db * 32 * QA_VLD);
+                        const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + db * 32 * QA_VLD + 16);
+                        om[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[kb][u], om[db], 0, 0, 0);
+                        oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[kb][u], oc[db], 0, 0, 0);
+                        oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[kb][u], oc[db], 0, 0, 0);
+                    }
+                }
+            }
+    }
+
+    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l;
+    if (q0 + r < N) {
+        float* Orow = a.O + ((int64_t)b * N + q0 + r) * a.ldo;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                float x[4], y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x[e] = (om[db][4 * g + e] + oc[db][4 * g + e] * (1.0f / 2048.0f)) * inv;
+                    y[e] = (om[db][4 * g + 4 + e] + oc[db][4 * g + 4 + e] * (1.0f / 2048.0f)) * inv;
+                }
+                if (a.out_f16x2) {
+                    pair_groups(x, y);
+                    store_f16x2_8(Orow, head * SM_HEAD_DIM + db * 32 + 8 * (g + h), x, y);
+                } else {
+                    const int d = head * SM_HEAD_DIM + db * 32 + 8 * g + 4 * h;
+                    *reinterpret_cast<float4*>(Orow + d) = make_float4(x[0], x[1], x[2], x[3]);
+                    *reinterpret_cast<float4*>(Orow + d + 8) = make_float4(y[0], y[1], y[2], y[3]);
+                }
+            }
+    }
+}
+
+}  // namespace sm
+
+extern "C" int sm_qkv_attention_max_tokens(void) { return sm::QA_KROWS; }
+
+extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
+    SM_REQUIRE(a && a->Xn && a->Wqkv && a->bias && a->O, "sm_qkv_attention_w16: null pointer");
+    SM_REQUIRE(a->B > 0 && a->N > 0 && a->N <= sm::QA_KROWS, "sm_qkv_attention_w16: N=%d tokens (1..%d: K and V of a head stay in LDS)",
+               a ? a->N : 0, sm::QA_KROWS);
+    SM_REQUIRE(a->scale > 0.f, "sm_qkv_attention_w16: scale must be positive");
+    int ex = 0;
+    SM_REQUIRE(a->w_scale > 0.f && frexpf(a->w_scale, &ex) == 0.5f, "sm_qkv_attention_w16: w_scale must be the weight's 2^-s");
+    SM_REQUIRE(a->ldx % 8 == 0 && a->ldx >= SM_EMBED && a->ldo % 8 == 0 && a->ldo >= SM_EMBED &&
+                   ((uintptr_t)a->Xn | (uintptr_t)a->Wqkv | (uintptr_t)a->O) % 32 == 0,
+               "sm_qkv_attention_w16: row strides must be multiples of 8 elements, pointers 32-B aligned");
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        (void)hipGetLastError();
+    });
+    hipLaunchKernelGGL(sm::qkv_attention_kernel, dim3(a->B * SM_HEADS), dim3(sm::QA_WAVES * 64), sm::QA_LDS, (hipStream_t)stream, *a);
+    return sm::check_launch("sm_qkv_attention_w16");
+}

@@ -44,6 +44,11 @@ class AttnArgs(C.Structure):
                 ("scale", C.c_float), ("out_f16x2", C.c_int32)]
 
 
+class QkvAttnArgs(C.Structure):
+    _fields_ = [("Xn", fp), ("Wqkv", fp), ("bias", fp), ("O", fp), ("ldx", C.c_int64), ("ldo", C.c_int64),
+                ("B", C.c_int32), ("N", C.c_int32), ("w_scale", C.c_float), ("scale", C.c_float), ("out_f16x2", C.c_int32)]
+
+
 ENC_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
               "fc2_w", "fc2_b"]
 DEC_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
@@ -122,6 +127,8 @@ SYMBOLS = {
     "sm_broadcast_rows_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_attention_f32": (C.c_int, [C.POINTER(AttnArgs), fp]),
     "sm_attention_f16x2": (C.c_int, [C.POINTER(AttnArgs), fp]),
+    "sm_qkv_attention_w16": (C.c_int, [C.POINTER(QkvAttnArgs), fp]),
+    "sm_qkv_attention_max_tokens": (C.c_int, []),
     "sm_im2col_patches_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_cls_rows_f32": (C.c_int, [fp, fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_pos_embed_bicubic_f32": (C.c_int, [fp, C.c_int32, fp, C.c_int32, C.c_int32, fp]),

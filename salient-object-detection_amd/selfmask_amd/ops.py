@@ -219,6 +219,23 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 
     return o
 
 
+def qkv_attention(xn: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor, B: int, scale: float = 0.125,
+                  out_f16x2: bool = False) -> torch.Tensor:
+    """Fused qkv Linear + softmax attention of an encoder block (sm_qkv_attention_w16): xn (B*N, 384) fp32 LayerNorm output
+    (converted to F16X2 here), w_qkv (1152, 384) / b_qkv (1152) fp32 -> (B*N, 384) merged-head attention output."""
+    _dev(xn, w_qkv, b_qkv)
+    M = xn.shape[0]
+    assert M % B == 0 and xn.shape[1] == N.EMBED
+    xs = split_f16x2(xn.contiguous())
+    w16, ws = split_w16(w_qkv)
+    o = torch.empty((M, N.EMBED), device=xn.device, dtype=torch.float32)
+    a = N.QkvAttnArgs()
+    a.Xn, a.Wqkv, a.bias, a.O = xs.data_ptr(), w16.data_ptr(), b_qkv.data_ptr(), o.data_ptr()
+    a.ldx, a.ldo, a.B, a.N, a.w_scale, a.scale, a.out_f16x2 = N.EMBED, N.EMBED, B, M // B, ws, scale, 1 if out_f16x2 else 0
+    N.check(N.load().sm_qkv_attention_w16(a, _stream()), "sm_qkv_attention_w16")
+    return o
+
+
 def im2col_patches(img: torch.Tensor, patch: int) -> torch.Tensor:
     _dev(img)
     img = img.contiguous()
