@@ -222,6 +222,27 @@ int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float*
 /* features[b,:] = mean_q queries[b, last_layer, q, :]   (maskformer.py:198-203) */
 int sm_query_mean_f32(const float* queries, float* features, int32_t B, int32_t L, int32_t nq, void* stream);
 
+/* ---- input pipeline: decoded uint8 images -> the model's normalised fp32 NCHW input ---------------------
+ * Replaces, per image, the host-side tail of the reference's data path: [T.Resize((S, S)) on the PIL image ->]
+ * ToTensor -> Normalize(mean, std)  (datasets/base_dataset.py:228-256, duts.py:108-147, app.py:198-205). */
+typedef struct sm_pre_image {
+    int64_t off;      /* byte offset of this image's (H, W, 3) interleaved uint8 RGB pixels inside `in` */
+    int64_t out_off;  /* sm_preprocess_normalize_u8: element offset of this image's (3, H, W) block inside `out` */
+    int32_t H, W;
+    int32_t coef_x, coef_y; /* sm_preprocess_resize_u8: int32 offsets of this image's horizontal / vertical tables in `coef`:
+                               [S][2] (first input index, tap count) followed by [S][ks] fixed-point taps (22 bits) */
+    int32_t ksx, ksy;       /* taps per output pixel in those tables */
+} sm_pre_image;
+/* Pillow-exact BILINEAR resize of B images to S x S (horizontal pass -> uint8 -> vertical pass, 22-bit fixed-point taps
+ * computed by the host as Pillow's precompute_coeffs does) fused with ToTensor + Normalize through `lut` (768 floats:
+ * lut[c*256 + v] = (v / 255 - mean_c) / std_c evaluated in fp32 by the host).  tmp: B x tmp_stride bytes of scratch
+ * (>= max_h * S * 3 each); out (B, 3, S, S) fp32. */
+int sm_preprocess_resize_u8(const uint8_t* in, const sm_pre_image* images, const int32_t* coef, const float* lut, uint8_t* tmp,
+                            int64_t tmp_stride, float* out, int32_t B, int32_t S, int32_t max_h, void* stream);
+/* native resolution (the reference's test mode): ToTensor + Normalize only; image b -> out + images[b].out_off as (3, H, W) */
+int sm_preprocess_normalize_u8(const uint8_t* in, const sm_pre_image* images, const float* lut, float* out, int32_t B,
+                               int32_t max_pixels, void* stream);
+
 /* ---- evaluator post-processing + metrics ------------------------------------------- */
 typedef struct sm_eval_image {
     int64_t gt_off; /* byte offset of this image's ground truth (H*W bytes, 0 / non-zero) inside `gt` */

@@ -86,6 +86,11 @@ class KernelTime(C.Structure):
                 ("bytes", C.c_double)]
 
 
+class PreImage(C.Structure):
+    _fields_ = [("off", C.c_int64), ("out_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32), ("coef_x", C.c_int32),
+                ("coef_y", C.c_int32), ("ksx", C.c_int32), ("ksy", C.c_int32)]
+
+
 class EvalImage(C.Structure):
     _fields_ = [("gt_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32)]
 
@@ -136,6 +141,8 @@ SYMBOLS = {
     "sm_upsample2x_logits_sigmoid_f32": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, fp]),
     "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_preprocess_resize_u8": (C.c_int, [fp, fp, fp, fp, fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_preprocess_normalize_u8": (C.c_int, [fp, fp, fp, fp, C.c_int32, C.c_int32, fp]),
     "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),

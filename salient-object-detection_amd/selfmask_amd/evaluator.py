@@ -33,7 +33,12 @@ class Evaluator(BaseStructure):
     @torch.no_grad()
     def __call__(self, dataset_name: str, dir_ckpt: str, img_size: Optional[int] = None, scale_factor: int = 2,
                  batch_size: int = 1, device: torch.device = torch.device("cuda:0"), cost_type: str = "iou",
-                 comm=None, streams: int = DEFAULT_STREAMS, hip_graph: bool = True) -> dict:
+                 comm=None, streams: int = DEFAULT_STREAMS, hip_graph: bool = True, input_pipeline: str = "device",
+                 workers: Optional[int] = None) -> dict:
+        """evaluator.pyc@L164-309.  Extra keyword arguments (not in the reference): ``comm`` / ``streams`` / ``hip_graph``
+        (image sharding, batches in flight, graph replay) and ``input_pipeline``: "device" (default) decodes on a pool of
+        ``workers`` host threads running ahead of the GPU and does resize + ToTensor + Normalize in HIP kernels
+        (pipeline.py, bit-identical inputs), "host" is the reference's order of work: one thread, PIL + numpy per image."""
         assert cost_type == "iou", "the upper bound is chosen by IoU (evaluator.pyc@L216); other costs are unused"
         if not getattr(self.model, "use_binary_classifier", True):
             raise RuntimeError("the evaluator dereferences objectness unconditionally (evaluator.pyc@L219): "
@@ -56,16 +61,31 @@ class Evaluator(BaseStructure):
         # native-resolution mode meets a new shape with almost every image: graphs would only thrash there
         self._graphed = GraphedForward(self.model, enabled=hip_graph and img_size is not None and
                                        isinstance(self.model, torch.nn.Module))
-        for s in range(0, len(mine), batch_size):
-            items = [dataset[i] for i in mine[s:s + batch_size]]
-            x = torch.stack([it["x"] for it in items])
+        assert input_pipeline in ("device", "host"), input_pipeline
+
+        def batches():
+            if input_pipeline == "host":
+                for s in range(0, len(mine), batch_size):
+                    items = [dataset[i] for i in mine[s:s + batch_size]]
+                    yield s, torch.stack([it["x"] for it in items]), [it["m"].squeeze() for it in items]
+            else:
+                from .pipeline import PrefetchingLoader, preprocess_on_device
+                s = 0
+                for rgbs, gts, _ in PrefetchingLoader(dataset, mine, batch_size, workers=workers, depth=len(ring.streams) + 1):
+                    yield s, (rgbs, preprocess_on_device), [torch.from_numpy(g) for g in gts]
+                    s += len(rgbs)
+
+        for s, x, gts in batches():
             with ring.next():
+                if isinstance(x, tuple):  # decoded uint8 images: resize / normalise on this batch's stream
+                    rgbs, pre = x
+                    x = pre(rgbs, img_size, device, pinned=True)
+                    x = x if img_size is not None else x[0]
                 out = self._forward({"x": x}, device=device)
                 mask_pred, obj = out["mask_pred"], out.get("objectness")
                 if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
                     mask_pred, obj = mask_pred[:, -1], obj[:, -1]
-                gts = [it["m"].squeeze().to(device) for it in items]
-                rows_local[s:s + len(items)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gts, scale=scale)
+                rows_local[s:s + len(gts)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), [g.to(device) for g in gts], scale=scale)
         ring.join()
         self.graph_stats = {"captures": self._graphed.captures, "replays": self._graphed.replays,
                             "failed": self._graphed.failed}

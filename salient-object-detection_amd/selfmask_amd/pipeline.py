@@ -1,0 +1,209 @@
+"""Input pipeline of the evaluator / serving path: JPEG decode on a pool of host threads, everything
+after it - the reference's ``T.Resize`` (PIL bilinear), ``ToTensor`` and ``Normalize`` - on the MI355X
+(``csrc/preprocess.hip``), with pinned staging buffers so decode, H2D copy and the model overlap.
+
+Reference semantics kept (datasets/base_dataset.py:228-256, duts.py:108-147, custom_dataset.py:26-32, app.py:198-205):
+RGB convert; fixed S x S resize = Pillow's BILINEAR resample (anti-aliased triangle filter, 22-bit fixed-point taps, uint8
+after each pass); ``/255``; mean (0.485, 0.456, 0.406) / std (0.229, 0.224, 0.225); GT in mode "L", ``m > 0`` when its max
+exceeds 1.  The host computes only what depends on sizes (tap tables) or on nothing (the 768-entry normalisation table);
+per-pixel arithmetic is the device's.
+"""
+import math
+import os
+from concurrent.futures import ThreadPoolExecutor
+from functools import lru_cache
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import _native as N
+from .datasets import MEAN, STD
+
+PRECISION_BITS = 32 - 8 - 2  # Pillow, libImaging/Resample.c
+
+
+def normalize_lut() -> np.ndarray:
+    """lut[c*256 + v] = (v / 255 - mean_c) / std_c in fp32: ToTensor (``.div(255)``) then Normalize (sub, div), the
+    reference's own expressions evaluated for every possible uint8 value."""
+    v = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    return np.concatenate([((v - np.float32(MEAN[c])) / np.float32(STD[c])).astype(np.float32) for c in range(3)])
+
+
+@lru_cache(maxsize=4096)
+def pil_resize_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the BILINEAR filter (support 1.0), box = the whole axis.
+    Returns (bounds int32 (out, 2) = first input index / tap count, taps int32 (out, ks), ks).  Plain Python floats are
+    IEEE doubles evaluated in the C code's order, so the fixed-point taps are Pillow's bit for bit."""
+    scale = in_size / out_size
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ks = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    taps = np.zeros((out_size, ks), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = []
+        ww = 0.0
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            if t < 0.0:
+                t = -t
+            wv = 1.0 - t if t < 1.0 else 0.0
+            w.append(wv)
+            ww += wv
+        for x in range(xmax):
+            k = w[x] / ww if ww != 0.0 else w[x]
+            taps[xx, x] = int(-0.5 + k * (1 << PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, taps, ks
+
+
+def resize_reference_numpy(img: np.ndarray, S: int) -> np.ndarray:
+    """The same integer arithmetic on the host (numpy): used by the CPU tests to pin ``pil_resize_coeffs`` against
+    ``PIL.Image.resize`` without a GPU.  img (H, W, 3) uint8 -> (S, S, 3) uint8."""
+    H, W, _ = img.shape
+
+    def one_pass(a, n_in, axis_len):  # a: (rows, n_in, 3) -> (rows, S, 3)
+        bounds, taps, ks = pil_resize_coeffs(n_in, S)
+        out = np.empty((a.shape[0], S, 3), np.uint8)
+        for xx in range(S):
+            x0, n = int(bounds[xx, 0]), int(bounds[xx, 1])
+            acc = (a[:, x0:x0 + n, :].astype(np.int64) * taps[xx, :n].astype(np.int64)[None, :, None]).sum(1) + (1 << (PRECISION_BITS - 1))
+            out[:, xx, :] = np.clip(acc >> PRECISION_BITS, 0, 255).astype(np.uint8)
+        return out
+
+    tmp = one_pass(img, W, S)                                       # horizontal first (Resample.c: ImagingResampleInner)
+    return one_pass(tmp.transpose(1, 0, 2), H, S).transpose(1, 0, 2)  # then vertical on the uint8 intermediate
+
+
+def pack_images(images: Sequence[np.ndarray], S: Optional[int], pinned: bool = False):
+    """images: list of (H, W, 3) uint8 arrays -> (pixels u8 tensor, coef int32 tensor, descr u8 tensor, max_h, max_pixels,
+    out_elems).  S = output side for the resize path, None for native resolution."""
+    import ctypes
+    B = len(images)
+    descr = (N.PreImage * B)()
+    offs, off = [], 0
+    for im in images:
+        offs.append(off)
+        off += (im.shape[0] * im.shape[1] * 3 + 15) & ~15
+    mk = (lambda n, dt: torch.empty(n, dtype=dt).pin_memory()) if pinned else (lambda n, dt: torch.empty(n, dtype=dt))
+    pixels = mk(max(off, 16), torch.uint8)
+    pv = pixels.numpy()
+    coef_parts, coef_index, ci = [], {}, 0
+    out_off = 0
+    for b, im in enumerate(images):
+        assert im.dtype == np.uint8 and im.ndim == 3 and im.shape[2] == 3, "decoded images must be (H, W, 3) uint8"
+        h, w = im.shape[:2]
+        pv[offs[b]:offs[b] + h * w * 3] = im.reshape(-1)
+        d = descr[b]
+        d.off, d.H, d.W, d.out_off = offs[b], h, w, out_off
+        out_off += 3 * h * w
+        if S is not None:
+            for n_in, key in ((w, "x"), (h, "y")):
+                if n_in not in coef_index:
+                    bounds, taps, ks = pil_resize_coeffs(n_in, S)
+                    coef_index[n_in] = (ci, ks)
+                    coef_parts += [bounds.reshape(-1), taps.reshape(-1)]
+                    ci += bounds.size + taps.size
+                o, ks = coef_index[n_in]
+                if key == "x":
+                    d.coef_x, d.ksx = o, ks
+                else:
+                    d.coef_y, d.ksy = o, ks
+    coef = mk(max(ci, 1), torch.int32)
+    if ci:
+        coef.numpy()[:ci] = np.concatenate(coef_parts)
+    dt = mk(ctypes.sizeof(descr), torch.uint8)
+    dt.numpy()[:] = np.frombuffer(bytes(descr), np.uint8)
+    return pixels, coef, dt, max(im.shape[0] for im in images), max(im.shape[0] * im.shape[1] for im in images), out_off
+
+
+_LUT = {}
+
+
+def _lut(device):
+    t = _LUT.get(device)
+    if t is None:
+        t = _LUT[device] = torch.from_numpy(normalize_lut()).to(device)
+    return t
+
+
+def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device, pinned: bool = False):
+    """Decoded uint8 images -> normalised fp32 model input on ``device``.  S given: (B, 3, S, S) after the PIL-exact
+    bilinear resize; S None: a list of (1, 3, H, W) tensors at native resolution (views of one buffer)."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("the input pipeline's resize / normalise kernels run on a HIP device (no CPU fallback)")
+    pixels, coef, descr, max_h, max_px, out_elems = pack_images(images, S, pinned)
+    st = torch.cuda.current_stream(device).cuda_stream
+    pd, cd, dd = (t.to(device, non_blocking=True) for t in (pixels, coef, descr))
+    lib = N.load()
+    B = len(images)
+    if S is not None:
+        tmp = torch.empty((B, max_h * S * 3), dtype=torch.uint8, device=device)
+        out = torch.empty((B, 3, S, S), dtype=torch.float32, device=device)
+        N.check(lib.sm_preprocess_resize_u8(pd.data_ptr(), dd.data_ptr(), cd.data_ptr(), _lut(device).data_ptr(), tmp.data_ptr(),
+                                            tmp.stride(0), out.data_ptr(), B, S, max_h, st), "sm_preprocess_resize_u8")
+        return out
+    out = torch.empty(out_elems, dtype=torch.float32, device=device)
+    N.check(lib.sm_preprocess_normalize_u8(pd.data_ptr(), dd.data_ptr(), _lut(device).data_ptr(), out.data_ptr(), B, max_px, st),
+            "sm_preprocess_normalize_u8")
+    views, o = [], 0
+    for im in images:
+        h, w = im.shape[:2]
+        views.append(out[o:o + 3 * h * w].view(1, 3, h, w))
+        o += 3 * h * w
+    return views
+
+
+def decode_item(p_img: str, p_gt: Optional[str]):
+    """Host part of one sample: RGB decode (+ GT decode and binarisation, base_dataset.py:248-255 / duts.py:123,144)."""
+    rgb = np.asarray(Image.open(p_img).convert("RGB"), np.uint8)
+    m = None
+    if p_gt is not None:
+        m = np.asarray(Image.open(p_gt).convert("L"))
+        if m.max() > 1:
+            m = m > 0
+        m = np.ascontiguousarray(m.astype(np.uint8))
+    return rgb, m
+
+
+class PrefetchingLoader:
+    """Batches of a SaliencyTestDataset decoded by ``workers`` host threads, ``depth`` batches ahead of the consumer.
+    Iterating yields (list of rgb uint8 arrays, list of GT uint8 arrays, list of dataset indices)."""
+
+    def __init__(self, dataset, indices: Sequence[int], batch_size: int, workers: Optional[int] = None, depth: int = 3):
+        self.ds, self.idx, self.bs, self.depth = dataset, list(indices), batch_size, max(1, depth)
+        if workers is None:
+            try:
+                workers = len(os.sched_getaffinity(0))
+            except AttributeError:
+                workers = os.cpu_count() or 4
+            workers = max(1, min(32, workers))
+        self.workers = workers
+
+    def __len__(self):
+        return -(-len(self.idx) // self.bs)
+
+    def __iter__(self):
+        batches = [self.idx[s:s + self.bs] for s in range(0, len(self.idx), self.bs)]
+        with ThreadPoolExecutor(max_workers=self.workers) as pool:
+            def submit(k):
+                return [pool.submit(decode_item, self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]]
+            inflight = [submit(k) for k in range(min(self.depth, len(batches)))]
+            for k in range(len(batches)):
+                futs = inflight.pop(0)
+                if k + self.depth < len(batches):
+                    inflight.append(submit(k + self.depth))
+                items = [f.result() for f in futs]
+                yield [it[0] for it in items], [it[1] for it in items], batches[k]

@@ -1,0 +1,58 @@
+"""Device side of the input pipeline (csrc/preprocess.hip) against PIL + the reference's ToTensor / Normalize
+expressions: bit-exact for both the fixed-size (PIL bilinear) and the native-resolution paths, and the Evaluator gives the
+same result rows whichever pipeline feeds it."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+from selfmask_amd import pipeline as P, datasets as DS, MaskFormer, synthetic_state_dict  # noqa: E402
+from selfmask_amd.evaluator import Evaluator  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _host(img, S):
+    """datasets.SaliencyTestDataset.__getitem__'s arithmetic (PIL resize, /255, mean / std in fp32)."""
+    im = Image.fromarray(img)
+    if S is not None:
+        im = im.resize((S, S), Image.BILINEAR)
+    x = np.asarray(im, np.float32) / np.float32(255.0)
+    x = (x - np.asarray(DS.MEAN, np.float32)) / np.asarray(DS.STD, np.float32)
+    return np.ascontiguousarray(x.transpose(2, 0, 1))
+
+
+@pytest.mark.parametrize("S", [224, 384])
+def test_resize_normalise_bit_exact_vs_pil(S):
+    rng = np.random.Generator(np.random.PCG64(S))
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for (h, w) in
+            [(300, 400), (371, 262), (224, 224), (97, 61), (400, 400), (S, S + 1), (1000, 333)]]
+    imgs[1][:100] = 255
+    x = P.preprocess_on_device(imgs, S, DEV).cpu().numpy()
+    for b, im in enumerate(imgs):
+        assert np.array_equal(x[b], _host(im, S)), b
+
+
+def test_native_resolution_bit_exact():
+    rng = np.random.Generator(np.random.PCG64(5))
+    imgs = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for (h, w) in [(301, 399), (64, 64), (1, 7)]]
+    xs = P.preprocess_on_device(imgs, None, DEV)
+    for x, im in zip(xs, imgs):
+        assert x.shape == (1, 3) + im.shape[:2] and np.array_equal(x[0].cpu().numpy(), _host(im, None))
+
+
+@pytest.mark.parametrize("img_size,bs", [(224, 4), (None, 1)])
+def test_evaluator_rows_do_not_depend_on_the_pipeline(tmp_path, img_size, bs):
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 9, seed=4, size_range=(150, 260))
+    m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(5, "soft", patch_size=16), strict=True)
+    ev = Evaluator(network=m.to(DEV), dir_dataset=str(tmp_path))
+    ev.device = torch.device(DEV)
+    r_host = ev("ecssd", dir_ckpt=str(tmp_path / "h"), img_size=img_size, batch_size=bs, device=torch.device(DEV),
+                input_pipeline="host")
+    rows_host = ev.last_rows.copy()
+    r_dev = ev("ecssd", dir_ckpt=str(tmp_path / "d"), img_size=img_size, batch_size=bs, device=torch.device(DEV),
+               input_pipeline="device", workers=3)
+    assert np.array_equal(rows_host, ev.last_rows) and r_host == r_dev

@@ -1,0 +1,70 @@
+"""Host side of the input pipeline (selfmask_amd/pipeline.py) pinned against Pillow and against the reference's
+ToTensor + Normalize expressions - no GPU needed: the device kernels apply exactly these tables in int32 / by look-up."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "salient-object-detection_amd"))
+
+from selfmask_amd import pipeline as P  # noqa: E402
+from selfmask_amd.datasets import MEAN, STD  # noqa: E402
+
+
+@pytest.mark.parametrize("h,w,S", [(300, 400, 224), (371, 262, 224), (224, 224, 224), (97, 61, 224), (400, 300, 384),
+                                   (1000, 333, 224), (225, 223, 224), (30, 500, 64)])
+def test_fixed_point_resize_is_pillow_bit_for_bit(h, w, S):
+    rng = np.random.Generator(np.random.PCG64(h * 1000 + w))
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    img[: h // 3] = (img[: h // 3] // 64) * 64          # flat areas, saturated edges
+    img[-3:, :, 0], img[:, -2:, 1] = 255, 0
+    ref = np.asarray(Image.fromarray(img).resize((S, S), Image.BILINEAR))
+    got = P.resize_reference_numpy(img, S)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} bytes differ (max {int(np.abs(got.astype(int) - ref).max())})"
+
+
+def test_tap_tables_shape_and_normalisation():
+    b, k, ks = P.pil_resize_coeffs(400, 224)
+    assert ks == 5 and b.shape == (224, 2) and k.shape == (224, 5)
+    assert (np.abs(k.sum(1) - (1 << P.PRECISION_BITS)) <= 3).all()          # taps sum to 1.0 in 22-bit fixed point
+    assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= 400).all()
+    b1, k1, _ = P.pil_resize_coeffs(224, 224)                                 # identity resize: one tap of 1.0
+    assert (k1[:, 0] == 1 << P.PRECISION_BITS).all() and (b1[:, 0] == np.arange(224)).all()
+
+
+def test_normalisation_table_is_totensor_then_normalize():
+    lut = P.normalize_lut()
+    v = torch.arange(256, dtype=torch.uint8)
+    for c in range(3):
+        t = v.to(torch.float32).div(255)                                      # TF.to_tensor
+        t = (t - torch.tensor(MEAN[c])) / torch.tensor(STD[c])                # TF.normalize: sub_ then div_
+        assert np.array_equal(lut[c * 256:(c + 1) * 256], t.numpy())
+
+
+def test_pack_images_layout():
+    imgs = [np.full((5, 7, 3), 9, np.uint8), np.full((4, 7, 3), 3, np.uint8)]
+    pixels, coef, descr, max_h, max_px, out_elems = P.pack_images(imgs, 16)
+    assert max_h == 5 and max_px == 35 and out_elems == 3 * (35 + 28)
+    d = np.frombuffer(descr.numpy().tobytes(), dtype=np.dtype([("off", "<i8"), ("out_off", "<i8"), ("H", "<i4"), ("W", "<i4"),
+                                                               ("cx", "<i4"), ("cy", "<i4"), ("ksx", "<i4"), ("ksy", "<i4")]))
+    assert list(d["H"]) == [5, 4] and list(d["W"]) == [7, 7] and d["off"][1] % 16 == 0 and d["out_off"][1] == 105
+    assert d["cx"][0] == d["cx"][1]                                           # equal widths share one tap table
+    assert pixels[int(d["off"][1])] == 3
+
+
+def test_prefetching_loader_order(tmp_path):
+    from selfmask_amd import datasets as DS
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 7, seed=3, size_range=(40, 60))
+    ds = DS.get_dataset(str(tmp_path), "ecssd")
+    seen = []
+    for rgbs, gts, idx in P.PrefetchingLoader(ds, range(len(ds)), batch_size=3, workers=2, depth=2):
+        assert len(rgbs) == len(gts) == len(idx)
+        for rgb, gt, i in zip(rgbs, gts, idx):
+            item = ds[i]
+            assert np.array_equal(gt, item["m"].numpy()) and rgb.shape[:2] == gt.shape and set(np.unique(gt)) <= {0, 1}
+        seen += idx
+    assert seen == list(range(7))
