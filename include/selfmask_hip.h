@@ -238,10 +238,16 @@ typedef struct sm_pre_image {
  * lut[c*256 + v] = (v / 255 - mean_c) / std_c evaluated in fp32 by the host).  tmp: B x tmp_stride bytes of scratch
  * (>= max_h * S * 3 each); out (B, 3, S, S) fp32. */
 int sm_preprocess_resize_u8(const uint8_t* in, const sm_pre_image* images, const int32_t* coef, const float* lut, uint8_t* tmp,
-                            int64_t tmp_stride, float* out, int32_t B, int32_t S, int32_t max_h, void* stream);
+                            int64_t tmp_stride, float* out, uint8_t* resized_u8, int32_t B, int32_t S, int32_t max_h, void* stream);
+/* resized_u8: NULL, or (B, S, S, 3) to also receive the resized uint8 RGB image (the bilateral solver's reference image) */
 /* native resolution (the reference's test mode): ToTensor + Normalize only; image b -> out + images[b].out_off as (3, H, W) */
 int sm_preprocess_normalize_u8(const uint8_t* in, const sm_pre_image* images, const float* lut, float* out, int32_t B,
                                int32_t max_pixels, void* stream);
+
+/* serving selection (SelfMaskInference.predict, app.py:266-284): best[b] = argmax_q objectness[b][q] (first maximum),
+ * out[b] = clip(masks[b][best[b]], 0, 1); masks: image b, query q at + b*mask_stride_b + q*hw (the last decoder layer) */
+int sm_pick_mask_f32(const float* masks, int64_t mask_stride_b, const float* objectness, int64_t obj_stride_b, float* out,
+                     int32_t* best, int32_t B, int32_t nq, int32_t hw, void* stream);
 
 /* ---- evaluator post-processing + metrics ------------------------------------------- */
 typedef struct sm_eval_image {
@@ -274,6 +280,15 @@ typedef struct sm_eval_args {
  * f_max over 255 thresholds, f_mean) / compute_mae / compute_pixel_accuracy / SMeasure (metrics/ *.py) for both. */
 size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq, int32_t mh, int32_t mw, int32_t max_pixels);
 int sm_evaluate_masks_f32(const sm_eval_args* args, void* stream);
+
+/* Refinement glue (BASELINE.json configs[2]: forward -> picked mask -> bilateral solver -> metrics).
+ * sm_upsample_selected_f64: out[b] (OH, OW) fp64 = F.interpolate(masks[b][q_b], size=(OH, OW), mode="bilinear",
+ * align_corners=False) with q_b = (int)rows[b][sel_col] as sm_evaluate_masks_f32 wrote it (14: arg-max objectness, 15:
+ * upper bound) - the `target` of bilateral_solver_output (bilateral_solver.py:152,181).
+ * sm_mask_u8_to_f32: the solver's 0/1 bytes as an fp32 one-query mask for sm_evaluate_masks_f32. */
+int sm_upsample_selected_f64(const float* masks, int64_t mask_stride_b, const float* rows, int32_t sel_col, double* out,
+                             int32_t B, int32_t mh, int32_t mw, int32_t OH, int32_t OW, void* stream);
+int sm_mask_u8_to_f32(const uint8_t* src, float* dst, int64_t n, void* stream);
 
 /* ---- bilateral-solver refinement ---------------------------------------------------- */
 typedef struct sm_bilateral_args {

@@ -505,6 +505,26 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     a.rows[(int64_t)b * 16 + 14 + which] = (float)q;
 }
 
+// ---- refinement glue (BASELINE.json configs[2]): the picked query's mask up-sampled to the solver's resolution as the fp64
+// target bilateral_solver_output expects (bilateral_solver.py:181: target cast to np.double), and the solver's binary
+// result back as an fp32 one-query "mask_pred" for the metric kernels ----------------------------------------------------
+__global__ __launch_bounds__(256) void eval_upsample_selected_kernel(const float* __restrict__ masks, int64_t stride_b,
+                                                                    const float* __restrict__ rows, int sel_col,
+                                                                    double* __restrict__ out, int mh, int mw, int OH, int OW) {
+    const int b = blockIdx.y;
+    const int q = (int)rows[(int64_t)b * 16 + sel_col];  // query index written by eval_finalize_kernel (column 14 / 15)
+    const float* m = masks + (int64_t)b * stride_b + (int64_t)q * mh * mw;
+    const float sy = (float)mh / (float)OH, sx = (float)mw / (float)OW;  // F.interpolate(size=(OH, OW)): in / out
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < OH * OW; p += gridDim.x * 256) {
+        const int y = p / OW, x = p - y * OW;
+        out[(int64_t)b * OH * OW + p] = (double)up_sample(m, mw, up_index(y, sy, mh), up_index(x, sx, mw));
+    }
+}
+
+__global__ __launch_bounds__(256) void eval_u8_to_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
 struct EvalWs { QueryStats *qs, *qpart; GtStats *gs, *gpart; MetricCounts* cnt; double* part; float* maskT; int* sel; float* thr_adapt; size_t total; };
 
 static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
@@ -532,6 +552,23 @@ static const int SM_EVAL_MAX_QUERIES = 960;  // one thread per query in the redu
 extern "C" size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq, int32_t mh, int32_t mw, int32_t max_pixels) {
     if (B <= 0 || nq <= 0 || nq > SM_EVAL_MAX_QUERIES || mh <= 0 || mw <= 0 || max_pixels <= 0 || max_pixels > SM_EVAL_MAX_PIXELS) return 0;
     return sm::carve_eval(B, nq, (max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK, mh * mw, nullptr).total;
+}
+
+extern "C" int sm_upsample_selected_f64(const float* masks, int64_t mask_stride_b, const float* rows, int32_t sel_col, double* out,
+                                        int32_t B, int32_t mh, int32_t mw, int32_t OH, int32_t OW, void* stream) {
+    SM_REQUIRE(masks && rows && out && B > 0 && mh > 0 && mw > 0 && OH > 0 && OW > 0 && (sel_col == 14 || sel_col == 15),
+               "sm_upsample_selected_f64: bad arguments (sel_col 14 = picked query, 15 = upper bound)");
+    const int gx = (OH * OW + 255) / 256 < 256 ? (OH * OW + 255) / 256 : 256;
+    hipLaunchKernelGGL(sm::eval_upsample_selected_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, masks, mask_stride_b, rows,
+                       sel_col, out, mh, mw, OH, OW);
+    return sm::check_launch("sm_upsample_selected_f64");
+}
+
+extern "C" int sm_mask_u8_to_f32(const uint8_t* src, float* dst, int64_t n, void* stream) {
+    SM_REQUIRE(src && dst && n > 0, "sm_mask_u8_to_f32: bad arguments");
+    const int64_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(sm::eval_u8_to_f32_kernel, dim3((int)(g < 2048 ? g : 2048)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return sm::check_launch("sm_mask_u8_to_f32");
 }
 
 extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {

@@ -270,6 +270,30 @@ extern "C" int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float
     return sm::check_launch("sm_rowdot_sigmoid_f32");
 }
 
+namespace sm {
+// serving path (app.py:266-284): best = argmax(objectness) (first maximum, as torch.argmax), out = clip(mask[best], 0, 1)
+__global__ __launch_bounds__(256) void pick_mask_kernel(const float* __restrict__ masks, int64_t mask_stride_b,
+                                                       const float* __restrict__ obj, int64_t obj_stride_b, float* __restrict__ out,
+                                                       int* __restrict__ best_out, int nq, int hw) {
+    const int b = blockIdx.y;
+    const float* o = obj + (int64_t)b * obj_stride_b;
+    int best = 0;
+    for (int q = 1; q < nq; ++q)
+        if (o[q] > o[best]) best = q;  // every thread repeats the nq-long scan (nq = 20): no shared memory, no divergence
+    if (blockIdx.x == 0 && threadIdx.x == 0) best_out[b] = best;
+    const float* m = masks + (int64_t)b * mask_stride_b + (int64_t)best * hw;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) out[(int64_t)b * hw + p] = fminf(fmaxf(m[p], 0.f), 1.f);
+}
+}  // namespace sm
+
+extern "C" int sm_pick_mask_f32(const float* masks, int64_t mask_stride_b, const float* objectness, int64_t obj_stride_b,
+                                float* out, int32_t* best, int32_t B, int32_t nq, int32_t hw, void* stream) {
+    SM_REQUIRE(masks && objectness && out && best && B > 0 && nq > 0 && hw > 0, "sm_pick_mask_f32: bad arguments");
+    hipLaunchKernelGGL(sm::pick_mask_kernel, dim3((hw + 255) / 256 < 64 ? (hw + 255) / 256 : 64, B), dim3(256), 0,
+                       (hipStream_t)stream, masks, mask_stride_b, objectness, obj_stride_b, out, best, nq, hw);
+    return sm::check_launch("sm_pick_mask_f32");
+}
+
 extern "C" int sm_query_mean_f32(const float* queries, float* features, int32_t B, int32_t L, int32_t nq, void* stream) {
     SM_REQUIRE(queries && features && B > 0 && L > 0 && nq > 0, "sm_query_mean_f32: bad arguments");
     hipLaunchKernelGGL(sm::query_mean_kernel, dim3(B * (SM_EMBED / 128)), dim3(128), 0, (hipStream_t)stream, queries, features, L, nq);

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void pp_resize_h_kernel(const unsigned char* _
 // vertical pass + ToTensor + Normalize: out[b][c][yy][xx] = lut[c][clip8(2^21 + sum_y tmp[b][ymin + y][xx][c] * k[yy][y])]
 __global__ __launch_bounds__(256) void pp_resize_v_norm_kernel(const unsigned char* __restrict__ tmp, const sm_pre_image* __restrict__ imgs,
                                                               const int* __restrict__ coef, const float* __restrict__ lut,
-                                                              float* __restrict__ out, int S, int64_t tmp_stride) {
+                                                              float* __restrict__ out, unsigned char* __restrict__ u8_out, int S,
+                                                              int64_t tmp_stride) {
     __shared__ float slut[768];
     for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
     __syncthreads();
@@ -68,9 +69,14 @@ __global__ __launch_bounds__(256) void pp_resize_v_norm_kernel(const unsigned ch
     }
     const int64_t plane = (int64_t)S * S;
     float* o = out + (int64_t)b * 3 * plane + (int64_t)yy * S + xx;
-    o[0] = slut[pp_clip8(s0)];
-    o[plane] = slut[256 + pp_clip8(s1)];
-    o[2 * plane] = slut[512 + pp_clip8(s2)];
+    const unsigned char r0 = pp_clip8(s0), r1 = pp_clip8(s1), r2 = pp_clip8(s2);
+    o[0] = slut[r0];
+    o[plane] = slut[256 + r1];
+    o[2 * plane] = slut[512 + r2];
+    if (u8_out) {  // the resized RGB image itself (H, W, 3): reference image of the bilateral solver
+        unsigned char* u = u8_out + ((int64_t)b * plane + (int64_t)yy * S + xx) * 3;
+        u[0] = r0; u[1] = r1; u[2] = r2;
+    }
 }
 
 // native resolution (the reference's test mode): ToTensor + Normalize only; one image per blockIdx.y, out[b] at out_off
@@ -93,14 +99,14 @@ __global__ __launch_bounds__(256) void pp_normalize_kernel(const unsigned char* 
 }  // namespace sm
 
 extern "C" int sm_preprocess_resize_u8(const uint8_t* in, const sm_pre_image* images, const int32_t* coef, const float* lut,
-                                       uint8_t* tmp, int64_t tmp_stride, float* out, int32_t B, int32_t S, int32_t max_h,
-                                       void* stream) {
+                                       uint8_t* tmp, int64_t tmp_stride, float* out, uint8_t* resized_u8, int32_t B, int32_t S,
+                                       int32_t max_h, void* stream) {
     SM_REQUIRE(in && images && coef && lut && tmp && out, "sm_preprocess_resize_u8: null pointer");
     SM_REQUIRE(B > 0 && S > 0 && max_h > 0 && tmp_stride >= (int64_t)max_h * S * 3, "sm_preprocess_resize_u8: bad shape / tmp_stride");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sm::pp_resize_h_kernel, dim3((S + 255) / 256, max_h, B), dim3(256), 0, st, in, images, coef, tmp, S, tmp_stride);
-    hipLaunchKernelGGL(sm::pp_resize_v_norm_kernel, dim3((S + 255) / 256, S, B), dim3(256), 0, st, tmp, images, coef, lut, out, S,
-                       tmp_stride);
+    hipLaunchKernelGGL(sm::pp_resize_v_norm_kernel, dim3((S + 255) / 256, S, B), dim3(256), 0, st, tmp, images, coef, lut, out,
+                       resized_u8, S, tmp_stride);
     return sm::check_launch("sm_preprocess_resize_u8");
 }
 

@@ -19,4 +19,7 @@ def __getattr__(name):  # lazy: `python -m selfmask_amd.evaluator` must not find
     if name == "Evaluator":
         from .evaluator import Evaluator
         return Evaluator
+    if name == "SelfMaskInference":
+        from .inference import SelfMaskInference
+        return SelfMaskInference
     raise AttributeError(name)

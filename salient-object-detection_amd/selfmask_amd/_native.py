@@ -141,8 +141,11 @@ SYMBOLS = {
     "sm_upsample2x_logits_sigmoid_f32": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, fp]),
     "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
-    "sm_preprocess_resize_u8": (C.c_int, [fp, fp, fp, fp, fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_preprocess_resize_u8": (C.c_int, [fp, fp, fp, fp, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_upsample_selected_f64": (C.c_int, [fp, C.c_int64, fp, C.c_int32, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_mask_u8_to_f32": (C.c_int, [fp, fp, C.c_int64, fp]),
     "sm_preprocess_normalize_u8": (C.c_int, [fp, fp, fp, fp, C.c_int32, C.c_int32, fp]),
+    "sm_pick_mask_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),

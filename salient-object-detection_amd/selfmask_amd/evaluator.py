@@ -34,11 +34,15 @@ class Evaluator(BaseStructure):
     def __call__(self, dataset_name: str, dir_ckpt: str, img_size: Optional[int] = None, scale_factor: int = 2,
                  batch_size: int = 1, device: torch.device = torch.device("cuda:0"), cost_type: str = "iou",
                  comm=None, streams: int = DEFAULT_STREAMS, hip_graph: bool = True, input_pipeline: str = "device",
-                 workers: Optional[int] = None) -> dict:
+                 workers: Optional[int] = None, refine: Optional[str] = None) -> dict:
         """evaluator.pyc@L164-309.  Extra keyword arguments (not in the reference): ``comm`` / ``streams`` / ``hip_graph``
         (image sharding, batches in flight, graph replay) and ``input_pipeline``: "device" (default) decodes on a pool of
         ``workers`` host threads running ahead of the GPU and does resize + ToTensor + Normalize in HIP kernels
-        (pipeline.py, bit-identical inputs), "host" is the reference's order of work: one thread, PIL + numpy per image."""
+        (pipeline.py, bit-identical inputs), "host" is the reference's order of work: one thread, PIL + numpy per image.
+        ``refine="bilateral"`` (batched mode only; BASELINE.json configs[2]): the picked query's mask is up-sampled to the
+        S x S input, refined by ``bilateral_solver_output`` (bilateral_solver.py:152-193) against the resized RGB image -
+        the whole batch in one launch sequence - and the solver's binary mask is scored by the same metric kernels; the
+        returned dict gains the seven ``*_refined`` values and ``metrics_<dataset>_refined.txt`` is written."""
         assert cost_type == "iou", "the upper bound is chosen by IoU (evaluator.pyc@L216); other costs are unused"
         if not getattr(self.model, "use_binary_classifier", True):
             raise RuntimeError("the evaluator dereferences objectness unconditionally (evaluator.pyc@L219): "
@@ -55,7 +59,12 @@ class Evaluator(BaseStructure):
         scale = 0.0 if img_size is not None else float(patch // scale_factor)
         if img_size is None and batch_size != 1:
             raise ValueError("native-resolution evaluation runs at batch_size=1 (images differ in size)")
+        if refine not in (None, "bilateral"):
+            raise ValueError(f"refine={refine!r}: None or 'bilateral'")
+        if refine and (img_size is None or input_pipeline != "device"):
+            raise ValueError("refine='bilateral' runs in the batched mode (img_size given) on the device input pipeline")
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
+        rows_refined = torch.empty((len(mine), 16), dtype=torch.float32, device=device) if refine else None
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
         # recurring batch shapes replay one captured hipGraph per stream instead of 171 launches (graphs.py)
         # native-resolution mode meets a new shape with almost every image: graphs would only thrash there
@@ -77,15 +86,27 @@ class Evaluator(BaseStructure):
 
         for s, x, gts in batches():
             with ring.next():
+                u8 = None
                 if isinstance(x, tuple):  # decoded uint8 images: resize / normalise on this batch's stream
                     rgbs, pre = x
-                    x = pre(rgbs, img_size, device, pinned=True)
-                    x = x if img_size is not None else x[0]
+                    if refine:
+                        x, u8 = pre(rgbs, img_size, device, pinned=True, return_u8=True)
+                    else:
+                        x = pre(rgbs, img_size, device, pinned=True)
+                        x = x if img_size is not None else x[0]
                 out = self._forward({"x": x}, device=device)
                 mask_pred, obj = out["mask_pred"], out.get("objectness")
                 if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
                     mask_pred, obj = mask_pred[:, -1], obj[:, -1]
-                rows_local[s:s + len(gts)] = ops.evaluate_masks(mask_pred, obj.squeeze(-1), [g.to(device) for g in gts], scale=scale)
+                gtb = ops.GtBatch([g.to(device) for g in gts], device)
+                rows = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gtb, scale=scale)
+                rows_local[s:s + len(gts)] = rows
+                if refine:
+                    from .bilateral_solver import bilateral_solver_batch_device
+                    target = ops.upsample_selected(mask_pred, rows, (img_size, img_size), "pick")
+                    _, binary = bilateral_solver_batch_device(u8, target)
+                    refined = ops.mask_u8_to_f32(binary).unsqueeze(1)  # one "query" per image; its objectness is moot
+                    rows_refined[s:s + len(gts)] = ops.evaluate_masks(refined, rows[:, 0:1], gtb, scale=0.0)
         ring.join()
         self.graph_stats = {"captures": self._graphed.captures, "replays": self._graphed.replays,
                             "failed": self._graphed.failed}
@@ -102,6 +123,15 @@ class Evaluator(BaseStructure):
                 f.write(",".join(str(results[k + sfx]) for sfx in ("", "_ub") for k in
                                  ("iou", "pixel_accuarcy", "f_score", "f_max", "f_mean", "mae", "s_measure")))
         self.last_rows = rows
+        if refine:
+            rr = gather_rows(rows_refined, mine, n_total, comm)
+            ref = average_rows(rr)
+            results.update({k + "_refined": ref[k] for k in KEYS})
+            self.last_rows_refined = rr
+            if comm.rank == 0:
+                with open(os.path.join(dir_ckpt, f"metrics_{dataset_name}_refined.txt"), "w") as f:
+                    f.write("iou,pixel_acc,f_score,f_max,f_mean,mae,s_measure\n")
+                    f.write(",".join(str(ref[k]) for k in ("iou", "pixel_accuarcy", "f_score", "f_max", "f_mean", "mae", "s_measure")))
         return results
 
 

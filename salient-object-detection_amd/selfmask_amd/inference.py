@@ -1,0 +1,115 @@
+"""Mirror of the reference's serving class ``SelfMaskInference`` (app.py:161-347), the call pattern behind POST /predict:
+``T.Resize((224, 224)) -> ToTensor -> Normalize -> BaseStructure._forward -> last decoder layer -> arg-max objectness ->
+clip(mask, 0, 1)`` at batch 1.
+
+On the MI355X the whole of it after the image decode is device work: the Pillow-exact resize + normalisation kernels
+(pipeline.py), the forward replayed from ONE captured hipGraph (batch 1 is launch-bound: ~170 kernels of a few
+microseconds), and a selection kernel - one small D2H copy of (index, 20 scores, mask) leaves the GPU.  The web shell
+around it (Flask, base64 PNG encoding, LANCZOS resize to the upload's size, jet heat map) is product code outside the hot
+path: ``predict()`` still returns the reference's response keys, built on the host from ``predict_tensors()``.
+"""
+import base64
+from argparse import Namespace
+from io import BytesIO
+from typing import Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image
+
+from . import _native as N
+from .base_structure import BaseStructure
+from .graphs import GraphedForward
+from .maskformer import load_checkpoint
+from .misc import get_model
+from .pipeline import preprocess_on_device
+
+
+class SelfMaskInference:
+    def __init__(self, model_path: Optional[str], config_path: Union[str, dict, Namespace], device: Optional[torch.device] = None,
+                 model: Optional[torch.nn.Module] = None, hip_graph: bool = True):
+        """app.py:162-211.  ``config_path``: the reference's YAML (or an already parsed dict / Namespace); ``model_path``: a
+        checkpoint in either of the reference's forms ({'model': state_dict} as app.py:185-186 expects, or a raw
+        state_dict).  ``model=`` injects a ready module instead (tests, benchmarks: there is no checkpoint offline)."""
+        if isinstance(config_path, str):
+            import yaml
+            with open(config_path, "r") as f:
+                config_path = yaml.safe_load(f)
+        self.config = Namespace(**config_path) if isinstance(config_path, dict) else config_path
+        self.device = device if device is not None else torch.device("cuda:0")
+        if self.device.type != "cuda":
+            raise RuntimeError("SelfMaskInference (MI355X) needs a HIP device; there is no CPU fallback")
+        if model is None:
+            model = get_model(arch="maskformer", configs=self.config)
+            if model_path is not None:
+                load_checkpoint(model, model_path)
+        self.model = model.to(self.device).eval()
+        self.base_structure = BaseStructure(model=self.model, device=self.device)
+        self.input_size = 224  # T.Resize((224, 224)), app.py:199
+        # batch 1, one shape: capture at the first call, replay ever after
+        self.base_structure._graphed = GraphedForward(self.model, enabled=hip_graph, max_graphs=2, admit_after=0)
+
+    # ---- host: whatever arrives -> (H, W, 3) uint8 ------------------------------------------------------------------------
+    @staticmethod
+    def _to_rgb_array(image) -> np.ndarray:
+        """app.py:215-219: a werkzeug FileStorage (anything with ``.stream``), a file object / path, a PIL image or an
+        array - converted to RGB."""
+        if hasattr(image, "stream"):
+            image = Image.open(image.stream)
+        elif isinstance(image, (str, bytes)) or hasattr(image, "read"):
+            image = Image.open(image)
+        elif isinstance(image, np.ndarray):
+            image = Image.fromarray(image)
+        return np.asarray(image.convert("RGB"), np.uint8)
+
+    def preprocess_image(self, image) -> torch.Tensor:
+        """app.py:213-238 -> (1, 3, 224, 224) on the device; resize / ToTensor / Normalize run in HIP kernels."""
+        return preprocess_on_device([self._to_rgb_array(image)], self.input_size, self.device, pinned=True)
+
+    # ---- device: the hot path -------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def predict_tensors(self, image) -> dict:
+        """The arithmetic of ``predict`` (app.py:241-284): {"best_idx", "objectness_scores" (nq,), "mask" (2g, 2g) in [0, 1]}."""
+        x = self.preprocess_image(image)
+        out = self.base_structure._forward({"x": x})
+        mask_pred, obj = out["mask_pred"], out.get("objectness")
+        if obj is None:
+            raise RuntimeError("the serving path selects by objectness (app.py:268-276): use_binary_classifier=True")
+        last, last_obj = mask_pred[:, -1], obj[:, -1, :, 0]
+        nq, h, w = last.shape[1:]
+        best_mask = torch.empty((1, h, w), dtype=torch.float32, device=self.device)
+        best = torch.empty(1, dtype=torch.int32, device=self.device)
+        N.check(N.load().sm_pick_mask_f32(last.data_ptr(), last.stride(0), last_obj.data_ptr(), last_obj.stride(0),
+                                          best_mask.data_ptr(), best.data_ptr(), 1, nq, h * w,
+                                          torch.cuda.current_stream(self.device).cuda_stream), "sm_pick_mask_f32")
+        scores = last_obj[0].cpu().numpy()  # (these D2H copies synchronise the stream: the request is done)
+        return {"best_idx": int(best.cpu()[0]), "objectness_scores": scores, "mask": best_mask[0].cpu().numpy()}
+
+    # ---- host: the reference's response ---------------------------------------------------------------------------------------
+    def predict(self, image) -> dict:
+        """app.py:241-347: same keys ('original', 'mask', 'heatmap' as base64 PNG data URLs, 'objectness_scores')."""
+        rgb = self._to_rgb_array(image)
+        if hasattr(image, "stream"):
+            image.stream.seek(0)
+        t = self.predict_tensors(rgb)
+        original = Image.fromarray(rgb)
+        mask_img = Image.fromarray((t["mask"] * 255).astype(np.uint8)).resize(original.size, Image.Resampling.LANCZOS)
+        heat = None
+        try:  # the jet colour map comes from matplotlib in the reference (app.py:296-304); optional here
+            import matplotlib.pyplot as plt
+            from PIL import ImageEnhance
+            rgba = (plt.get_cmap("jet")(np.array(mask_img) / 255.0) * 255).astype(np.uint8)
+            heat_img = Image.fromarray(rgba).convert("RGBA").resize(original.size, Image.Resampling.LANCZOS)
+            heat = ImageEnhance.Brightness(Image.blend(original.convert("RGBA"), heat_img, alpha=0.5)).enhance(1.1)
+        except ImportError:
+            pass
+
+        def url(img):
+            if img is None:
+                return None
+            buf = BytesIO()
+            img.save(buf, format="PNG")
+            return "data:image/png;base64," + base64.b64encode(buf.getvalue()).decode()
+
+        return {"original": url(original), "mask": url(mask_img), "heatmap": url(heat),
+                "objectness_scores": t["objectness_scores"], "best_idx": t["best_idx"]}

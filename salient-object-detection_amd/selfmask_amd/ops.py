@@ -343,3 +343,26 @@ def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, 
     a.max_pixels = max_pixels
     N.check(lib.sm_evaluate_masks_f32(a, _stream()), "sm_evaluate_masks_f32")
     return (rows, ious) if return_ious else rows
+
+
+def upsample_selected(mask_pred_last: torch.Tensor, rows: torch.Tensor, size, which: str = "pick") -> torch.Tensor:
+    """(B, nq, mh, mw) probabilities + the (B, 16) rows of evaluate_masks -> (B, OH, OW) float64: the picked ("pick") or
+    upper-bound ("ub") query's mask up-sampled bilinearly to ``size`` - the bilateral solver's target."""
+    _dev(mask_pred_last, rows)
+    B, nq, mh, mw = mask_pred_last.shape
+    assert mask_pred_last.stride(3) == 1 and mask_pred_last.stride(2) == mw and mask_pred_last.stride(1) == mh * mw
+    assert rows.shape == (B, 16) and rows.is_contiguous()
+    out = torch.empty((B, size[0], size[1]), dtype=torch.float64, device=mask_pred_last.device)
+    N.check(N.load().sm_upsample_selected_f64(mask_pred_last.data_ptr(), mask_pred_last.stride(0), rows.data_ptr(),
+                                              14 if which == "pick" else 15, out.data_ptr(), B, mh, mw, size[0], size[1],
+                                              _stream()), "sm_upsample_selected_f64")
+    return out
+
+
+def mask_u8_to_f32(m: torch.Tensor) -> torch.Tensor:
+    if not m.is_cuda or m.dtype != torch.uint8:
+        raise RuntimeError("mask_u8_to_f32 takes a uint8 tensor on a HIP device")
+    m = m.contiguous()
+    out = torch.empty(m.shape, dtype=torch.float32, device=m.device)
+    N.check(N.load().sm_mask_u8_to_f32(m.data_ptr(), out.data_ptr(), m.numel(), _stream()), "sm_mask_u8_to_f32")
+    return out

@@ -138,9 +138,10 @@ def _lut(device):
     return t
 
 
-def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device, pinned: bool = False):
+def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device, pinned: bool = False, return_u8: bool = False):
     """Decoded uint8 images -> normalised fp32 model input on ``device``.  S given: (B, 3, S, S) after the PIL-exact
-    bilinear resize; S None: a list of (1, 3, H, W) tensors at native resolution (views of one buffer)."""
+    bilinear resize (``return_u8``: also the resized uint8 images (B, S, S, 3)); S None: a list of (1, 3, H, W) tensors at
+    native resolution (views of one buffer)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("the input pipeline's resize / normalise kernels run on a HIP device (no CPU fallback)")
@@ -152,9 +153,11 @@ def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device,
     if S is not None:
         tmp = torch.empty((B, max_h * S * 3), dtype=torch.uint8, device=device)
         out = torch.empty((B, 3, S, S), dtype=torch.float32, device=device)
+        u8 = torch.empty((B, S, S, 3), dtype=torch.uint8, device=device) if return_u8 else None
         N.check(lib.sm_preprocess_resize_u8(pd.data_ptr(), dd.data_ptr(), cd.data_ptr(), _lut(device).data_ptr(), tmp.data_ptr(),
-                                            tmp.stride(0), out.data_ptr(), B, S, max_h, st), "sm_preprocess_resize_u8")
-        return out
+                                            tmp.stride(0), out.data_ptr(), u8.data_ptr() if return_u8 else None, B, S, max_h, st),
+                "sm_preprocess_resize_u8")
+        return (out, u8) if return_u8 else out
     out = torch.empty(out_elems, dtype=torch.float32, device=device)
     N.check(lib.sm_preprocess_normalize_u8(pd.data_ptr(), dd.data_ptr(), _lut(device).data_ptr(), out.data_ptr(), B, max_px, st),
             "sm_preprocess_normalize_u8")

@@ -27,8 +27,11 @@ def timeit(fn):
 
 for name, Nn, K, epi, osplit, res in SHAPES:
     g = torch.Generator().manual_seed(1)
-    a = ops.split_f16x2(torch.randn(M, K, generator=g).to(dev))
+    zero = os.environ.get("ZERO") == "1"  # all-zero operands: same instruction stream, far less switching power
+    a = ops.split_f16x2((torch.randn(M, K, generator=g) * (0.0 if zero else 1.0)).to(dev))
     w = (torch.randn(Nn, K, generator=g) * 0.03).to(dev)
+    if zero:
+        w = w * 0.0 + 1e-30
     b = torch.randn(Nn, generator=g).to(dev)
     w_s, (w16, ws) = ops.split_f16x2(w), ops.split_w16(w)
     out = torch.empty(1, M, Nn, device=dev)

@@ -111,3 +111,52 @@ def test_batches_in_flight_on_several_streams_give_identical_rows(tmp_path):
     assert np.array_equal(rows[0], rows[1]) and np.array_equal(rows[0], rows[2])
     ev("duts", dir_ckpt=str(tmp_path / "eager"), img_size=224, batch_size=3, device=DEV, streams=2, hip_graph=False)
     assert np.array_equal(rows[0], ev.last_rows) and ev.graph_stats["replays"] == 0
+
+
+def test_reference_mode_16_ecssd_images_patch16(tmp_path):
+    """configs[0] as BASELINE.json words it: ViT-S/16, nq = 20, batch 1, native resolution (the evaluator's hard-coded x4
+    generalised to patch_size // scale_factor = 8, SURVEY.md 0.1)."""
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 16, seed=17, size_range=(120, 200))
+    model, sd = _model(16, 24)
+    ev = Evaluator(network=model, dir_dataset=str(tmp_path))
+    ev.device = DEV
+    res = ev("ecssd", dir_ckpt=str(tmp_path / "ckpt"), scale_factor=2, batch_size=1, device=DEV)
+    ref_rows = _oracle_pipeline(DS.get_dataset(str(tmp_path), "ecssd"), sd, 16, scale_factor=8)
+    _check(res, ev.last_rows, ref_rows)
+    assert ev.graph_stats["captures"] == 0  # native resolution: a new shape per image, graphs stay off
+
+
+def test_configs2_384_bilateral_refinement_end_to_end(tmp_path):
+    """BASELINE.json configs[2]: 384^2 inputs, picked mask -> x8 up-sample -> bilateral solver (the whole batch in one
+    launch sequence) -> metrics of the refined binary mask, against the oracle chained the same way (oracle forward ->
+    post-processing -> F.interpolate x8 -> numpy solver restatement -> metrics)."""
+    from oracle import bilateral_oracle as BO
+    from PIL import Image
+    import torch.nn.functional as F
+    S, n_img = 384, 3
+    DS.write_synthetic_dataset(str(tmp_path), "duts", n_img, seed=31, size_range=(300, 400))
+    model, sd = _model(16, 26)
+    ev = Evaluator(network=model, dir_dataset=str(tmp_path))
+    ev.device = DEV
+    res = ev("duts", dir_ckpt=str(tmp_path / "ckpt"), img_size=S, batch_size=n_img, device=DEV, refine="bilateral", workers=2)
+    ds = DS.get_dataset(str(tmp_path), "duts", eval_img_size=S)
+    rows_ref, rows_refined_ref, flips = [], [], []
+    for i in range(n_img):
+        it = ds[i]
+        out = O.forward(it["x"][None], sd, 16)
+        gt = it["m"].to(torch.int64)
+        pm, q, ub, _ = E.postprocess(out["mask_pred"][0, -1], out["objectness"][0, -1, :, 0], gt, scale_factor=None)
+        rows_ref.append(np.concatenate([E.all_metrics(pm[q], gt), E.all_metrics(pm[ub], gt), [q, ub]]))
+        target = F.interpolate(out["mask_pred"][0, -1, q][None, None], size=(S, S), mode="bilinear", align_corners=False)[0, 0]
+        rgb = np.asarray(Image.open(ds.p_imgs[i]).convert("RGB").resize((S, S), Image.BILINEAR))
+        soft, binary = BO.bilateral_solver_output(rgb, target.double().numpy())
+        refined = F.interpolate(torch.from_numpy(binary.astype(np.float32))[None, None], size=tuple(gt.shape), mode="bilinear",
+                                align_corners=False)[0, 0]
+        rows_refined_ref.append(E.all_metrics(refined, gt))
+    _check({k: v for k, v in res.items() if not k.endswith("_refined")}, ev.last_rows, np.array(rows_ref))
+    got = ev.last_rows_refined[:, :7]
+    ref = np.array(rows_refined_ref)
+    print("\nconfigs[2] refined metrics (hip | oracle):\n", np.round(got, 5), "\n", np.round(ref, 5))
+    assert np.abs(got - ref).max() <= 2e-3
+    assert set(res) == {k + s for k in D.KEYS for s in ("", "_ub", "_refined")}
+    assert os.path.exists(tmp_path / "ckpt" / "metrics_duts_refined.txt")
