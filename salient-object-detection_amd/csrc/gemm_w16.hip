@@ -332,6 +332,244 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
     }
 }
 
+// ---- persistent variant ----------------------------------------------------------------------------------------------------
+// What the one-tile-per-workgroup kernel above cannot hide: every workgroup of a launch starts
+// together, so all of them wait for their first K-tiles together, run their MFMA loops together and write their C tiles
+// together - the epilogue's HBM burst and the prologue's DMA latency are dead time for the matrix cores (a 128 x 128 tile
+// with K = 384 lives 12 K-tiles: prologue + epilogue are a third of its life).  Here min(tiles, 512) workgroups stay
+// resident (two per CU) and walk the tile list with a stride:
+//   * the LAST K-tile iteration of a tile issues the FIRST K-tile of the workgroup's next tile into the ring slot that is
+//     already free, so that DMA flies under the epilogue (which is staged in the other slot, unpadded + XOR-swizzled to fit);
+//   * the second resident workgroup of every CU starts half a tile late (one s_sleep loop, once per launch), so one
+//     workgroup's epilogue runs beside the other's MFMA loop instead of beside its epilogue.
+// 128 x 128 tile, eight waves of 64 x 32, 32-k stages, two ring slots (64 KiB); K / 32 must be even (slot parity).
+template <int WPS>
+__global__ __launch_bounds__(512, WPS) void gemm_w16_persist_kernel(sm_gemm_args g, int n_tiles, int stagger) {
+    constexpr int BM = 128, BN = 128, KT = 32, NWM = 2, NWN = 4, NW = 8, WTM = 64, WTN = 32, TM = 2, TN = 1;
+    constexpr int ROWB = 128, A_INST = 2, W_INST = 2, NI = 4;
+    constexpr int A_STAGE = BM * ROWB, W_STAGE = BN * ROWB, W_RING = 2 * A_STAGE;
+    extern __shared__ __attribute__((aligned(16))) char smemp[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r = lane & 31, h = lane >> 5;
+    const int M = g.M, N = g.N;
+    const int ntn = (N + BN - 1) / BN;
+    const int nk = g.K / KT;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smemp;
+    const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                        (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
+    const float ws = g.w_scale;
+    const bool out_split = g.patch_n < 0;
+
+    // virtual tile id -> (m0, n0): XCD-aware order over the whole list (ids 8 apart share an XCD; gridDim.x % 8 == 0)
+    auto tile_origin = [&](int vid, int& m0, int& n0) {
+        const int q8 = n_tiles >> 3, r8 = n_tiles & 7, xcd = vid & 7, slot = vid >> 3;
+        const int t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        n0 = (t % ntn) * BN;
+        m0 = (t / ntn) * BM;
+    };
+    struct Src { const char* a[A_INST]; const char* w[W_INST]; };
+    auto make_src = [&](int m0, int n0, Src& s) {
+        const char* A = reinterpret_cast<const char*>((g.alt_from_n > 0 && n0 >= g.alt_from_n) ? g.A_alt : g.A);
+        const char* W = reinterpret_cast<const char*>(g.W);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) {
+            const int row = (wave * A_INST + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            s.a[i] = A + ((int64_t)gm * g.lda) * 4 + c * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < W_INST; ++i) {
+            const int row = (wave * W_INST + i) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int gn = n0 + row;
+            gn = gn < N ? gn : N - 1;
+            s.w[i] = W + ((int64_t)gn * g.ldw) * 4 + c * 16;
+        }
+    };
+    auto issue = [&](const Src& s, int kt, int slot) {
+        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + wave * W_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < W_INST; ++i) lds_dma16(s.w[i] + kt * ROWB, sw + i * 1024);
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + wave * A_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) lds_dma16(s.a[i] + kt * ROWB, sa + i * 1024);
+    };
+    const int swz = (r >> 1) & 7;
+    int off_hi[2], off_lo[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        off_hi[s] = ((2 * (2 * s + h)) ^ swz) * 16;
+        off_lo[s] = ((2 * (2 * s + h) + 1) ^ swz) * 16;
+    }
+    const int a_row = (wm * WTM + r) * ROWB;
+    const int w_row = (wn * WTN + r) * ROWB;
+    // epilogue staging of this wave: 32 rows x 128 B inside ring slot 1 (waves 0-3 in the A half, 4-7 in the W half)
+    char* ep = smemp + (wave < 4 ? A_STAGE + wave * 4096 : W_RING + W_STAGE + (wave - 4) * 4096);
+
+    int vid = blockIdx.x;
+    if (vid >= n_tiles) return;
+    if (stagger > 0 && ((blockIdx.x >> 8) & 1)) {  // the second resident workgroup of a CU: start half a tile late
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);  // ~512 clocks each
+    }
+    int m0, n0;
+    tile_origin(vid, m0, n0);
+    Src cur, nxt;
+    make_src(m0, n0, cur);
+    issue(cur, 0, 0);
+    while (true) {
+        const int vnext = vid + gridDim.x;
+        const bool has_next = vnext < n_tiles;
+        int m1 = 0, n1 = 0;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][0][v] = 0.f;
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt_w<0>();              // K-tile kt has landed (and, at kt = 0, the previous tile's stores are acknowledged)
+            __builtin_amdgcn_s_barrier();   // ... for every wave; every wave is done with the slot refilled next (at kt = 0:
+            __builtin_amdgcn_sched_barrier(0);  //     with the epilogue staging in slot 1)
+            if (kt + 1 < nk) issue(cur, kt + 1, (kt + 1) & 1);
+            else if (has_next) {  // nk is even: slot 0 is free during the last K-tile and the epilogue
+                tile_origin(vnext, m1, n1);
+                make_src(m1, n1, nxt);  // (computed here, not at the tile's start: 16 fewer live registers in the loop)
+                issue(nxt, 0, 0);
+            }
+            const char* sta = smemp + (kt & 1) * A_STAGE;
+            const char* stw = smemp + W_RING + (kt & 1) * W_STAGE;
+            f16x8 ah[2][TM], al[2][TM], wh[2], wl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                wh[s] = *reinterpret_cast<const f16x8*>(stw + w_row + off_hi[s]);
+                wl[s] = *reinterpret_cast<const f16x8*>(stw + w_row + off_lo[s]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[s][i] = *reinterpret_cast<const f16x8*>(sta + a_row + i * 32 * ROWB + off_hi[s]);
+                    al[s][i] = *reinterpret_cast<const f16x8*>(sta + a_row + i * 32 * ROWB + off_lo[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 whs = wh[s] * down;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], ah[s][i], acc[i][0], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], ah[s][i], acc[i][0], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whs, al[s][i], acc[i][0], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // every wave is done reading slot 1 (nk - 1 is odd): it becomes the epilogue's staging
+
+        // ---- epilogue (same arithmetic and order as gemm_w16_kernel; staging rows are 128 B, piece p of row r at p ^ (r & 7))
+        auto run = [&](auto epi_tag, auto fmt_tag) {
+            constexpr int EPI = decltype(epi_tag)::value;
+            constexpr bool F = decltype(fmt_tag)::value;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (F) {
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        float x[4], y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int nx = n0 + wn * WTN + 8 * q + 4 * h + e, ny = nx + 8;
+                            x[e] = acc[i][0][4 * q + e] * ws + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
+                            y[e] = acc[i][0][4 * q + 4 + e] * ws + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
+                            if constexpr (EPI == SM_EPI_GELU) {
+                                x[e] = 0.5f * x[e] * (1.0f + fast_erff(x[e] * 0.70710678118654752440f));
+                                y[e] = 0.5f * y[e] * (1.0f + fast_erff(y[e] * 0.70710678118654752440f));
+                            } else if constexpr (EPI == SM_EPI_RELU) {
+                                x[e] = fmaxf(x[e], 0.f);
+                                y[e] = fmaxf(y[e], 0.f);
+                            }
+                        }
+                        pair_groups(x, y);  // this lane now owns the whole 8-element group q + h: pieces 2 (q + h), + 1
+                        f16x4 h0, l0, h1, l1;
+                        split4(x, h0, l0);
+                        split4(y, h1, l1);
+                        f16x8 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { hi[e] = h0[e]; hi[4 + e] = h1[e]; lo[e] = l0[e]; lo[4 + e] = l1[e]; }
+                        const int pc = 2 * (q + h);
+                        *reinterpret_cast<f16x8*>(ep + r * 128 + ((pc ^ (r & 7)) * 16)) = hi;
+                        *reinterpret_cast<f16x8*>(ep + r * 128 + (((pc + 1) ^ (r & 7)) * 16)) = lo;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + wn * WTN + 8 * q + 4 * h;
+                        float4 val;
+                        float* vp = &val.x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float b = (g.bias && n < N) ? g.bias[n + e] : 0.f;
+                            float t = acc[i][0][4 * q + e] * ws + b;
+                            if constexpr (EPI == SM_EPI_GELU) t = 0.5f * t * (1.0f + fast_erff(t * 0.70710678118654752440f));
+                            else if constexpr (EPI == SM_EPI_RELU) t = fmaxf(t, 0.f);
+                            vp[e] = t;
+                        }
+                        *reinterpret_cast<float4*>(ep + r * 128 + (((2 * q + h) ^ (r & 7)) * 16)) = val;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = it * 64 + lane, row = idx >> 3, pc = idx & 7;
+                    int m = m0 + wm * WTM + i * 32 + row;
+                    const int n = n0 + wn * WTN + pc * 4;
+                    if (m < M && n < N) {
+                        float4 v = *reinterpret_cast<const float4*>(ep + row * 128 + ((pc ^ (row & 7)) * 16));
+                        if constexpr (EPI == SM_EPI_RESIDUAL) {
+                            const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)m * g.ldr + n);
+                            v.x = rr.x + v.x; v.y = rr.y + v.y; v.z = rr.z + v.z; v.w = rr.w + v.w;
+                        } else if constexpr (EPI == SM_EPI_PATCH) {
+                            const int img = m / g.patch_n, p = m - img * g.patch_n;
+                            const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
+                            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                            m = img * (g.patch_n + 1) + 1 + p;
+                        }
+                        *reinterpret_cast<float4*>(g.C + (int64_t)m * g.ldc + n) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
+        using T = std::true_type;
+        using Fa = std::false_type;
+        switch (g.epilogue) {
+            case SM_EPI_GELU: out_split ? run(std::integral_constant<int, SM_EPI_GELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_GELU>{}, Fa{}); break;
+            case SM_EPI_RELU: out_split ? run(std::integral_constant<int, SM_EPI_RELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_RELU>{}, Fa{}); break;
+            case SM_EPI_RESIDUAL: run(std::integral_constant<int, SM_EPI_RESIDUAL>{}, Fa{}); break;
+            case SM_EPI_PATCH: run(std::integral_constant<int, SM_EPI_PATCH>{}, Fa{}); break;
+            default: out_split ? run(std::integral_constant<int, SM_EPI_BIAS>{}, T{}) : run(std::integral_constant<int, SM_EPI_BIAS>{}, Fa{}); break;
+        }
+        if (!has_next) break;
+        vid = vnext;
+        m0 = m1; n0 = n1;
+        cur = nxt;
+    }
+    wait_vmcnt_w<0>();
+}
+
+static int launch_gemm_w_persist(const sm_gemm_args& g, int stagger, hipStream_t st) {
+    const int n_tiles = ((g.N + 127) / 128) * ((g.M + 127) / 128);
+    int grid = n_tiles < 512 ? n_tiles : 512;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w16_persist_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  64 * 1024);
+        (void)hipGetLastError();
+    });
+    hipLaunchKernelGGL((gemm_w16_persist_kernel<4>), dim3(grid), dim3(512), 64 * 1024, st, g, n_tiles, stagger);
+    return check_launch("sm_gemm_w16 (persistent)");
+}
+
 // fp32 weights (rows, K) -> W16: per group of 8 k, 16 B of wh = f16(w * scale) then 16 B of wl = f16(w * scale - wh)
 __global__ __launch_bounds__(256) void split_w16_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
                                                         int64_t ldd, int K, int64_t total_groups, float scale) {
@@ -438,6 +676,13 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 13: return sm::launch_gemm_w<256, 128, 16, 4, 4, 2, 2, 1>(a, st);  // 8 waves of 64x64, 96 KiB: one per CU
         case 14: return sm::launch_gemm_w<128, 64, 16, 4, 2, 2, 4, 1>(a, st);   // 4 waves of 64x32, 48 KiB: three per CU
         case 15: return sm::launch_gemm_w<128, 128, 32, 3, 2, 2, 2, 1>(a, st);  // 4 waves of 64x64, 32-k stages x 3, 96 KiB: one per CU
+        // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
+        case 20: case 21: case 22: case 23: case 24: {
+            SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
+            static const int stag_env = getenv("SM_W16_STAGGER") ? atoi(getenv("SM_W16_STAGGER")) : -1;
+            const int stag[5] = {0, 8, 16, 32, 64};  // x ~512 clocks of s_sleep: 0, 4k, 8k, 16k, 33k cycles
+            return sm::launch_gemm_w_persist(a, stag_env >= 0 ? stag_env : stag[variant - 20], st);
+        }
     }
     sm::set_error("sm_gemm_w16_tile: unknown variant %d", variant);
     return SM_EINVAL;
@@ -459,6 +704,7 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 13: return "gemm_w16_kernel<256, 128, 16, 4, 4, 2, 2, 1>";
         case 14: return "gemm_w16_kernel<128, 64, 16, 4, 2, 2, 4, 1>";
         case 15: return "gemm_w16_kernel<128, 128, 32, 3, 2, 2, 2, 1>";
+        case 20: case 21: case 22: case 23: case 24: return "gemm_w16_persist_kernel<4>";
     }
     return nullptr;
 }

@@ -149,7 +149,7 @@ def test_configs2_384_bilateral_refinement_end_to_end(tmp_path):
         rows_ref.append(np.concatenate([E.all_metrics(pm[q], gt), E.all_metrics(pm[ub], gt), [q, ub]]))
         target = F.interpolate(out["mask_pred"][0, -1, q][None, None], size=(S, S), mode="bilinear", align_corners=False)[0, 0]
         rgb = np.asarray(Image.open(ds.p_imgs[i]).convert("RGB").resize((S, S), Image.BILINEAR))
-        soft, binary = BO.bilateral_solver_output(rgb, target.double().numpy())
+        soft, binary = BO.bilateral_solver_output(rgb, target.double().numpy())[:2]
         refined = F.interpolate(torch.from_numpy(binary.astype(np.float32))[None, None], size=tuple(gt.shape), mode="bilinear",
                                 align_corners=False)[0, 0]
         rows_refined_ref.append(E.all_metrics(refined, gt))

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from selfmask_amd import ops, _native as N  # noqa: E402
 
 DEV = "cuda:0"
-VARIANTS = [0, 1, 2, 3, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15]
+VARIANTS = [0, 1, 2, 3, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 20, 22]  # 20+: persistent (stagger 0 / 16)
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -50,6 +50,7 @@ def test_w16_format_round_trip():
     (61, 200, 64, N.EPI_RELU, False),             # N not a multiple of any tile, short K
     (20, 384, 384, N.EPI_BIAS, False),            # one partial tile
     (1000, 384, 768, N.EPI_BIAS, False),          # several 256-row tiles
+    (12608, 1152, 384, N.EPI_BIAS, True),         # the bench's qkv shape: 891 tiles - persistent workgroups walk two tiles
 ])
 def test_variants_epilogues_formats(variant, M, Nn, K, epi, osplit):
     a, w, b = _rand(M, K, seed=2), _rand(Nn, K, seed=3, scale=0.05), _rand(Nn, seed=4)
