@@ -676,6 +676,14 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 13: return sm::launch_gemm_w<256, 128, 16, 4, 4, 2, 2, 1>(a, st);  // 8 waves of 64x64, 96 KiB: one per CU
         case 14: return sm::launch_gemm_w<128, 64, 16, 4, 2, 2, 4, 1>(a, st);   // 4 waves of 64x32, 48 KiB: three per CU
         case 15: return sm::launch_gemm_w<128, 128, 32, 3, 2, 2, 2, 1>(a, st);  // 4 waves of 64x64, 32-k stages x 3, 96 KiB: one per CU
+        // deep rings, one workgroup per CU: what bounds the shallow variants is bytes in flight (Little's law on the LDS-DMA
+        // feed: ~2.6k cycles issue -> landed under load x the bytes per cycle the MFMAs consume), DESIGN.md section 5
+        case 30: return sm::launch_gemm_w<256, 128, 32, 3, 4, 4, 4>(a, st);   // 16 waves of 64x32, 144 KiB
+        case 31: return sm::launch_gemm_w<256, 128, 32, 3, 4, 2, 2>(a, st);   // 8 waves of 64x64, 144 KiB
+        case 32: return sm::launch_gemm_w<256, 256, 32, 2, 2, 8, 4>(a, st);   // 16 waves of 128x32, 128 KiB
+        case 33: return sm::launch_gemm_w<128, 128, 32, 4, 2, 4, 4>(a, st);   // 8 waves of 64x32, 128 KiB
+        case 34: return sm::launch_gemm_w<128, 128, 32, 5, 2, 4, 4>(a, st);   // ... 160 KiB
+        case 35: return sm::launch_gemm_w<256, 128, 16, 6, 4, 2, 2>(a, st);   // 8 waves of 64x64, 16-k stages x 6, 144 KiB
         // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
         case 20: case 21: case 22: case 23: case 24: {
             SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
@@ -690,14 +698,14 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
 
 extern "C" const char* sm_gemm_w16_variant_name(int variant) {
     switch (variant) {
-        case 0: return "gemm_w16_kernel<256, 128, 16, 3, 4, 2, 4>";
-        case 1: return "gemm_w16_kernel<256, 128, 32, 2, 4, 4, 4>";
-        case 2: return "gemm_w16_kernel<128, 128, 32, 2, 2, 4, 4>";
-        case 3: return "gemm_w16_kernel<128, 128, 16, 3, 2, 2, 3>";
-        case 4: return "gemm_w16_kernel<64, 64, 32, 3, 2, 2, 3>";
-        case 6: return "gemm_w16_kernel<256, 128, 32, 2, 4, 2, 2>";
-        case 7: return "gemm_w16_kernel<128, 64, 32, 2, 2, 2, 3>";
-        case 8: return "gemm_w16_kernel<128, 128, 16, 3, 2, 4, 6>";
+        case 0: return "gemm_w16_kernel<256, 128, 16, 3, 4, 2, 4, 0>";
+        case 1: return "gemm_w16_kernel<256, 128, 32, 2, 4, 4, 4, 0>";
+        case 2: return "gemm_w16_kernel<128, 128, 32, 2, 2, 4, 4, 0>";
+        case 3: return "gemm_w16_kernel<128, 128, 16, 3, 2, 2, 3, 0>";
+        case 4: return "gemm_w16_kernel<64, 64, 32, 3, 2, 2, 3, 0>";
+        case 6: return "gemm_w16_kernel<256, 128, 32, 2, 4, 2, 2, 0>";
+        case 7: return "gemm_w16_kernel<128, 64, 32, 2, 2, 2, 3, 0>";
+        case 8: return "gemm_w16_kernel<128, 128, 16, 3, 2, 4, 6, 0>";
         case 10: return "gemm_w16_kernel<128, 128, 16, 3, 2, 2, 3, 1>";
         case 11: return "gemm_w16_kernel<128, 128, 16, 4, 2, 2, 2, 1>";
         case 12: return "gemm_w16_kernel<128, 128, 16, 4, 2, 4, 4, 1>";
@@ -705,6 +713,12 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 14: return "gemm_w16_kernel<128, 64, 16, 4, 2, 2, 4, 1>";
         case 15: return "gemm_w16_kernel<128, 128, 32, 3, 2, 2, 2, 1>";
         case 20: case 21: case 22: case 23: case 24: return "gemm_w16_persist_kernel<4>";
+        case 30: return "gemm_w16_kernel<256, 128, 32, 3, 4, 4, 4, 0>";
+        case 31: return "gemm_w16_kernel<256, 128, 32, 3, 4, 2, 2, 0>";
+        case 32: return "gemm_w16_kernel<256, 256, 32, 2, 2, 8, 4, 0>";
+        case 33: return "gemm_w16_kernel<128, 128, 32, 4, 2, 4, 4, 0>";
+        case 34: return "gemm_w16_kernel<128, 128, 32, 5, 2, 4, 4, 0>";
+        case 35: return "gemm_w16_kernel<256, 128, 16, 6, 4, 2, 2, 0>";
     }
     return nullptr;
 }

@@ -20,8 +20,11 @@
 // Phase 2 - attention, as attention_f16x2.hip: S^T = K Q^T (3 MFMAs per 16 dims), softmax on the lane (keys on the
 // accumulator rows: one cross-half shuffle), lazy running maximum, P split in registers = B operand of O^T = V^T P^T.
 //
-// LDS: K 208 x 256 B + V^T 64 x 848 B (16 B of padding per row: conflict-free b128 reads) + ring 2 x 26 KiB = 157 KiB -
-// one workgroup per CU, so N <= 208 tokens: the ViT-S/16 224^2 headline shape (197).  Other shapes take the unfused path.
+// LDS: one workgroup per CU owns all of it.  During phase 1 the whole 160 KiB is the LDS-DMA ring - six 26-KiB stages, five
+// in flight: the feed is latency-bound (issue -> landed ~2.6k cycles under load), so what it sustains is bytes in flight
+// divided by that latency, and a two-slot ring starved the MFMAs (75 us per launch instead of 5x us).  After the last stage
+// (one barrier) the same memory becomes K (208 x 256 B) + V^T (64 x 848 B, 16 B of padding per row: conflict-free b128
+// reads) = 105 KiB.  N <= 208 tokens: the ViT-S/16 224^2 headline shape (197); other shapes take the unfused path.
 #include "common.h"
 #include <math.h>
 #include <mutex>
@@ -38,10 +41,13 @@ constexpr int QA_V_BYTES = 64 * QA_VLD;      // 54272
 constexpr int QA_XT = QA_TOK * 64;           // 14336 B: Xn stage (16 k = 64 B per row)
 constexpr int QA_WT = 192 * 64;              // 12288 B: weight stage (Q, K, V rows of the head)
 constexpr int QA_STAGE = QA_XT + QA_WT;      // 26624
-constexpr int QA_RING = QA_K_BYTES + QA_V_BYTES;
-constexpr int QA_LDS = QA_RING + 2 * QA_STAGE;  // 160768 <= 163840
+constexpr int QA_NST = 6;                        // ring stages (phase 1 only; K / V^T overlay them afterwards)
+constexpr int QA_DUMP = QA_NST * QA_STAGE;       // 2 KiB behind the ring: landing zone of the two filler pieces
+constexpr int QA_LDS = QA_DUMP + 2048;           // 161792 <= 163840
+static_assert(QA_K_BYTES + QA_V_BYTES <= QA_DUMP, "K and V^T overlay the ring");
 constexpr int QA_XP = QA_XT / 1024, QA_WP = QA_WT / 1024, QA_NP = QA_XP + QA_WP;  // 14 + 12 = 26 one-KiB pieces per stage
-constexpr int QA_PPW = (QA_NP + QA_WAVES - 1) / QA_WAVES;                           // <= 4 pieces per wave
+constexpr int QA_PPW = 4;                        // every wave issues 4 pieces per stage (7 x 4 = 28: two fillers), so the
+                                                 // counted vmcnt below is the same immediate in every wave
 
 __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_attn_args a) {
     extern __shared__ __attribute__((aligned(16))) char smq[];
@@ -77,18 +83,20 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
             const int tok = row < N ? row : N - 1;
             src[j] = X + (int64_t)tok * a.ldx * 4 + c * 16;
         } else {
-            const int row = (p - QA_XP) * 16 + prow;  // 0..191: [Q dims | K dims | V dims] of this head
+            const int row = ((p < QA_NP ? p : QA_XP) - QA_XP) * 16 + prow;  // 0..191: [Q dims | K dims | V dims] of this head
             const int c = (lane & 3) ^ ((row >> 2) & 3);
             const int wrow = (row >> 6) * SM_EMBED + head * SM_HEAD_DIM + (row & 63);
             src[j] = W + (int64_t)wrow * SM_EMBED * 4 + c * 16;
         }
-        dst[j] = p * 1024;
+        dst[j] = p * 1024;  // pieces 26, 27 (fillers: a repeat of weight piece 14) land in the dump zone, see issue()
     }
     auto issue = [&](int kt, int slot) {
 #pragma unroll
-        for (int j = 0; j < QA_PPW; ++j)
-            if (wave + QA_WAVES * j < QA_NP)
-                lds_dma16(src[j] + kt * 64, __builtin_amdgcn_readfirstlane(lds0 + QA_RING + slot * QA_STAGE + dst[j]));
+        for (int j = 0; j < QA_PPW; ++j) {
+            const int p = wave + QA_WAVES * j;
+            const unsigned d = p < QA_NP ? lds0 + slot * QA_STAGE + dst[j] : lds0 + QA_DUMP + (p - QA_NP) * 1024;
+            lds_dma16(src[j] + kt * 64, __builtin_amdgcn_readfirstlane(d));
+        }
     };
 
     // fragment offsets inside a 64-B stage row: lane half h -> k-group h -> chunks 2h (hi), 2h+1 (lo)
@@ -107,13 +115,18 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
 
     constexpr int NKT = SM_EMBED / 16;  // 24 stages
-    issue(0, 0);
+#pragma unroll
+    for (int t = 0; t < QA_NST - 1; ++t) issue(t, t);
     for (int kt = 0; kt < NKT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage kt has landed for every wave; every wave is done with stage kt-1
+        // stage kt has landed (this wave's pieces): all but the QA_NST - 2 younger stages' pieces are done
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QA_NST - 2) * QA_PPW) : "memory");
+        __builtin_amdgcn_s_barrier();  // ... for every wave; every wave is done with stage kt-1, whose slot is refilled now
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < NKT) issue(kt + 1, (kt + 1) & 1);
-        const char* st = smq + QA_RING + (kt & 1) * QA_STAGE;
+        {   // stages past the end re-fetch the last one, so that every iteration issues the same number of pieces
+            const int t = kt + QA_NST - 1;
+            issue(t < NKT ? t : NKT - 1, t % QA_NST);
+        }
+        const char* st = smq + (kt % QA_NST) * QA_STAGE;
         const f16x8 ah = *reinterpret_cast<const f16x8*>(st + x_hi);
         const f16x8 al = *reinterpret_cast<const f16x8*>(st + x_lo);
         f16x8 wh[6], wl[6];
@@ -138,6 +151,9 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every DMA has landed and every wave has read its last stage: the ring becomes K / V^T
 
     // ---- accumulators -> Q fragments (registers), K and V^T (LDS) ---------------------------------------------------------
     const float ws = a.w_scale;

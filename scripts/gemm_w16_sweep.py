@@ -12,7 +12,7 @@ M = int(os.environ.get("M", 12608))
 SHAPES = [("qkv", 1152, 384, N.EPI_BIAS, True, False), ("proj", 384, 384, N.EPI_RESIDUAL, False, True),
           ("fc1", 1536, 384, N.EPI_GELU, True, False), ("fc2", 384, 1536, N.EPI_RESIDUAL, False, True),
           ("kv", 4608, 384, N.EPI_BIAS, True, False)]
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "2,7,20,21,22,23,24").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "2,7,30,31,32,33,34,35").split(",")]
 ROUNDS, ITERS = 7, 20
 
 
