@@ -29,6 +29,7 @@
 #include <math.h>
 #include <mutex>
 #include <stdlib.h>
+#include <string.h>
 
 namespace sm {
 
@@ -38,18 +39,19 @@ constexpr int QA_KROWS = 208;                // keys kept in LDS (13 MFMA steps 
 constexpr int QA_K_BYTES = QA_KROWS * 256;   // 53248
 constexpr int QA_VLD = 208 * 4 + 16;         // bytes per head-dim row of V^T (+16: b128 reads of 16 rows hit 16 slots)
 constexpr int QA_V_BYTES = 64 * QA_VLD;      // 54272
-constexpr int QA_XT = QA_TOK * 64;           // 14336 B: Xn stage (16 k = 64 B per row)
-constexpr int QA_WT = 192 * 64;              // 12288 B: weight stage (Q, K, V rows of the head)
-constexpr int QA_STAGE = QA_XT + QA_WT;      // 26624
-constexpr int QA_NST = 6;                        // ring stages (phase 1 only; K / V^T overlay them afterwards)
-constexpr int QA_DUMP = QA_NST * QA_STAGE;       // 2 KiB behind the ring: landing zone of the two filler pieces
-constexpr int QA_LDS = QA_DUMP + 2048;           // 161792 <= 163840
-static_assert(QA_K_BYTES + QA_V_BYTES <= QA_DUMP, "K and V^T overlay the ring");
-constexpr int QA_XP = QA_XT / 1024, QA_WP = QA_WT / 1024, QA_NP = QA_XP + QA_WP;  // 14 + 12 = 26 one-KiB pieces per stage
-constexpr int QA_PPW = 4;                        // every wave issues 4 pieces per stage (7 x 4 = 28: two fillers), so the
-                                                 // counted vmcnt below is the same immediate in every wave
+constexpr int QA_LDS = 160 * 1024;           // the whole LDS of a CU (one workgroup per CU)
+static_assert(QA_K_BYTES + QA_V_BYTES <= QA_LDS, "K and V^T overlay the ring");
 
+// KT = k per ring stage: 32 -> a stage row is one full 128-B line (8 rows per 1-KiB LDS-DMA piece), 16 -> 64-B half lines
+// (16 rows per piece).  NST = ring stages.  Stage = [224 Xn rows | 192 weight rows] x KT * 4 bytes.
+template <int KT, int NST>
 __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_attn_args a) {
+    constexpr int ROWB = KT * 4, CH = KT / 4, RPP = 1024 / ROWB, KS = KT / 16;
+    constexpr int XT = QA_TOK * ROWB, WT = 192 * ROWB, STAGE = XT + WT;
+    constexpr int XP = XT / 1024, NP = STAGE / 1024;                  // Xn pieces / all pieces per stage
+    constexpr int PPW = (NP + QA_WAVES - 1) / QA_WAVES;               // pieces per wave, the same immediate in every wave: the
+    constexpr int DUMP = NST * STAGE;                                 // surplus ("filler") pieces land in a dump zone behind the ring
+    static_assert(DUMP + (PPW * QA_WAVES - NP) * 1024 <= QA_LDS, "ring + dump zone must fit in LDS");
     extern __shared__ __attribute__((aligned(16))) char smq[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smq;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -68,43 +70,46 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
     const int N = a.N;
     const char* X = reinterpret_cast<const char*>(a.Xn + (int64_t)b * N * a.ldx);
     const char* W = reinterpret_cast<const char*>(a.Wqkv);
+    auto swz = [](int row) { return KT == 32 ? (row >> 1) & 7 : (row >> 2) & 3; };
 
-    // ---- ring fill: piece p of a stage = 16 rows x 64 B; p < 14: Xn rows 16p.., else weight rows 16(p-14)..; dealt
-    // round-robin over the waves.  Lane l fetches chunk (l & 3) ^ swz(row) of row l >> 2 (swz = (row >> 2) & 3).
-    const char* src[QA_PPW];
-    unsigned dst[QA_PPW];
+    // ---- ring fill: piece p of a stage = RPP rows; p < XP: Xn rows, else weight rows; dealt round-robin over the waves.
+    // Lane l fetches chunk (l % CH) ^ swz(row) of row l / CH.
+    const char* src[PPW];
 #pragma unroll
-    for (int j = 0; j < QA_PPW; ++j) {
+    for (int j = 0; j < PPW; ++j) {
         const int p = wave + QA_WAVES * j;
-        const int prow = lane >> 2;
-        if (p < QA_XP) {
-            const int row = p * 16 + prow;
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const int prow = lane / CH;
+        if (p < XP) {
+            const int row = p * RPP + prow;
+            const int c = (lane % CH) ^ swz(row);
             const int tok = row < N ? row : N - 1;
             src[j] = X + (int64_t)tok * a.ldx * 4 + c * 16;
         } else {
-            const int row = ((p < QA_NP ? p : QA_XP) - QA_XP) * 16 + prow;  // 0..191: [Q dims | K dims | V dims] of this head
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const int row = ((p < NP ? p : XP) - XP) * RPP + prow;  // 0..191: [Q dims | K dims | V dims] of this head
+            const int c = (lane % CH) ^ swz(row);
             const int wrow = (row >> 6) * SM_EMBED + head * SM_HEAD_DIM + (row & 63);
             src[j] = W + (int64_t)wrow * SM_EMBED * 4 + c * 16;
         }
-        dst[j] = p * 1024;  // pieces 26, 27 (fillers: a repeat of weight piece 14) land in the dump zone, see issue()
     }
     auto issue = [&](int kt, int slot) {
 #pragma unroll
-        for (int j = 0; j < QA_PPW; ++j) {
+        for (int j = 0; j < PPW; ++j) {
             const int p = wave + QA_WAVES * j;
-            const unsigned d = p < QA_NP ? lds0 + slot * QA_STAGE + dst[j] : lds0 + QA_DUMP + (p - QA_NP) * 1024;
-            lds_dma16(src[j] + kt * 64, __builtin_amdgcn_readfirstlane(d));
+            const unsigned d = p < NP ? lds0 + slot * STAGE + p * 1024 : lds0 + DUMP + (p - NP) * 1024;  // fillers: dump zone
+            lds_dma16(src[j] + kt * ROWB, __builtin_amdgcn_readfirstlane(d));
         }
     };
 
-    // fragment offsets inside a 64-B stage row: lane half h -> k-group h -> chunks 2h (hi), 2h+1 (lo)
+    // fragment offsets inside a stage row: k16 step s, lane half h -> k-group 2s+h -> chunks 2(2s+h) (hi), +1 (lo)
     const int xrow = wave * 32 + r;
-    const int xoff = xrow * 64, xsw = (xrow >> 2) & 3;
-    const int x_hi = xoff + (((2 * h) ^ xsw) * 16), x_lo = xoff + (((2 * h + 1) ^ xsw) * 16);
-    const int wsw = (r >> 2) & 3;  // weight rows 32 blk + r: (row >> 2) & 3 does not depend on blk
-    const int w_hi = QA_XT + r * 64 + (((2 * h) ^ wsw) * 16), w_lo = QA_XT + r * 64 + (((2 * h + 1) ^ wsw) * 16);
+    int x_hi[KS], x_lo[KS], w_hi[KS], w_lo[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        x_hi[s] = xrow * ROWB + (((2 * (2 * s + h)) ^ swz(xrow)) * 16);
+        x_lo[s] = xrow * ROWB + (((2 * (2 * s + h) + 1) ^ swz(xrow)) * 16);
+        w_hi[s] = XT + r * ROWB + (((2 * (2 * s + h)) ^ swz(r)) * 16);   // weight rows 32 blk + r: swz does not depend on blk
+        w_lo[s] = XT + r * ROWB + (((2 * (2 * s + h) + 1) ^ swz(r)) * 16);
+    }
 
     f32x16 acc[6];  // [Q d0-31, Q d32-63, K d0-31, K d32-63, V d0-31, V d32-63]
 #pragma unroll
@@ -114,40 +119,43 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
     const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
 
-    constexpr int NKT = SM_EMBED / 16;  // 24 stages
+    constexpr int NKT = SM_EMBED / KT;
 #pragma unroll
-    for (int t = 0; t < QA_NST - 1; ++t) issue(t, t);
+    for (int t = 0; t < NST - 1; ++t) issue(t, t);
     for (int kt = 0; kt < NKT; ++kt) {
-        // stage kt has landed (this wave's pieces): all but the QA_NST - 2 younger stages' pieces are done
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((QA_NST - 2) * QA_PPW) : "memory");
+        // stage kt has landed (this wave's pieces): all but the NST - 2 younger stages' pieces are done
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW) : "memory");
         __builtin_amdgcn_s_barrier();  // ... for every wave; every wave is done with stage kt-1, whose slot is refilled now
         __builtin_amdgcn_sched_barrier(0);
         {   // stages past the end re-fetch the last one, so that every iteration issues the same number of pieces
-            const int t = kt + QA_NST - 1;
-            issue(t < NKT ? t : NKT - 1, t % QA_NST);
+            const int t = kt + NST - 1;
+            issue(t < NKT ? t : NKT - 1, t % NST);
         }
-        const char* st = smq + (kt % QA_NST) * QA_STAGE;
-        const f16x8 ah = *reinterpret_cast<const f16x8*>(st + x_hi);
-        const f16x8 al = *reinterpret_cast<const f16x8*>(st + x_lo);
-        f16x8 wh[6], wl[6];
+        const char* st = smq + (kt % NST) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            wh[i] = *reinterpret_cast<const f16x8*>(st + w_hi + i * 32 * 64);
-            wl[i] = *reinterpret_cast<const f16x8*>(st + w_lo + i * 32 * 64);
-        }
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(st + x_hi[s]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(st + x_lo[s]);
+            f16x8 wh[6], wl[6];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {  // Q^T, K^T: D[dim][token]
-            const f16x8 whs = wh[i] * down;
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], ah, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], ah, acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whs, al, acc[i], 0, 0, 0);
-        }
+            for (int i = 0; i < 6; ++i) {
+                wh[i] = *reinterpret_cast<const f16x8*>(st + w_hi[s] + i * 32 * ROWB);
+                wl[i] = *reinterpret_cast<const f16x8*>(st + w_lo[s] + i * 32 * ROWB);
+            }
 #pragma unroll
-        for (int i = 4; i < 6; ++i) {  // V: D[token][dim]
-            const f16x8 whs = wh[i] * down;
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[i], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[i], acc[i], 0, 0, 0);
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, whs, acc[i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {  // Q^T, K^T: D[dim][token]
+                const f16x8 whs = wh[i] * down;
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], ah, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], ah, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whs, al, acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 4; i < 6; ++i) {  // V: D[token][dim]
+                const f16x8 whs = wh[i] * down;
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[i], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[i], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, whs, acc[i], 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -351,10 +359,20 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
                "sm_qkv_attention_w16: row strides must be multiples of 8 elements, pointers 32-B aligned");
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        const void* ks[] = {reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 3>),
+                            reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 6>)};
+        for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
         (void)hipGetLastError();
     });
-    hipLaunchKernelGGL(sm::qkv_attention_kernel, dim3(a->B * SM_HEADS), dim3(sm::QA_WAVES * 64), sm::QA_LDS, (hipStream_t)stream, *a);
+    // stage shape of the projection phase: tuning knob (same results), "<k per stage>x<ring stages>"; measured on MI355X with
+    // scripts/qkv_attn_bench.py: full 128-B line pieces (32-k stages) move at twice the bytes per address-unit cycle of 64-B pieces
+    static const char* ring = getenv("SM_QKV_RING");
+    const int mode = !ring ? 0 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : 0;
+    const dim3 grid(a->B * SM_HEADS), block(sm::QA_WAVES * 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 3>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 2) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 2>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 3) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 6>), grid, block, sm::QA_LDS, st, *a);
+    else hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 2>), grid, block, sm::QA_LDS, st, *a);
     return sm::check_launch("sm_qkv_attention_w16");
 }
