@@ -12,8 +12,16 @@ timed region.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline      - the kernel holding the largest share of the forward, timed in situ: HIP events around each of its
-                  launches on the launch stream inside real forwards (sm_forward_timing);
-  cpu_baseline  - the CPU oracle (torch-CPU restatement of the reference) on this box's host cores, rank 0, N=1 only.
+                  launches on the launch stream inside real forwards (sm_forward_timing); `traffic` = HBM bytes per launch
+                  from the committed PMC passes, quoted only if they were taken on exactly these kernel sources;
+  sustained     - the same step loop run for --sustained-steps more steps (the K-step figure is a short burst);
+  cpu_baseline  - the CPU oracle (torch-CPU restatement of the reference) on this box's host cores, rank 0, N=1 only:
+                  the same work as a GPU step (forward + post-processing + 14 metrics) on all cores (`value`), the
+                  forward alone on all cores and on one thread, and the reference's own operating point (batch 1);
+  end_to_end    - the real Evaluator over a generated DUTS-layout JPEG tree (decode pool -> device resize / normalise ->
+                  forward -> metrics): what a user sees, bounded by JPEG decoding on the host cores;
+  serving       - SelfMaskInference.predict_tensors at batch 1 (app.py's call pattern): p50 / p99 latency.
+--quick skips everything but the timed steps and the roofline (profiling runs).
 """
 import argparse
 import json
@@ -72,28 +80,133 @@ def time_forward_kernels(model, x, forwards=3):
     return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms_per_forward"]))
 
 
-def cpu_baseline(P, S, budget_s=15.0):
-    """The CPU oracle (torch-CPU restatement, fp32) on this host: bounded sample of the same workload."""
-    from oracle import selfmask_oracle as O  # measured as the BASELINE only, never on the product path
-    from selfmask_amd import synthetic_state_dict, synthetic_images
+def source_hash() -> str:
+    """Hash of the kernel sources: PMC measurements are only quoted for exactly the code they were taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(REPO, "salient-object-detection_amd", "csrc", "*"))) + \
+        [os.path.join(REPO, "include", "selfmask_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def _cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("SM_CPU_BASELINE_THREADS", "16")))  # a 1-GPU box's CPU share is 16 cores
-    torch.set_num_threads(cores)
+    return min(cores, int(os.environ.get("SM_CPU_BASELINE_THREADS", "16")))  # a 1-GPU box's CPU share is 16 cores
+
+
+def cpu_baseline(P, S, budget_s=7.0):
+    """The CPU oracle (torch-CPU restatement, fp32) on this host: bounded samples of the same workload."""
+    import numpy as np
+    from oracle import selfmask_oracle as O  # measured as the BASELINE only, never on the product path
+    from oracle import evaluator_oracle as E
+    from selfmask_amd import synthetic_state_dict, synthetic_images
+    cores = _cores()
     sd = synthetic_state_dict(0, "soft", patch_size=P)
     Bc = 16
     x = torch.from_numpy(synthetic_images(1234, (Bc, 3, S, S)))
-    O.forward(x, sd, P)  # warm-up
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        O.forward(x, sd, P)
-        n += Bc
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} images (batches of {Bc}, ViT-S/{P} {S}x{S}, fp32 torch-CPU oracle) in {dt:.1f}s"}
+    rng = np.random.Generator(np.random.PCG64(99))
+    gts = []
+    for _ in range(Bc):
+        h, w = (int(v) for v in rng.integers(300, 401, size=2))
+        yy, xx = np.mgrid[:h, :w]
+        gts.append(torch.from_numpy((((yy - h * .5) / (h * .2)) ** 2 + ((xx - w * .5) / (w * .25)) ** 2 <= 1).astype(np.int64)))
+
+    def timed(fn, per_call, threads):
+        torch.set_num_threads(threads)
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            fn()
+            n += per_call
+        return n, time.perf_counter() - t0
+
+    def step_all():  # what one GPU step does: forward, post-processing to each GT's size, both selections, 14 metrics
+        out = O.forward(x, sd, P)
+        for b in range(Bc):
+            pm, q, ub, _ = E.postprocess(out["mask_pred"][b, -1], out["objectness"][b, -1, :, 0], gts[b], scale_factor=None)
+            E.all_metrics(pm[q], gts[b]); E.all_metrics(pm[ub], gts[b])
+
+    n_all, t_all = timed(step_all, Bc, cores)
+    n_fwd, t_fwd = timed(lambda: O.forward(x, sd, P), Bc, cores)
+    n_one, t_one = timed(lambda: O.forward(x[:4], sd, P), 4, 1)
+    n_b1, t_b1 = timed(lambda: O.forward(x[:1], sd, P), 1, cores)
+    return {"value": round(n_all / t_all, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_all} images (batches of {Bc}, ViT-S/{P} {S}x{S}: fp32 torch-CPU oracle forward + post-processing + "
+                      f"14 metrics per image) in {t_all:.1f}s",
+            "forward_only_all_cores": {"value": round(n_fwd / t_fwd, 2), "cores": cores, "sample": f"{n_fwd} images in {t_fwd:.1f}s"},
+            "forward_only_one_thread": {"value": round(n_one / t_one, 2), "cores": 1, "sample": f"{n_one} images (batches of 4) in {t_one:.1f}s"},
+            "forward_only_batch1_all_cores": {"value": round(n_b1 / t_b1, 2), "cores": cores,
+                                              "sample": f"{n_b1} images at batch 1 (the reference evaluator's operating point) in {t_b1:.1f}s"}}
+
+
+def end_to_end(model, dev, P, S, B, streams, n_images=384):
+    """The real Evaluator over a generated DUTS-layout tree of JPEG / PNG files (300-400 px): decode on the
+    host pool, resize + normalise + forward + metrics on the device."""
+    import shutil
+    import tempfile
+    from selfmask_amd import datasets as DS
+    from selfmask_amd.evaluator import Evaluator
+    root = tempfile.mkdtemp(prefix="sm_bench_ds_")
+    try:
+        DS.write_synthetic_dataset(root, "duts", n_images, seed=7)
+        ev = Evaluator(network=model, dir_dataset=root)
+        ev.device = dev
+        ev("duts", dir_ckpt=os.path.join(root, "ckpt"), img_size=S, batch_size=B, device=dev, streams=streams)  # warm: page cache, graphs
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = ev("duts", dir_ckpt=os.path.join(root, "ckpt"), img_size=S, batch_size=B, device=dev, streams=streams)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        # the host part alone: decode of the same files on the same pool, nothing else
+        from selfmask_amd.pipeline import PrefetchingLoader
+        ds = DS.get_dataset(root, "duts", eval_img_size=S)
+        t1 = time.perf_counter()
+        for _ in PrefetchingLoader(ds, range(len(ds)), B, depth=streams + 1):
+            pass
+        dt_dec = time.perf_counter() - t1
+        return {"end_to_end_images_per_sec": round(n_images / dt, 1), "images": n_images, "decode_workers": _cores(),
+                "host_decode_only_images_per_sec": round(n_images / dt_dec, 1), "iou": res["iou"],
+                "what": "Evaluator('duts', img_size=%d, batch_size=%d): JPEG/PNG decode on host threads, Pillow-exact resize + "
+                        "normalise + forward + metrics on the device" % (S, B)}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def serving_latency(model, dev, n=200):
+    """SelfMaskInference.predict_tensors (app.py:241-284) at batch 1 on a 300x400 image: decoded array in -> (index, scores,
+    mask) out, per-request wall time including the final device->host copies."""
+    import io
+    import numpy as np
+    from argparse import Namespace
+    from PIL import Image
+    from selfmask_amd.inference import SelfMaskInference
+    inf = SelfMaskInference(None, Namespace(), device=dev, model=model)
+    rng = np.random.Generator(np.random.PCG64(5))
+    rgb = rng.integers(0, 256, size=(300, 400, 3), dtype=np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="JPEG", quality=92)
+    jpeg = buf.getvalue()
+    for _ in range(10):
+        inf.predict_tensors(rgb)
+    lat, lat_jpeg = [], []
+    for _ in range(n):
+        t0 = time.perf_counter(); inf.predict_tensors(rgb); lat.append(time.perf_counter() - t0)
+    for _ in range(n // 4):
+        t0 = time.perf_counter(); inf.predict_tensors(io.BytesIO(jpeg)); lat_jpeg.append(time.perf_counter() - t0)
+    q = lambda v, p: round(float(np.percentile(np.array(v) * 1e3, p)), 3)
+    g = inf.base_structure._graphed
+    return {"batch": 1, "requests": n, "p50_ms": q(lat, 50), "p99_ms": q(lat, 99), "with_jpeg_decode_p50_ms": q(lat_jpeg, 50),
+            "with_jpeg_decode_p99_ms": q(lat_jpeg, 99), "hip_graph_replays": g.replays, "hip_graph_failed": g.failed,
+            "what": "SelfMaskInference.predict_tensors: 300x400 RGB -> resize 224 + normalise (HIP) -> graph-replayed forward -> "
+                    "arg-max objectness + mask (HIP) -> D2H"}
 
 
 def spawn_ranks(n: int, argv) -> int:
@@ -169,6 +282,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the forward's 171 kernels eagerly instead of replaying "
                                                             "one captured hipGraph per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustained-steps", type=int, default=500, help="extra untimed-by-the-contract leg: the same loop for this many steps")
+    ap.add_argument("--quick", action="store_true", help="timed steps + roofline only (no sustained / CPU / end-to-end / serving legs)")
     ap.add_argument("--host-input", action="store_true",
                     help="diagnostic: every step copies its batch from pinned host memory first (PCIe-inclusive rate; "
                          "the metric keeps inputs resident in HBM)")
@@ -273,17 +388,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    # sustained leg (outside the contract's timed region): the K-step figure above is a ~0.2 s burst
+    sustained = None
+    if a.sustained_steps > 0 and not a.quick:
+        sync()
+        t1 = time.perf_counter()
+        run_steps(a.sustained_steps)
+        sync()
+        ds_ = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([ds_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ds_ = t.item()
+        sustained = {"steps": a.sustained_steps, "value": round(world * a.sustained_steps * B / ds_, 1), "unit": "images/sec",
+                     "ms_per_step": round(ds_ / a.sustained_steps * 1e3, 3)}
+
     if rank == 0:
         value = world * a.steps * B / dt
         flops_img = forward_flops_per_image(P, S)
         kern = time_forward_kernels(model, x)
         dom_name, dom = next(iter(kern.items()))
-        # HBM bytes per launch from the PMC passes of this same command (profiles/r01_pmc_traffic.json holds the recipe;
-        # a profiler cannot run inside the timed process, so the committed measurement is quoted, null if absent)
-        traffic = None
+        # HBM bytes per launch from the PMC passes of this same command (scripts/pmc_traffic.sh writes
+        # profiles/r02_pmc_traffic.json with the hash of the kernel sources it ran on).  A profiler cannot run inside the
+        # timed process, so the committed measurement is quoted - only if it was taken on exactly these sources, else null.
+        traffic, traffic_note = None, "no PMC file for these kernel sources"
         try:
-            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+            with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("source_hash") == source_hash():
+                traffic = pmc["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic_note = "profiles/r02_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950)"
+            else:
+                traffic_note = "profiles/r02_pmc_traffic.json was taken on other kernel sources (hash mismatch): not quoted"
         except (OSError, ValueError, KeyError):
             pass
         gemm = "gemm" in dom_name or "attention" in dom_name
@@ -306,7 +442,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if model.gemm_mode == "fp32" else "f32 (GEMM operands split into two f16 halves, f16 MFMA, f32 accumulate)",
+            "dtype": "f32" if model.gemm_mode == "fp32" else "f32 (GEMM operands split into two f16 halves, 3 f16 MFMAs per product, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
                                    f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
@@ -315,7 +451,7 @@ def main():
                        "hip_graph": {"captures": fwd.captures, "replays": fwd.replays, "failed": fwd.failed},
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
-            "roofline": dict(roof(dom, dom_name), kernel=dom_name, traffic=traffic,
+            "roofline": dict(roof(dom, dom_name), kernel=dom_name, traffic=traffic, traffic_source=traffic_note,
                              avg_launch_us=round(dom["avg_launch_us"], 2),
                              launches_per_forward=dom["launches_per_forward"],
                              flops_per_launch=dom["flops_per_launch"],
@@ -327,7 +463,11 @@ def main():
                                                launches_per_forward=v["launches_per_forward"])
                                        for k, v in list(kern.items())[1:]},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        res["sustained"] = sustained
+        if world == 1 and not a.quick:
+            res["end_to_end"] = end_to_end(model, dev, P, S, B, len(ring.streams))
+            res["serving"] = serving_latency(model, dev)
+        if world == 1 and not a.no_cpu_baseline and not a.quick:
             res["cpu_baseline"] = cpu_baseline(P, S)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -299,3 +299,26 @@ extern "C" int sm_query_mean_f32(const float* queries, float* features, int32_t 
     hipLaunchKernelGGL(sm::query_mean_kernel, dim3(B * (SM_EMBED / 128)), dim3(128), 0, (hipStream_t)stream, queries, features, L, nq);
     return sm::check_launch("sm_query_mean_f32");
 }
+
+#ifdef SM_TUNING
+// Diagnostic (tuning build only): one wave samples the shader clock counter (s_memtime) against the constant 100 MHz
+// reference counter (s_memrealtime) for `spins` iterations; out[0..3] = first / last pair.  Run beside a kernel under test on
+// another stream: (d memtime / d memrealtime) x 100 MHz is the clock the chip holds under that load.
+namespace sm {
+__global__ void clock_probe_kernel(unsigned long long* out, int spins) {
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = t0, r1 = r0;
+    for (int i = 0; i < spins; ++i) {
+        __builtin_amdgcn_s_sleep(32);
+        t1 = __builtin_amdgcn_s_memtime();
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    if (threadIdx.x == 0) { out[0] = t0; out[1] = r0; out[2] = t1; out[3] = r1; }
+}
+}  // namespace sm
+extern "C" int sm_clock_probe(unsigned long long* out, int spins, int blocks, void* stream) {
+    for (int b = 0; b < blocks; ++b)
+        hipLaunchKernelGGL(sm::clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out + 4 * b, spins);
+    return sm::check_launch("sm_clock_probe");
+}
+#endif

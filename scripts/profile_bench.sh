@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -- python3 bench.py --no-cpu-baseline "$@" > gpurun_out/$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$TAG -- python3 bench.py --quick "$@" > gpurun_out/$TAG.log 2>&1
 echo "rc=$?"
 tail -1 gpurun_out/$TAG.log
 F=$(find gpurun_out/$TAG -name "*kernel_stats.csv" | head -1)
