@@ -388,6 +388,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    # per-kernel taps right behind the timed steps (same clocks / cache state as the K steps; agreement with rocprofv3's
+    # kernel-trace averages of the same command is checked in profiles/)
+    kern = time_forward_kernels(model, x) if rank == 0 else None
+
     # sustained leg (outside the contract's timed region): the K-step figure above is a ~0.2 s burst
     sustained = None
     if a.sustained_steps > 0 and not a.quick:
@@ -406,7 +410,6 @@ def main():
     if rank == 0:
         value = world * a.steps * B / dt
         flops_img = forward_flops_per_image(P, S)
-        kern = time_forward_kernels(model, x)
         dom_name, dom = next(iter(kern.items()))
         # HBM bytes per launch from the PMC passes of this same command (scripts/pmc_traffic.sh writes
         # profiles/r02_pmc_traffic.json with the hash of the kernel sources it ran on).  A profiler cannot run inside the

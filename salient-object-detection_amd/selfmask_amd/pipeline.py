@@ -86,9 +86,50 @@ def resize_reference_numpy(img: np.ndarray, S: int) -> np.ndarray:
     return one_pass(tmp.transpose(1, 0, 2), H, S).transpose(1, 0, 2)  # then vertical on the uint8 intermediate
 
 
+class PinnedPool:
+    """Reusable page-locked staging buffers.  ``pin_memory()`` per batch costs milliseconds (and now and then tens of
+    milliseconds) of hipHostMalloc; the pool hands out a buffer again once the event recorded behind its last H2D copy has
+    completed, and grows only when every buffer of a size class is still in flight."""
+
+    def __init__(self):
+        self._free = {}  # (dtype, rounded size) -> list of [tensor, event or None]
+
+    @staticmethod
+    def _round(n: int) -> int:
+        r = 4096
+        while r < n:
+            r *= 2
+        return r
+
+    def get(self, n: int, dtype) -> torch.Tensor:
+        key = (dtype, self._round(max(n, 1)))
+        for ent in self._free.setdefault(key, []):
+            if ent[1] is None or ent[1].query():
+                ent[1] = None
+                self._last = ent
+                return ent[0][:n]
+        ent = [torch.empty(key[1], dtype=dtype).pin_memory(), None]
+        self._free[key].append(ent)
+        self._last = ent
+        return ent[0][:n]
+
+    def release_after(self, tensors, stream) -> None:
+        """The buffers behind ``tensors`` may be reused once the work queued on ``stream`` so far has finished."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        for lst in self._free.values():
+            for ent in lst:
+                if any(t.data_ptr() == ent[0].data_ptr() for t in tensors):
+                    ent[1] = ev
+
+
+_POOL = PinnedPool()
+
+
 def pack_images(images: Sequence[np.ndarray], S: Optional[int], pinned: bool = False):
     """images: list of (H, W, 3) uint8 arrays -> (pixels u8 tensor, coef int32 tensor, descr u8 tensor, max_h, max_pixels,
-    out_elems).  S = output side for the resize path, None for native resolution."""
+    out_elems).  S = output side for the resize path, None for native resolution.  ``pinned``: buffers come from the
+    page-locked pool (the caller must call ``_POOL.release_after`` once the H2D copies are queued)."""
     import ctypes
     B = len(images)
     descr = (N.PreImage * B)()
@@ -96,7 +137,7 @@ def pack_images(images: Sequence[np.ndarray], S: Optional[int], pinned: bool = F
     for im in images:
         offs.append(off)
         off += (im.shape[0] * im.shape[1] * 3 + 15) & ~15
-    mk = (lambda n, dt: torch.empty(n, dtype=dt).pin_memory()) if pinned else (lambda n, dt: torch.empty(n, dtype=dt))
+    mk = (lambda n, dt: _POOL.get(n, dt)) if pinned else (lambda n, dt: torch.empty(n, dtype=dt))
     pixels = mk(max(off, 16), torch.uint8)
     pv = pixels.numpy()
     coef_parts, coef_index, ci = [], {}, 0
@@ -148,6 +189,8 @@ def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device,
     pixels, coef, descr, max_h, max_px, out_elems = pack_images(images, S, pinned)
     st = torch.cuda.current_stream(device).cuda_stream
     pd, cd, dd = (t.to(device, non_blocking=True) for t in (pixels, coef, descr))
+    if pinned:
+        _POOL.release_after((pixels, coef, descr), torch.cuda.current_stream(device))
     lib = N.load()
     B = len(images)
     if S is not None:
