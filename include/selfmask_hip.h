@@ -290,6 +290,18 @@ int sm_upsample_selected_f64(const float* masks, int64_t mask_stride_b, const fl
                              int32_t B, int32_t mh, int32_t mw, int32_t OH, int32_t OW, void* stream);
 int sm_mask_u8_to_f32(const uint8_t* src, float* dst, int64_t n, void* stream);
 
+/* ---- pseudo-mask voting (BASELINE.json configs[4]) -------------------------------------------------------
+ * masks (M, H, W) uint8 0/1, M <= 64 candidate masks of ONE image.  filter_masks (utils/misc.py:285-314; mask_to_bbox
+ * :269-282): a candidate is dropped when it predicts nothing, when (remove_long) its bounding box spans the full height or
+ * the full width, when (remove_small_large) its area is under 5 % of the image or its box over 95 %.  vote_mask
+ * (datasets/mask_generator.pyc@L202-230): iou[i][j] = |mi & mj| / (|mi | mj| + 1e-7) over the survivors, score = row sum,
+ * best = the highest score.  Outputs (device): keep[M] 0/1, iou (M, M) fp32 (0 for dropped rows / columns), row_sums[M]
+ * (-1 for dropped masks), best = index into the ORIGINAL list (-1 if nothing survives). */
+size_t sm_vote_workspace_bytes(int32_t M, int32_t H, int32_t W);
+int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int32_t remove_long, int32_t remove_small_large,
+                     int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 /* ---- bilateral-solver refinement ---------------------------------------------------- */
 typedef struct sm_bilateral_args {
     const uint8_t* img;    /* (H, W, 3) interleaved RGB = np.array(PIL image)   (bilateral_solver.py:159)            */

@@ -154,6 +154,45 @@ def gen_forward3d():
           f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
 
 
+def _voting_cases():
+    """Candidate sets shaped like the generator's (k-way one-hot cluster maps at image resolution): 9 masks per case, with
+    full-height / full-width strips, an empty mask, a tiny and a near-full one, on non-multiple-of-64 sizes."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    cases = []
+    for (h, w) in [(97, 133), (224, 224), (300, 401)]:
+        yy, xx = np.mgrid[:h, :w]
+        ms = []
+        for _ in range(4):  # blobs around a common object: these should win the vote
+            cy, cx = h * rng.uniform(.4, .6), w * rng.uniform(.4, .6)
+            ms.append((((yy - cy) / (h * rng.uniform(.15, .3))) ** 2 + ((xx - cx) / (w * rng.uniform(.15, .3))) ** 2) <= 1)
+        ms.append(xx < w * 0.3)                       # spans the full height: "long"
+        ms.append(yy > h * 0.6)                       # spans the full width: "long"
+        ms.append(np.zeros((h, w), bool))             # predicts nothing
+        ms.append((yy > 3) & (yy < 9) & (xx > 5) & (xx < 12))            # tiny
+        ms.append((yy >= 1) & (yy < h - 1) & (xx >= 1) & (xx < w - 1))   # nearly everything, not touching the border
+        cases.append(np.stack(ms).astype(np.uint8))
+    return cases
+
+
+def gen_voting():
+    """utils.misc.filter_masks (the REAL reference function) on the candidate sets, for both flag combinations."""
+    sys.path.insert(0, REF)
+    if "natsort" not in sys.modules:
+        m = types.ModuleType("natsort")
+        m.natsorted = sorted
+        sys.modules["natsort"] = m
+    from utils.misc import filter_masks
+    save = {}
+    for i, masks in enumerate(_voting_cases()):
+        save[f"masks_{i}"] = masks
+        for tag, (rl, rs) in {"long": (True, False), "both": (True, True), "none": (False, False)}.items():
+            kept, new_to_prev = filter_masks(torch.from_numpy(masks), remove_long_masks=rl, remove_small_large_masks=rs)
+            save[f"kept_{i}_{tag}"] = np.array([new_to_prev[k] for k in range(len(new_to_prev))], np.int32)
+            print(i, tag, "survivors:", save[f"kept_{i}_{tag}"].tolist())
+    save["n_cases"] = np.array(len(_voting_cases()))
+    np.savez_compressed(os.path.join(GOLD, "voting.npz"), **save)
+
+
 def _metric_cases():
     """(pred, gt) pairs covering the branches of metrics/*.py (all-zero / all-one GT, empty prediction, ties)."""
     rng = np.random.Generator(np.random.PCG64(77))
@@ -267,6 +306,8 @@ if __name__ == "__main__":
         gen_forward()
     if a.only in (None, "forward3d"):
         gen_forward3d()
+    if a.only in (None, "voting"):
+        gen_voting()
     if a.only in (None, "metrics"):
         gen_metrics()
     if a.only in (None, "bilateral"):

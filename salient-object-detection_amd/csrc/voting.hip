@@ -1,0 +1,150 @@
+// Spectral-cluster VOTING step of the pseudo-mask generator (BASELINE.json configs[4]): among the candidate
+// masks of one image (27 in the reference: 3 backbones x k = 2, 3, 4 clusters), drop the degenerate ones and keep the mask
+// that agrees most with all the others.
+//   filter_masks / mask_to_bbox   utils/misc.py:269-314 (same logic as mask_generator.pyc@L40-87)
+//   vote_mask                     mask_generator.pyc@L202-230: iou[i][j] = |mi & mj| / (|mi | mj| + 1e-7)
+//                                 over the surviving masks, score = row sum, best = argsort(descending)[0]
+// The clustering that PRODUCES the candidates (faiss k-NN affinity + eigen-decomposition) is absent from the reference in
+// any form and stays out of scope.
+//
+// Byte / integer work, HBM-bound on reading the masks once: each mask becomes a bitmap (64 pixels per wave ballot), its
+// bounding box and area come from integer atomics (deterministic), and the pairwise intersections are popcounts of ANDed
+// bitmap words - M (M+1) / 2 pairs x H W / 64 words, nothing next to the first pass.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace sm {
+
+struct VoteBox { int ymin, ymax, xmin, xmax; unsigned area; };
+
+__global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __restrict__ masks, unsigned long long* __restrict__ bits,
+                                                       VoteBox* __restrict__ box, int H, int W, int words) {
+    const int m = blockIdx.y;
+    const int64_t npx = (int64_t)H * W;
+    const unsigned char* src = masks + (int64_t)m * npx;
+    const int lane = threadIdx.x & 63;
+    int ymin = 1 << 30, ymax = -1, xmin = 1 << 30, xmax = -1;
+    unsigned area = 0;
+    for (int wd = blockIdx.x * 4 + (threadIdx.x >> 6); wd < words; wd += gridDim.x * 4) {
+        const int64_t p = (int64_t)wd * 64 + lane;
+        const bool on = p < npx && src[p] != 0;
+        const unsigned long long word = __ballot(on);
+        if (lane == 0) bits[(int64_t)m * words + wd] = word;
+        if (on) {
+            const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+            ymin = min(ymin, y); ymax = max(ymax, y); xmin = min(xmin, x); xmax = max(xmax, x);
+            area += 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ymin = min(ymin, __shfl_xor(ymin, o, 64)); ymax = max(ymax, __shfl_xor(ymax, o, 64));
+        xmin = min(xmin, __shfl_xor(xmin, o, 64)); xmax = max(xmax, __shfl_xor(xmax, o, 64));
+        area += __shfl_xor(area, o, 64);
+    }
+    if (lane == 0 && area) {
+        atomicMin(&box[m].ymin, ymin); atomicMax(&box[m].ymax, ymax);
+        atomicMin(&box[m].xmin, xmin); atomicMax(&box[m].xmax, xmax);
+        atomicAdd(&box[m].area, area);
+    }
+}
+
+__global__ __launch_bounds__(256) void vote_init_kernel(VoteBox* box, unsigned* inter, int M) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < M) { box[t].ymin = 1 << 30; box[t].ymax = -1; box[t].xmin = 1 << 30; box[t].xmax = -1; box[t].area = 0; }
+    if (t < M * M) inter[t] = 0;
+}
+
+// one workgroup per (pair (i, j >= i), word chunk)
+__global__ __launch_bounds__(256) void vote_pairs_kernel(const unsigned long long* __restrict__ bits, unsigned* __restrict__ inter, int M,
+                                                        int words) {
+    int i = 0, rem = blockIdx.y;  // pair index -> (i, j): row i holds M - i pairs
+    while (rem >= M - i) { rem -= M - i; ++i; }
+    const int j = i + rem;
+    const unsigned long long* a = bits + (int64_t)i * words;
+    const unsigned long long* b = bits + (int64_t)j * words;
+    unsigned c = 0;
+    for (int wd = blockIdx.x * 256 + threadIdx.x; wd < words; wd += gridDim.x * 256) c += __popcll(a[wd] & b[wd]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&inter[i * M + j], c);
+}
+
+__global__ __launch_bounds__(64) void vote_finalize_kernel(const VoteBox* __restrict__ box, const unsigned* __restrict__ inter, int M, int H,
+                                                          int W, int remove_long, int remove_small_large, int* __restrict__ keep,
+                                                          float* __restrict__ iou, float* __restrict__ row_sums, int* __restrict__ best) {
+    const int t = threadIdx.x;
+    __shared__ int skeep[64];
+    if (t < M) {
+        const VoteBox b = box[t];
+        int k = b.area > 0;  // mask_to_bbox skips masks that predict nothing (misc.py:277-281)
+        if (k && remove_long) {
+            if (b.ymin == 0 && b.ymax + 1 == H) k = 0;
+            else if (b.xmin == 0 && b.xmax + 1 == W) k = 0;
+        }
+        if (k && remove_small_large) {  // misc.py:302-306: tensor sum (fp32 after promotion) against python doubles
+            if ((float)b.area < (float)(0.05 * H * W)) k = 0;
+            else if ((double)((b.xmax - b.xmin) * (b.ymax - b.ymin)) > 0.95 * H * W) k = 0;
+        }
+        skeep[t] = k;
+        keep[t] = k;
+    }
+    __syncthreads();
+    if (t < M) {
+        float s = 0.f;
+        for (int j = 0; j < M; ++j) {
+            float v = 0.f;
+            if (skeep[t] && skeep[j]) {
+                const unsigned in = t <= j ? inter[t * M + j] : inter[j * M + t];
+                const unsigned un = box[t].area + box[j].area - in;
+                v = (float)in / ((float)un + 1e-7f);
+                s = s + v;  // surviving masks in index order
+            }
+            iou[t * M + j] = v;
+        }
+        row_sums[t] = skeep[t] ? s : -1.f;
+    }
+    __syncthreads();
+    if (t == 0) {  // first maximum among the survivors (ties: the fixtures are tie-free, torch's argsort is unstable)
+        int bi = -1;
+        float bs = -1.f;
+        for (int i = 0; i < M; ++i)
+            if (skeep[i] && row_sums[i] > bs) { bs = row_sums[i]; bi = i; }
+        *best = bi;
+    }
+}
+
+}  // namespace sm
+
+extern "C" size_t sm_vote_workspace_bytes(int32_t M, int32_t H, int32_t W) {
+    if (M <= 0 || M > 64 || H <= 0 || W <= 0) return 0;
+    const size_t words = ((size_t)H * W + 63) / 64;
+    return (((size_t)M * words * 8 + 255) & ~(size_t)255) + (((size_t)M * sizeof(sm::VoteBox) + 255) & ~(size_t)255) +
+           (((size_t)M * M * 4 + 255) & ~(size_t)255);
+}
+
+extern "C" int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int32_t remove_long, int32_t remove_small_large,
+                                int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    SM_REQUIRE(masks && keep && iou && row_sums && best && workspace, "sm_vote_masks_u8: null pointer");
+    SM_REQUIRE(M > 0 && M <= 64 && H > 0 && W > 0, "sm_vote_masks_u8: M=%d candidates (1..64), %dx%d", M, H, W);
+    SM_REQUIRE(workspace_bytes >= sm_vote_workspace_bytes(M, H, W) && ((uintptr_t)workspace % 256) == 0,
+               "sm_vote_masks_u8: workspace too small or misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int words = (int)(((size_t)H * W + 63) / 64);
+    char* w = (char*)workspace;
+    auto* bits = (unsigned long long*)w;
+    w += ((size_t)M * words * 8 + 255) & ~(size_t)255;
+    auto* box = (sm::VoteBox*)w;
+    w += ((size_t)M * sizeof(sm::VoteBox) + 255) & ~(size_t)255;
+    auto* inter = (unsigned*)w;
+    hipLaunchKernelGGL(sm::vote_init_kernel, dim3((M * M + 255) / 256), dim3(256), 0, st, box, inter, M);
+    const int gx = (words + 3) / 4 < 256 ? (words + 3) / 4 : 256;
+    hipLaunchKernelGGL(sm::vote_pack_kernel, dim3(gx, M), dim3(256), 0, st, masks, bits, box, H, W, words);
+    hipLaunchKernelGGL(sm::vote_pairs_kernel, dim3((words + 255) / 256 < 16 ? (words + 255) / 256 : 16, M * (M + 1) / 2), dim3(256), 0, st,
+                       bits, inter, M, words);
+    hipLaunchKernelGGL(sm::vote_finalize_kernel, dim3(1), dim3(64), 0, st, box, inter, M, H, W, remove_long, remove_small_large, keep, iou,
+                       row_sums, best);
+    return sm::check_launch("sm_vote_masks_u8");
+}
