@@ -723,9 +723,13 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
     return nullptr;
 }
 
-// Measured on MI355X alone on the GPU (scripts/gemm_w16_sweep.py, M = 12608): N = 384 outputs (proj, fc2) are fastest as
-// 128 x 64 tiles (three workgroups per CU), wider ones as 128 x 128 with eight waves; 256 x 128 tiles - 3/4 of the staged
-// bytes per MFMA - are NOT faster (+-3 %): the kernel is not bound by staging bandwidth.
+// Tile choice.  Alone on the GPU every shape from 128 x 64 to 256 x 256 lands within a few per cent of the others
+// (scripts/gemm_w16_sweep.py; 128 x 64 is even the fastest for N = 384 because it fills the CUs best).  What ships is
+// decided by the quantity the bench measures - three batches in flight, the chip at its power limit (1.9 GHz), other
+// streams' kernels filling every idle CU: there the shapes that stage the fewest bytes per MFMA win (profiles/
+// r02_pipeline_variant_sweep.log): 256 x 256 tiles (one workgroup of 16 waves per CU) for outputs that are a multiple of
+// 256 wide, 256 x 128 with a three-stage ring otherwise - +3...6 % images/s over 128 x 128 / 128 x 64 although a lone
+// launch is no faster.  Small problems (decoder, batch 1) keep 128 x 128 / 128 x 64 / 64 x 64 by workgroup count.
 extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     if (!g) return -1;
     static const int forced_w = getenv("SM_W16_VARIANT_WIDE") ? atoi(getenv("SM_W16_VARIANT_WIDE")) : -1;    // tuning knobs
@@ -733,9 +737,18 @@ extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     const long nb = g->split_k > 1 ? g->split_k : 1;
     const long wg128x64 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * nb;
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
+    const long wg256x128 = (long)((g->M + 255) / 256) * ((g->N + 127) / 128) * nb;
+    const long wg256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256) * nb;
     if (wg128x64 < 512) return 4;
-    if (g->N <= 384 || wg128 < 256) return forced_n >= 0 ? forced_n : 7;
-    return forced_w >= 0 ? forced_w : 2;
+    const bool narrow = g->N <= 384;
+    if (narrow && forced_n >= 0) return forced_n;
+    if (!narrow && forced_w >= 0) return forced_w;
+    if (g->alt_from_n == 0 || g->alt_from_n % 256 == 0) {
+        if (g->N % 256 == 0 && g->N >= 1024 && wg256 >= 128) return 32;  // 256 x 256
+        if (wg256x128 >= 128) return 31;                                  // 256 x 128, ring of three
+    }
+    if (wg128 >= 256) return 2;
+    return 7;
 }
 
 extern "C" int sm_gemm_w16(const sm_gemm_args* g, int out_f16x2, void* stream) {
