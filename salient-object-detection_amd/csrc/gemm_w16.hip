@@ -684,6 +684,7 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 33: return sm::launch_gemm_w<128, 128, 32, 4, 2, 4, 4>(a, st);   // 8 waves of 64x32, 128 KiB
         case 34: return sm::launch_gemm_w<128, 128, 32, 5, 2, 4, 4>(a, st);   // ... 160 KiB
         case 35: return sm::launch_gemm_w<256, 128, 16, 6, 4, 2, 2>(a, st);   // 8 waves of 64x64, 16-k stages x 6, 144 KiB
+        case 36: return sm::launch_gemm_w<512, 128, 32, 2, 8, 2, 4>(a, st);   // 16 waves of 64x64, 160 KiB: fewest bytes per MFMA at N = 384
         // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
         case 20: case 21: case 22: case 23: case 24: {
             SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
@@ -719,6 +720,7 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 33: return "gemm_w16_kernel<128, 128, 32, 4, 2, 4, 4, 0>";
         case 34: return "gemm_w16_kernel<128, 128, 32, 5, 2, 4, 4, 0>";
         case 35: return "gemm_w16_kernel<256, 128, 16, 6, 4, 2, 2, 0>";
+        case 36: return "gemm_w16_kernel<512, 128, 32, 2, 8, 2, 4, 0>";
     }
     return nullptr;
 }

@@ -6,7 +6,7 @@ import glob
 import sys
 
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
-rows = list(csv.DictReader(open(f)))
+rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))  # the CSV is not in launch order
 idx = [i for i, r in enumerate(rows) if "im2col" in r["Kernel_Name"]]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 s = idx[which]
