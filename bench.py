@@ -460,8 +460,14 @@ def main():
                              flops_per_launch=dom["flops_per_launch"],
                              share_of_forward=round(dom["total_ms_per_forward"] / sum(v["total_ms_per_forward"] for v in kern.values()), 3),
                              event_overhead_us=round(dom["event_overhead_us"], 2),
-                             how="HIP events around every launch of this kernel inside 3 real forwards "
-                                 "(sm_forward_timing); an empty event pair's time (event_overhead_us) is subtracted per launch"),
+                             how="HIP events around every launch of this kernel inside 3 real forwards on ONE stream "
+                                 "(sm_forward_timing); an empty event pair's time (event_overhead_us) is subtracted per launch",
+                             whole_step={"achieved": round(value / world * flops_img / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                         "frac": round(value / world * flops_img / 1e12 / peak, 4),
+                                         "mfma_issued_tflops": round(value / world * flops_img / 1e12 * issue, 2),
+                                         "what": "algorithmic FLOPs of the forward x images/s of the timed region, per GPU: the rate the "
+                                                 "three-batches-in-flight pipeline sustains (the tile shapes are chosen for THIS figure; "
+                                                 "a lone launch of the dominant kernel is slower than with smaller tiles)"}),
             "roofline_other_kernels": {k: dict(roof(v, k), avg_launch_us=round(v["avg_launch_us"], 2),
                                                launches_per_forward=v["launches_per_forward"])
                                        for k, v in list(kern.items())[1:]},
