@@ -332,6 +332,216 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
     }
 }
 
+// ---- 16x16x32 MFMA variant -------------------------------------------------------------------------------------------------
+// The same GEMM on v_mfma_f32_16x16x32_f16.  Why: with three batches in flight the chip sits at its power limit, and in
+// an MFMA-dense loop on random operands the 16x16x32 shape sustains 12-14 % more FLOP/s than 32x32x16 at the same cycles
+// per FLOP (scripts/mb/mfma_shape.hip: 1.75 vs 1.55 PFLOP/s; MI355X_MICROARCH.md, DVFS give-back item 7).
+// A / B operands: lane l holds row (l & 15), k-group (l >> 4) of a 32-k stage - one 16-B hi chunk and one 16-B lo chunk per
+// fragment, so a stage is ONE MFMA step.  C: lane l holds output row m = l & 15 and four consecutive n = 4 (l >> 4) + reg.
+// LDS image of a 128-B stage row (four k-groups x [hi | lo]): the XOR swizzle of the 32x32 kernel puts two lanes of every
+// ds_read_b128 group on one 16-B slot here (the 16 lanes of a group are 8 rows of k-group a and 8 rows of k-group a ^ 1), so
+// the pair of k-group kg sits at pair position (kg + 2 * ((row >> 3) & 1)) % 4 and hi / lo swap places on rows with
+// (row >> 1) & 1 - conflict-free for all four lane groups and both halves (brute-forced over the 4^8 x 2^8 layouts of this
+// family).  The LDS-DMA destination is linear, so the permutation goes on the per-lane SOURCE address, as before.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int m16_slot(int row, int kg, int x) {  // 16-B slot of (k-group kg, x = 0 hi / 1 lo) in its stage row
+    return 2 * ((kg + 2 * ((row >> 3) & 1)) & 3) + (x ^ ((row >> 1) & 1));
+}
+
+template <int BM, int BN, int NST, int NWM, int NWN, int WPS>
+__global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gemm_args g) {
+    constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
+    constexpr int TM = WTM / 16, TN = WTN / 16;       // 16x16 tiles per wave
+    constexpr int ROWB = 128;
+    constexpr int A_INST = BM / 8 / NW, W_INST = BN / 8 / NW;
+    static_assert(A_INST * 8 * NW == BM && W_INST * 8 * NW == BN && TM * 16 * NWM == BM && TN * 16 * NWN == BN && (TM % 2) == 0, "tile split");
+    constexpr int NI = A_INST + W_INST;
+    constexpr int A_STAGE = BM * ROWB, W_STAGE = BN * ROWB, W_RING = NST * A_STAGE, RING_BYTES = NST * (A_STAGE + W_STAGE);
+    extern __shared__ __attribute__((aligned(16))) char smemm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int r16 = lane & 15, kg = lane >> 4;
+    int tile_id = blockIdx.x;
+    const int ntn = (g.N + BN - 1) / BN;
+    {
+        const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = tile_id & 7, slot = tile_id >> 3;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    }
+    const int n0 = (tile_id % ntn) * BN, m0 = (tile_id / ntn) * BM;
+    const int M = g.M, N = g.N;
+    const int split = g.split_k > 1 ? g.split_k : 1;
+    const int nk = g.K / 32 / split;
+    const int k_begin = split > 1 ? (int)blockIdx.z * nk * 32 : 0;
+    const char* A = reinterpret_cast<const char*>(((g.alt_from_n > 0 && n0 >= g.alt_from_n) ? g.A_alt : g.A) + k_begin);
+    const char* W = reinterpret_cast<const char*>(g.W + k_begin);
+    // DMA: lane -> (row = lane >> 3 of its 8-row piece, slot p = lane & 7); the slot holds chunk (2 kg + x) with
+    // kg = ((p >> 1) + 2 * ((row >> 3) & 1)) & 3 (the pair rotation is its own inverse), x = (p & 1) ^ ((row >> 1) & 1)
+    const char* a_src[A_INST];
+    const char* w_src[W_INST];
+    auto src_chunk = [&](int row) { const int p = lane & 7; return 2 * (((p >> 1) + 2 * ((row >> 3) & 1)) & 3) + ((p & 1) ^ ((row >> 1) & 1)); };
+#pragma unroll
+    for (int i = 0; i < A_INST; ++i) {
+        const int row = (wave * A_INST + i) * 8 + (lane >> 3);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        a_src[i] = A + ((int64_t)gm * g.lda) * 4 + src_chunk(row) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < W_INST; ++i) {
+        const int row = (wave * W_INST + i) * 8 + (lane >> 3);
+        int gn = n0 + row;
+        gn = gn < N ? gn : N - 1;
+        w_src[i] = W + ((int64_t)gn * g.ldw) * 4 + src_chunk(row) * 16;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smemm;
+    auto issue_step = [&](int kt) {
+        const int t = kt + NST - 1;
+        const int tt = t < nk ? t : nk - 1, slot = t % NST;
+        const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + wave * W_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < W_INST; ++i) lds_dma16(w_src[i] + tt * ROWB, sw + i * 1024);
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + wave * A_INST * 1024);
+#pragma unroll
+        for (int i = 0; i < A_INST; ++i) lds_dma16(a_src[i] + tt * ROWB, sa + i * 1024);
+    };
+    // fragment offsets: tile rows are multiples of 16, so the slot of (row = base + r16, kg) does not depend on the tile
+    const int off_hi = r16 * ROWB + m16_slot(r16, kg, 0) * 16, off_lo = r16 * ROWB + m16_slot(r16, kg, 1) * 16;
+    const int a_base = wm * WTM * ROWB, w_base = wn * WTN * ROWB;
+
+    f32x4v acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
+#pragma unroll
+    for (int v = -(NST - 1); v < 0; ++v) issue_step(v);
+    const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                        (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt_w<(NST - 2) * NI>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_step(kt);
+        const char* sta = smemm + (kt % NST) * A_STAGE + a_base;
+        const char* stw = smemm + W_RING + (kt % NST) * W_STAGE + w_base;
+        f16x8 ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            wh[j] = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_hi);
+            wl[j] = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_lo);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(sta + i * 16 * ROWB + off_hi);
+            al[i] = *reinterpret_cast<const f16x8*>(sta + i * 16 * ROWB + off_lo);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const f16x8 whs = wh[j] * down;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, al[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    wait_vmcnt_w<0>();
+
+    float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : 0) * g.strideC;
+    const bool out_split = g.patch_n < 0;
+    const float ws = g.w_scale;
+    constexpr int EPLD = WTN * 4 + 16;
+    constexpr int PIECES = WTN / 4;
+    static_assert(NW * 32 * EPLD <= RING_BYTES, "epilogue staging must fit in the ring");
+    __builtin_amdgcn_s_barrier();
+    char* ep = smemm + wave * (32 * EPLD);
+
+    auto run = [&](auto epi_tag, auto fmt_tag) {
+        constexpr int EPI = decltype(epi_tag)::value;
+        constexpr bool F = decltype(fmt_tag)::value;
+#pragma unroll
+        for (int ib = 0; ib < TM / 2; ++ib) {  // 32 staged rows = two 16-row tiles
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * ib + ii, row = ii * 16 + r16;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = j * 16 + 4 * kg, n = n0 + wn * WTN + nl;  // this lane: columns nl .. nl+3 of its row
+                    float t[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = (g.bias && n < N) ? g.bias[n + e] : 0.f;
+                        t[e] = acc[i][j][e] * ws + b;
+                        if constexpr (EPI == SM_EPI_GELU) t[e] = 0.5f * t[e] * (1.0f + fast_erff(t[e] * 0.70710678118654752440f));
+                        else if constexpr (EPI == SM_EPI_RELU) t[e] = fmaxf(t[e], 0.f);
+                    }
+                    if constexpr (F) {  // F16X2: elements nl..nl+3 of group nl / 8: hi at 32 G + 8 (kg & 1), lo 16 B further
+                        f16x4 hi, lo;
+                        split4(t, hi, lo);
+                        char* p = ep + row * EPLD + (nl >> 3) * 32 + (kg & 1) * 8;
+                        *reinterpret_cast<f16x4*>(p) = hi;
+                        *reinterpret_cast<f16x4*>(p + 16) = lo;
+                    } else {
+                        *reinterpret_cast<float4*>(ep + row * EPLD + nl * 4) = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 32 * PIECES / 64; ++it) {
+                const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
+                int m = m0 + wm * WTM + ib * 32 + row;
+                const int n = n0 + wn * WTN + pc * 4;
+                if (m < M && n < N) {
+                    float4 v = *reinterpret_cast<const float4*>(ep + row * EPLD + pc * 16);
+                    if constexpr (EPI == SM_EPI_RESIDUAL) {
+                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)m * g.ldr + n);
+                        v.x = rr.x + v.x; v.y = rr.y + v.y; v.z = rr.z + v.z; v.w = rr.w + v.w;
+                    } else if constexpr (EPI == SM_EPI_PATCH) {
+                        const int img = m / g.patch_n, p = m - img * g.patch_n;
+                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                        m = img * (g.patch_n + 1) + 1 + p;
+                    }
+                    *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+    using T = std::true_type;
+    using Fa = std::false_type;
+    switch (g.epilogue) {
+        case SM_EPI_GELU: out_split ? run(std::integral_constant<int, SM_EPI_GELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_GELU>{}, Fa{}); break;
+        case SM_EPI_RELU: out_split ? run(std::integral_constant<int, SM_EPI_RELU>{}, T{}) : run(std::integral_constant<int, SM_EPI_RELU>{}, Fa{}); break;
+        case SM_EPI_RESIDUAL: run(std::integral_constant<int, SM_EPI_RESIDUAL>{}, Fa{}); break;
+        case SM_EPI_PATCH: run(std::integral_constant<int, SM_EPI_PATCH>{}, Fa{}); break;
+        default: out_split ? run(std::integral_constant<int, SM_EPI_BIAS>{}, T{}) : run(std::integral_constant<int, SM_EPI_BIAS>{}, Fa{}); break;
+    }
+}
+
+template <int BM, int BN, int NST, int NWM, int NWN, int WPS>
+static int launch_gemm_m16(const sm_gemm_args& g, hipStream_t st) {
+    dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : 1);
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
+    if (lds > 64 * 1024) {
+        static std::once_flag attr_once;
+        std::call_once(attr_once, [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w16m16_kernel<BM, BN, NST, NWM, NWN, WPS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipGetLastError();
+        });
+    }
+    hipLaunchKernelGGL((gemm_w16m16_kernel<BM, BN, NST, NWM, NWN, WPS>), grid, dim3(NWM * NWN * 64), lds, st, g);
+    return check_launch("sm_gemm_w16 (16x16x32)");
+}
+
 // ---- persistent variant ----------------------------------------------------------------------------------------------------
 // What the one-tile-per-workgroup kernel above cannot hide: every workgroup of a launch starts
 // together, so all of them wait for their first K-tiles together, run their MFMA loops together and write their C tiles
@@ -685,6 +895,12 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 34: return sm::launch_gemm_w<128, 128, 32, 5, 2, 4, 4>(a, st);   // ... 160 KiB
         case 35: return sm::launch_gemm_w<256, 128, 16, 6, 4, 2, 2>(a, st);   // 8 waves of 64x64, 16-k stages x 6, 144 KiB
         case 36: return sm::launch_gemm_w<512, 128, 32, 2, 8, 2, 4>(a, st);   // 16 waves of 64x64, 160 KiB: fewest bytes per MFMA at N = 384
+        // v_mfma_f32_16x16x32_f16 forms of the shipped shapes
+        case 40: return sm::launch_gemm_m16<256, 256, 2, 2, 8, 4>(a, st);   // as 32: 16 waves of 128x32
+        case 41: return sm::launch_gemm_m16<256, 128, 3, 4, 2, 2>(a, st);   // as 31: 8 waves of 64x64, ring of three
+        case 42: return sm::launch_gemm_m16<128, 128, 2, 2, 4, 4>(a, st);   // as 2
+        case 44: return sm::launch_gemm_m16<64, 64, 3, 2, 2, 3>(a, st);     // as 4
+        case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // as 7
         // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
         case 20: case 21: case 22: case 23: case 24: {
             SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
@@ -721,6 +937,11 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 34: return "gemm_w16_kernel<128, 128, 32, 5, 2, 4, 4, 0>";
         case 35: return "gemm_w16_kernel<256, 128, 16, 6, 4, 2, 2, 0>";
         case 36: return "gemm_w16_kernel<512, 128, 32, 2, 8, 2, 4, 0>";
+        case 40: return "gemm_w16m16_kernel<256, 256, 2, 2, 8, 4>";
+        case 41: return "gemm_w16m16_kernel<256, 128, 3, 4, 2, 2>";
+        case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4>";
+        case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3>";
+        case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3>";
     }
     return nullptr;
 }
@@ -741,16 +962,19 @@ extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
     const long wg256x128 = (long)((g->M + 255) / 256) * ((g->N + 127) / 128) * nb;
     const long wg256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256) * nb;
-    if (wg128x64 < 512) return 4;
+    // SM_W16_MFMA=32 selects the v_mfma_f32_32x32x16_f16 kernels of the same shapes (tuning knob; the 16x16x32 forms are
+    // +4.7 % images/s in the pipeline and 10-15 % faster alone: less energy per FLOP at the chip's power limit)
+    static const bool m32 = getenv("SM_W16_MFMA") && atoi(getenv("SM_W16_MFMA")) == 32;
+    if (wg128x64 < 512) return m32 ? 4 : 44;
     const bool narrow = g->N <= 384;
     if (narrow && forced_n >= 0) return forced_n;
     if (!narrow && forced_w >= 0) return forced_w;
     if (g->alt_from_n == 0 || g->alt_from_n % 256 == 0) {
-        if (g->N % 256 == 0 && g->N >= 1024 && wg256 >= 128) return 32;  // 256 x 256
-        if (wg256x128 >= 128) return 31;                                  // 256 x 128, ring of three
+        if (g->N % 256 == 0 && g->N >= 1024 && wg256 >= 128) return m32 ? 32 : 40;  // 256 x 256
+        if (wg256x128 >= 128) return m32 ? 31 : 41;                                  // 256 x 128, ring of three
     }
-    if (wg128 >= 256) return 2;
-    return 7;
+    if (wg128 >= 256) return m32 ? 2 : 42;
+    return m32 ? 7 : 45;
 }
 
 extern "C" int sm_gemm_w16(const sm_gemm_args* g, int out_f16x2, void* stream) {
