@@ -151,7 +151,15 @@ __device__ __forceinline__ float fast_erff(float x) {
     return t < 1.0f ? x * q : big;
 }
 
+// LDS image of a 128-B stage row (four 8-k groups x [hi | lo]) for the fragment reads of v_mfma_f32_16x16x32_f16 (lane =
+// (row & 15, k-group)): 16-B slot of (k-group kg, x = 0 hi / 1 lo) in its row - see gemm_w16.hip
+__device__ __forceinline__ int m16_slot(int row, int kg, int x) { return 2 * ((kg + 2 * ((row >> 3) & 1)) & 3) + (x ^ ((row >> 1) & 1)); }
+// inverse, for the LDS-DMA source address: the chunk (2 kg + x) that lives in slot p of `row`
+__device__ __forceinline__ int m16_chunk_of_slot(int row, int p) { return 2 * (((p >> 1) + 2 * ((row >> 3) & 1)) & 3) + ((p & 1) ^ ((row >> 1) & 1)); }
+
 // row of a 32x32 MFMA accumulator held in register v by lane-half h  (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
 }  // namespace sm
+
+const char* sm_qkv_attention_kernel_name();  // qkv_attention.hip: rocprofv3 name of the selected fused kernel

@@ -345,9 +345,6 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
 // family).  The LDS-DMA destination is linear, so the permutation goes on the per-lane SOURCE address, as before.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ int m16_slot(int row, int kg, int x) {  // 16-B slot of (k-group kg, x = 0 hi / 1 lo) in its stage row
-    return 2 * ((kg + 2 * ((row >> 3) & 1)) & 3) + (x ^ ((row >> 1) & 1));
-}
 
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS>
 __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gemm_args g) {
@@ -380,7 +377,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
     // kg = ((p >> 1) + 2 * ((row >> 3) & 1)) & 3 (the pair rotation is its own inverse), x = (p & 1) ^ ((row >> 1) & 1)
     const char* a_src[A_INST];
     const char* w_src[W_INST];
-    auto src_chunk = [&](int row) { const int p = lane & 7; return 2 * (((p >> 1) + 2 * ((row >> 3) & 1)) & 3) + ((p & 1) ^ ((row >> 1) & 1)); };
+    auto src_chunk = [&](int row) { return m16_chunk_of_slot(row, lane & 7); };
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
         const int row = (wave * A_INST + i) * 8 + (lane >> 3);

@@ -343,7 +343,292 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
     }
 }
 
+// ---- the same kernel on v_mfma_f32_16x16x32_f16 ---------------------------------------------------------------------------
+// Less energy per FLOP at the chip's power limit (gemm_w16.hip, 16x16x32 variant) and 16-row granularity.  The operand
+// reuse carries over tile for tile: a 16x16 accumulator holds, per lane (c = lane & 15, kg = lane >> 4), column c and rows
+// 4 kg + reg; two such tiles along the contraction axis are the 8 k-elements lane-group kg supplies to one 32-k step of the
+// next product, in the order k = 16 (j >> 2) + 4 kg + (j & 3) - the same on both operands, so Q (B operand of S^T = K Q^T)
+// stays in registers, K rows and V^T rows go to LDS as the 16-B hi / lo pieces the consumer lane (same c, same kg) reads
+// back, and P (the S^T accumulators) is the B operand of O^T = V^T P^T.  A wave owns two 16-token tiles.
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+constexpr int QM_KROWS = QA_TOK;                 // 224 key rows kept (14 tiles; tile 13 only ever holds repeats of the last token)
+constexpr int QM_K_BYTES = QM_KROWS * 256;       // K: [key][dim-step s ^ (key & 1)][slot]: 256 B per key
+constexpr int QM_VLD = QA_WAVES * 128;           // V^T: [dim][32-key step][slot]: 896 B per head-dim (odd multiple of 128 B)
+constexpr int QM_V_BYTES = 64 * QM_VLD;
+static_assert(QM_K_BYTES + QM_V_BYTES <= QA_LDS, "K and V^T overlay the ring");
+
+template <int NST>
+__global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_qkv_attn_args a) {
+    constexpr int ROWB = 128, XT = QA_TOK * ROWB, WT = 192 * ROWB, STAGE = XT + WT;
+    constexpr int XP = XT / 1024, NP = STAGE / 1024, PPW = (NP + QA_WAVES - 1) / QA_WAVES, DUMP = NST * STAGE;
+    static_assert(DUMP + (PPW * QA_WAVES - NP) * 1024 <= QA_LDS, "ring + dump zone must fit in LDS");
+    extern __shared__ __attribute__((aligned(16))) char smm[];
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smm;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, kg = lane >> 4;
+    int head, b;
+    {
+        const int id = blockIdx.x, pairs = a.B * SM_HEADS;
+        int lin = id;
+        if ((pairs & 7) == 0) lin = (id & 7) * (pairs >> 3) + (id >> 3);
+        b = lin / SM_HEADS;
+        head = lin - b * SM_HEADS;
+    }
+    const int N = a.N;
+    const char* X = reinterpret_cast<const char*>(a.Xn + (int64_t)b * N * a.ldx);
+    const char* W = reinterpret_cast<const char*>(a.Wqkv);
+
+    const char* src[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int p = wave + QA_WAVES * j;
+        const int prow = lane >> 3;
+        if (p < XP) {
+            const int row = p * 8 + prow;
+            const int tok = row < N ? row : N - 1;
+            src[j] = X + (int64_t)tok * a.ldx * 4 + m16_chunk_of_slot(row, lane & 7) * 16;
+        } else {
+            const int row = ((p < NP ? p : XP) - XP) * 8 + prow;  // 0..191: [Q dims | K dims | V dims] of this head
+            const int wrow = (row >> 6) * SM_EMBED + head * SM_HEAD_DIM + (row & 63);
+            src[j] = W + (int64_t)wrow * SM_EMBED * 4 + m16_chunk_of_slot(row, lane & 7) * 16;
+        }
+    }
+    auto issue = [&](int kt, int slot) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave + QA_WAVES * j;
+            const unsigned d = p < NP ? lds0 + slot * STAGE + p * 1024 : lds0 + DUMP + (p - NP) * 1024;
+            lds_dma16(src[j] + kt * ROWB, __builtin_amdgcn_readfirstlane(d));
+        }
+    };
+    // fragment offsets: tiles start at multiples of 16 rows, so a lane's slot does not depend on the tile
+    const int f_hi = c16 * ROWB + m16_slot(c16, kg, 0) * 16, f_lo = c16 * ROWB + m16_slot(c16, kg, 1) * 16;
+
+    f32x4q acc[12][2];  // [Q dims 0-15 .. 48-63 | K ... | V ...][token tile of this wave]
+#pragma unroll
+    for (int d = 0; d < 12; ++d)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[d][t][v] = 0.f;
+    const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
+                        (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
+    constexpr int NKT = SM_EMBED / 32;
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t) issue(t, t);
+    for (int kt = 0; kt < NKT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int t = kt + NST - 1;
+            issue(t < NKT ? t : NKT - 1, t % NST);
+        }
+        const char* st = smm + (kt % NST) * STAGE;
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            xh[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_hi);
+            xl[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_lo);
+        }
+#pragma unroll
+        for (int d = 0; d < 12; ++d) {
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_hi);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_lo);
+            const f16x8 whs = wh * down;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if (d < 8) {  // Q^T, K^T: D[dim][token]
+                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc[d][t], 0, 0, 0);
+                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[t], acc[d][t], 0, 0, 0);
+                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, xl[t], acc[d][t], 0, 0, 0);
+                } else {      // V: D[token][dim]
+                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wh, acc[d][t], 0, 0, 0);
+                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wl, acc[d][t], 0, 0, 0);
+                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], whs, acc[d][t], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // the ring becomes K / V^T
+
+    // ---- accumulators -> Q fragments (registers), K and V^T (LDS) ---------------------------------------------------------
+    const float ws = a.w_scale;
+    const float* bq = a.bias + head * SM_HEAD_DIM;
+    const float* bk = bq + SM_EMBED;
+    const float* bv = bk + SM_EMBED;
+    f16x8 qh[2][2], ql[2][2];  // [query tile][dim step s]: element j = dim 32 s + 16 (j >> 2) + 4 kg + (j & 3)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int key = wave * 32 + t * 16 + c16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 kh8, kl8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int dt = 2 * s + (j >> 2), d = 16 * dt + 4 * kg + (j & 3);
+                _Float16 hi, lo;
+                split1(acc[dt][t][j & 3] * ws + bq[d], hi, lo);
+                qh[t][s][j] = hi;
+                ql[t][s][j] = lo;
+                split1(acc[4 + dt][t][j & 3] * ws + bk[d], hi, lo);
+                kh8[j] = hi;
+                kl8[j] = lo;
+            }
+            char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
+            *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 0) * 16) = kh8;
+            *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 1) * 16) = kl8;
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {  // V^T row of head-dim 16 dt + c16: this wave's 32 tokens = key step `wave`
+        const int d = 16 * dt + c16;
+        const float bias = bv[d];
+        f16x8 vh8, vl8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            _Float16 hi, lo;
+            split1(acc[8 + dt][j >> 2][j & 3] * ws + bias, hi, lo);
+            vh8[j] = hi;
+            vl8[j] = lo;
+        }
+        char* vp = smm + QM_K_BYTES + d * QM_VLD + wave * 128;
+        *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 0) * 16) = vh8;
+        *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 1) * 16) = vl8;
+    }
+    __syncthreads();
+
+    // ---- attention: this wave's two 16-query tiles against all keys, 32 keys per step ---------------------------------------
+    const int q0 = wave * 32;
+    if (q0 >= N) return;
+    const float cs = a.scale * 1.44269504088896340736f;
+    f32x4q om[4][2], oc[4][2];  // O^T tiles [dim tile][query tile]: lane holds query c16, dims 4 kg + reg
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { om[dt][t][v] = 0.f; oc[dt][t][v] = 0.f; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const int nsteps = (N + 31) >> 5;
+    for (int stp = 0; stp < nsteps; ++stp) {
+        // scores: S^T tile [key tile kt][query tile t] = sum over the two dim steps
+        f32x4q sc[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = stp * 32 + kt * 16 + c16;
+            f16x8 kh[2], kl[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
+                kh[s] = *reinterpret_cast<const f16x8*>(kp + m16_slot(key, kg, 0) * 16);
+                kl[s] = *reinterpret_cast<const f16x8*>(kp + m16_slot(key, kg, 1) * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4q mn = {0.f, 0.f, 0.f, 0.f}, cr = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    mn = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], qh[t][s], mn, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], ql[t][s], cr, 0, 0, 0);
+                    cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[s], qh[t][s], cr, 0, 0, 0);
+                }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int kidx = stp * 32 + kt * 16 + 4 * kg + v;  // the key this register holds
+                    sc[kt][t][v] = kidx < N ? fmaf(cr[v], 1.0f / 2048.0f, mn[v]) : -INFINITY;
+                }
+            }
+        }
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float cmax = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cmax = fmaxf(cmax, sc[kt][t][v]);
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            const float lim = 8.0f / cs;  // lazy running maximum: p <= 2^8 between moves
+            if (__builtin_amdgcn_ballot_w64(cmax > m_run[t] + lim) != 0) {
+                const float m_new = fmaxf(m_run[t], cmax);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * cs);
+                m_run[t] = m_new;
+                l_run[t] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { om[dt][t][v] *= alpha; oc[dt][t][v] *= alpha; }
+            }
+            const float moff = -m_run[t] * cs;
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {  // element j = key 16 (j >> 2) + 4 kg + (j & 3) of the step
+                const float p = __builtin_amdgcn_exp2f(fmaf(sc[j >> 2][t][j & 3], cs, moff));
+                psum += p;
+                _Float16 hi, lo;
+                split1(p, hi, lo);
+                ph[t][j] = hi;
+                pl[t][j] = lo;
+            }
+            l_run[t] += psum;
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int d = 16 * dt + c16;
+            const char* vp = smm + QM_K_BYTES + d * QM_VLD + stp * 128;
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(vp + m16_slot(d, kg, 0) * 16);
+            const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + m16_slot(d, kg, 1) * 16);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                om[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[t], om[dt][t], 0, 0, 0);
+                oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t], oc[dt][t], 0, 0, 0);
+                oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], oc[dt][t], 0, 0, 0);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float l = l_run[t];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + t * 16 + c16;
+        if (q < N) {
+            float* Orow = a.O + ((int64_t)b * N + q) * a.ldo;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (om[dt][t][e] + oc[dt][t][e] * (1.0f / 2048.0f)) * inv;
+                const int d = head * SM_HEAD_DIM + 16 * dt + 4 * kg;  // this lane's four consecutive head-dims
+                if (a.out_f16x2) store_f16x2_4(Orow, d, x);
+                else *reinterpret_cast<float4*>(Orow + d) = make_float4(x[0], x[1], x[2], x[3]);
+            }
+        }
+    }
+}
+
 }  // namespace sm
+
+// kernel selection: tuning knob (same results up to summation order).  SM_QKV_RING = "m16x2" (default: the 16x16x32-MFMA
+// kernel, 32-k stages, ring of two) | "m16x3" | "32x2" | "32x3" | "16x2" | "16x6" (the 32x32x16-MFMA kernel, "<k per stage>x<stages>")
+static int qkv_mode() {
+    static const char* ring = getenv("SM_QKV_RING");
+    return !ring ? 4 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : !strcmp(ring, "32x2") ? 0 :
+           !strcmp(ring, "m16x3") ? 5 : 4;
+}
+// name rocprofv3 reports for the selected kernel (labels the in-situ taps of forward.hip)
+const char* sm_qkv_attention_kernel_name() {
+    static const char* names[] = {"qkv_attention_kernel<32, 2>", "qkv_attention_kernel<32, 3>", "qkv_attention_kernel<16, 2>",
+                                  "qkv_attention_kernel<16, 6>", "qkv_attention_m16_kernel<2>", "qkv_attention_m16_kernel<3>"};
+    return names[qkv_mode()];
+}
 
 extern "C" int sm_qkv_attention_max_tokens(void) { return sm::QA_KROWS; }
 
@@ -362,15 +647,18 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
         const void* ks[] = {reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 3>),
                             reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 6>)};
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
         (void)hipGetLastError();
     });
     // stage shape of the projection phase: tuning knob (same results), "<k per stage>x<ring stages>"; measured on MI355X with
     // scripts/qkv_attn_bench.py: full 128-B line pieces (32-k stages) move at twice the bytes per address-unit cycle of 64-B pieces
-    static const char* ring = getenv("SM_QKV_RING");
-    const int mode = !ring ? 0 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : 0;
+    const int mode = qkv_mode();
     const dim3 grid(a->B * SM_HEADS), block(sm::QA_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 1) hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 3>), grid, block, sm::QA_LDS, st, *a);
+    if (mode == 4) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 5) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 1) hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 3>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 2) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 2>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 3) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 6>), grid, block, sm::QA_LDS, st, *a);
     else hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 2>), grid, block, sm::QA_LDS, st, *a);
