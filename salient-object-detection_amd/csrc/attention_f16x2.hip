@@ -190,15 +190,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                float pf[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * u + j], cs, moff));  // masked / absent: exp2(-inf) = 0
-                    psum += p;
-                    _Float16 hi, lo;
-                    split1(p, hi, lo);
-                    ph[kb][u][j] = hi;
-                    pl[kb][u][j] = lo;
+                    pf[j] = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * u + j], cs, moff));  // masked / absent: exp2(-inf) = 0
+                    psum += pf[j];
                 }
+                split8(pf, ph[kb][u], pl[kb][u]);
             }
         }
         l_run += psum;

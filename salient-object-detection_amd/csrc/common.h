@@ -62,23 +62,43 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// The hi conversion goes through inline asm so that the value stored and the value subtracted are ONE v_cvt_f16_f32
+// The hi conversion goes through inline asm so that the value stored and the value subtracted are ONE conversion
 // result: left to itself hipcc emitted a packed round-toward-zero convert for a stored vector and a round-to-nearest
 // one for the subtraction (lo then had the wrong sign whenever the two roundings differed).
 __device__ __forceinline__ void split1(float x, _Float16& hi, _Float16& lo) {
     float hf;
-    asm volatile("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(x));
-    asm volatile("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(hi));
+    asm("v_cvt_f16_f32 %0, %1" : "=v"(hi) : "v"(x));
+    asm("v_cvt_f32_f16 %0, %1" : "=v"(hf) : "v"(hi));
     lo = (_Float16)((x - hf) * 2048.0f);
 }
+// Two elements in 5 VALU instructions instead of 12, same bits as split1: one packed round-to-nearest convert (gfx950
+// v_cvt_pk_f16_f32) for the hi pair, then lo = f16(fma(f32(hi), -2048, 2048 x)) by v_fma_mixlo/mixhi_f16, which read the
+// f16 halves of the hi register directly and write the halves of the lo register (2048 (x - hi) is exact in f32, so the
+// single fma rounds like the subtract-multiply-convert chain).
+__device__ __forceinline__ void split2(float x0, float x1, f16x2& hi, f16x2& lo) {
+    unsigned h, l;
+    const float m2048 = -2048.0f;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    const float y0 = x0 * 2048.0f, y1 = x1 * 2048.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "s"(m2048), "v"(y0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "s"(m2048), "v"(y1));
+    hi = __builtin_bit_cast(f16x2, h);
+    lo = __builtin_bit_cast(f16x2, l);
+}
 __device__ __forceinline__ void split4(const float (&x)[4], f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        _Float16 h, l;
-        split1(x[i], h, l);
-        hi[i] = h;
-        lo[i] = l;
-    }
+    f16x2 h0, l0, h1, l1;
+    split2(x[0], x[1], h0, l0);
+    split2(x[2], x[3], h1, l1);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
+}
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+    f16x4 h0, l0, h1, l1;
+    const float a[4] = {x[0], x[1], x[2], x[3]}, b[4] = {x[4], x[5], x[6], x[7]};
+    split4(a, h0, l0);
+    split4(b, h1, l1);
+    hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // byte offset of element k of an F16X2 row: hi half; the lo half lives 16 bytes further
 __device__ __forceinline__ int64_t f16x2_off(int64_t k) { return (k & ~(int64_t)7) * 4 + (k & 7) * 2; }
@@ -93,9 +113,7 @@ __device__ __forceinline__ void store_f16x2_4(void* row, int64_t k, const float 
 // store 2 consecutive elements k, k+1 (k even)
 __device__ __forceinline__ void store_f16x2_2(void* row, int64_t k, float x0, float x1) {
     f16x2 hi, lo;
-    _Float16 h, l;
-    split1(x0, h, l); hi[0] = h; lo[0] = l;
-    split1(x1, h, l); hi[1] = h; lo[1] = l;
+    split2(x0, x1, hi, lo);
     char* p = reinterpret_cast<char*>(row) + f16x2_off(k);
     *reinterpret_cast<f16x2*>(p) = hi;
     *reinterpret_cast<f16x2*>(p + 16) = lo;
@@ -149,6 +167,48 @@ __device__ __forceinline__ float fast_erff(float x) {
     p = fmaf(p, tc, -4.374439013e-04f);
     const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(-p), x);
     return t < 1.0f ? x * q : big;
+}
+
+// The same erf on two values per instruction (v_pk_fma_f32 / v_pk_mul_f32: the fp32 vector rate doubles on packed
+// operands), same operations in the same order per element - bitwise the scalar function's results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fast_erff2(f32x2 x) {
+    const f32x2 t = __builtin_elementwise_abs(x), s = x * x;
+    f32x2 q = 7.882497448e-05f;
+    q = __builtin_elementwise_fma(q, s, (f32x2)(-8.018855006e-04f));
+    q = __builtin_elementwise_fma(q, s, (f32x2)(5.189312156e-03f));
+    q = __builtin_elementwise_fma(q, s, (f32x2)(-2.685432881e-02f));
+    q = __builtin_elementwise_fma(q, s, (f32x2)(1.128359735e-01f));
+    q = __builtin_elementwise_fma(q, s, (f32x2)(-3.761262596e-01f));
+    q = __builtin_elementwise_fma(q, s, (f32x2)(1.128379107e+00f));
+    const f32x2 tc = __builtin_elementwise_min(t, (f32x2)(4.0f));
+    f32x2 p = -2.328598612e-06f;
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(6.577336899e-05f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(-8.551856736e-04f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(6.838695146e-03f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(-3.803624585e-02f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(1.586650759e-01f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(9.116925001e-01f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(1.630485892e+00f));
+    p = __builtin_elementwise_fma(p, tc, (f32x2)(-4.374439013e-04f));
+    const f32x2 xq = x * q;
+    f32x2 r;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(-p[i]), x[i]);
+        r[i] = t[i] < 1.0f ? xq[i] : big;
+    }
+    return r;
+}
+// exact-erf GELU (nn.GELU default) of four values, in place
+__device__ __forceinline__ void gelu4(float (&t)[4]) {
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {
+        const f32x2 x = {t[e], t[e + 1]};
+        const f32x2 y = (0.5f * x) * (1.0f + fast_erff2(x * 0.70710678118654752440f));
+        t[e] = y[0];
+        t[e + 1] = y[1];
+    }
 }
 
 // LDS image of a 128-B stage row (four 8-k groups x [hi | lo]) for the fragment reads of v_mfma_f32_16x16x32_f16 (lane =

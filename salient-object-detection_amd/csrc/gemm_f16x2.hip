@@ -319,14 +319,12 @@ __global__ __launch_bounds__(NWM * NWN * 64, MINB) void gemm_f16x2_kernel(sm_gem
                             const int nx = n0 + wn * WTN + j * 32 + 8 * q + 4 * h + e, ny = nx + 8;
                             x[e] = (acc[i][j][4 * q + e] + crs[i][j][4 * q + e] * (1.0f / 2048.0f)) + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
                             y[e] = (acc[i][j][4 * q + 4 + e] + crs[i][j][4 * q + 4 + e] * (1.0f / 2048.0f)) + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
-                            if constexpr (EPI == SM_EPI_GELU) {
-                                x[e] = 0.5f * x[e] * (1.0f + fast_erff(x[e] * 0.70710678118654752440f));
-                                y[e] = 0.5f * y[e] * (1.0f + fast_erff(y[e] * 0.70710678118654752440f));
-                            } else if constexpr (EPI == SM_EPI_RELU) {
+                            if constexpr (EPI == SM_EPI_RELU) {
                                 x[e] = fmaxf(x[e], 0.f);
                                 y[e] = fmaxf(y[e], 0.f);
                             }
                         }
+                        if constexpr (EPI == SM_EPI_GELU) { gelu4(x); gelu4(y); }
                         pair_groups(x, y);
                         store_f16x2_8(ep + r * EPLD, j * 32 + 8 * (q + h), x, y);
                     }

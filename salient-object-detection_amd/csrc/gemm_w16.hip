@@ -269,14 +269,12 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
                             const int nx = n0 + wn * WTN + j * 32 + 8 * q + 4 * h + e, ny = nx + 8;
                             x[e] = acc[i][j][4 * q + e] * ws + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
                             y[e] = acc[i][j][4 * q + 4 + e] * ws + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
-                            if constexpr (EPI == SM_EPI_GELU) {
-                                x[e] = 0.5f * x[e] * (1.0f + fast_erff(x[e] * 0.70710678118654752440f));
-                                y[e] = 0.5f * y[e] * (1.0f + fast_erff(y[e] * 0.70710678118654752440f));
-                            } else if constexpr (EPI == SM_EPI_RELU) {
+                            if constexpr (EPI == SM_EPI_RELU) {
                                 x[e] = fmaxf(x[e], 0.f);
                                 y[e] = fmaxf(y[e], 0.f);
                             }
                         }
+                        if constexpr (EPI == SM_EPI_GELU) { gelu4(x); gelu4(y); }
                         pair_groups(x, y);
                         store_f16x2_8(ep + r * EPLD, j * 32 + 8 * (q + h), x, y);
                     }
@@ -475,9 +473,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                     for (int e = 0; e < 4; ++e) {
                         const float b = (g.bias && n < N) ? g.bias[n + e] : 0.f;
                         t[e] = acc[i][j][e] * ws + b;
-                        if constexpr (EPI == SM_EPI_GELU) t[e] = 0.5f * t[e] * (1.0f + fast_erff(t[e] * 0.70710678118654752440f));
-                        else if constexpr (EPI == SM_EPI_RELU) t[e] = fmaxf(t[e], 0.f);
+                        if constexpr (EPI == SM_EPI_RELU) t[e] = fmaxf(t[e], 0.f);
                     }
+                    if constexpr (EPI == SM_EPI_GELU) gelu4(t);
                     if constexpr (F) {  // F16X2: elements nl..nl+3 of group nl / 8: hi at 32 G + 8 (kg & 1), lo 16 B further
                         f16x4 hi, lo;
                         split4(t, hi, lo);
@@ -688,14 +686,12 @@ __global__ __launch_bounds__(512, WPS) void gemm_w16_persist_kernel(sm_gemm_args
                             const int nx = n0 + wn * WTN + 8 * q + 4 * h + e, ny = nx + 8;
                             x[e] = acc[i][0][4 * q + e] * ws + ((g.bias && nx < N) ? g.bias[nx] : 0.f);
                             y[e] = acc[i][0][4 * q + 4 + e] * ws + ((g.bias && ny < N) ? g.bias[ny] : 0.f);
-                            if constexpr (EPI == SM_EPI_GELU) {
-                                x[e] = 0.5f * x[e] * (1.0f + fast_erff(x[e] * 0.70710678118654752440f));
-                                y[e] = 0.5f * y[e] * (1.0f + fast_erff(y[e] * 0.70710678118654752440f));
-                            } else if constexpr (EPI == SM_EPI_RELU) {
+                            if constexpr (EPI == SM_EPI_RELU) {
                                 x[e] = fmaxf(x[e], 0.f);
                                 y[e] = fmaxf(y[e], 0.f);
                             }
                         }
+                        if constexpr (EPI == SM_EPI_GELU) { gelu4(x); gelu4(y); }
                         pair_groups(x, y);  // this lane now owns the whole 8-element group q + h: pieces 2 (q + h), + 1
                         f16x4 h0, l0, h1, l1;
                         split4(x, h0, l0);

@@ -175,17 +175,15 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 kh8, kl8;
+            float qf[8], kf[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int d = db * 32 + acc_row(8 * s + j, h);
-                _Float16 hi, lo;
-                split1(acc[db][8 * s + j] * ws + bq[d], hi, lo);
-                qh[2 * db + s][j] = hi;
-                ql[2 * db + s][j] = lo;
-                split1(acc[2 + db][8 * s + j] * ws + bk[d], hi, lo);
-                kh8[j] = hi;
-                kl8[j] = lo;
+                qf[j] = acc[db][8 * s + j] * ws + bq[d];
+                kf[j] = acc[2 + db][8 * s + j] * ws + bk[d];
             }
+            split8(qf, qh[2 * db + s], ql[2 * db + s]);
+            split8(kf, kh8, kl8);
             if (key < QA_KROWS) {  // K row of this key: chunk 2 (4 db + 2 s + h) (+1 = lo), XOR-ed with key & 15
                 const int c = 2 * (4 * db + 2 * s + h);
                 *reinterpret_cast<f16x8*>(smq + key * 256 + ((c ^ (key & 15)) * 16)) = kh8;
@@ -200,13 +198,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
         for (int u = 0; u < 2; ++u) {
             if (wave * 32 + 16 * u < QA_KROWS) {
                 f16x8 vh8, vl8;
+                float vf[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    _Float16 hi, lo;
-                    split1(acc[4 + db][8 * u + j] * ws + bias, hi, lo);
-                    vh8[j] = hi;
-                    vl8[j] = lo;
-                }
+                for (int j = 0; j < 8; ++j) vf[j] = acc[4 + db][8 * u + j] * ws + bias;
+                split8(vf, vh8, vl8);
                 char* p = smq + QA_K_BYTES + d * QA_VLD + wave * 128 + u * 64 + h * 32;
                 *reinterpret_cast<f16x8*>(p) = vh8;
                 *reinterpret_cast<f16x8*>(p + 16) = vl8;
@@ -288,16 +283,15 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u) {
+                float pf[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * u + j], cs, moff));
-                    psum += p;
-                    _Float16 hi, lo;
-                    split1(p, hi, lo);
-                    ph[kb][u][j] = hi;
-                    pl[kb][u][j] = lo;
+                    pf[j] = __builtin_amdgcn_exp2f(fmaf(s[kb][8 * u + j], cs, moff));
+                    psum += pf[j];
                 }
+                split8(pf, ph[kb][u], pl[kb][u]);
+            }
         l_run += psum;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -467,17 +461,15 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 kh8, kl8;
+            float qf[8], kf[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int dt = 2 * s + (j >> 2), d = 16 * dt + 4 * kg + (j & 3);
-                _Float16 hi, lo;
-                split1(acc[dt][t][j & 3] * ws + bq[d], hi, lo);
-                qh[t][s][j] = hi;
-                ql[t][s][j] = lo;
-                split1(acc[4 + dt][t][j & 3] * ws + bk[d], hi, lo);
-                kh8[j] = hi;
-                kl8[j] = lo;
+                qf[j] = acc[dt][t][j & 3] * ws + bq[d];
+                kf[j] = acc[4 + dt][t][j & 3] * ws + bk[d];
             }
+            split8(qf, qh[t][s], ql[t][s]);
+            split8(kf, kh8, kl8);
             char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
             *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 0) * 16) = kh8;
             *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 1) * 16) = kl8;
@@ -488,13 +480,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         const int d = 16 * dt + c16;
         const float bias = bv[d];
         f16x8 vh8, vl8;
+        float vf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 hi, lo;
-            split1(acc[8 + dt][j >> 2][j & 3] * ws + bias, hi, lo);
-            vh8[j] = hi;
-            vl8[j] = lo;
-        }
+        for (int j = 0; j < 8; ++j) vf[j] = acc[8 + dt][j >> 2][j & 3] * ws + bias;
+        split8(vf, vh8, vl8);
         char* vp = smm + QM_K_BYTES + d * QM_VLD + wave * 128;
         *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 0) * 16) = vh8;
         *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 1) * 16) = vl8;
@@ -565,16 +554,13 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                     for (int v = 0; v < 4; ++v) { om[dt][t][v] *= alpha; oc[dt][t][v] *= alpha; }
             }
             const float moff = -m_run[t] * cs;
-            float psum = 0.f;
+            float psum = 0.f, pf[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {  // element j = key 16 (j >> 2) + 4 kg + (j & 3) of the step
-                const float p = __builtin_amdgcn_exp2f(fmaf(sc[j >> 2][t][j & 3], cs, moff));
-                psum += p;
-                _Float16 hi, lo;
-                split1(p, hi, lo);
-                ph[t][j] = hi;
-                pl[t][j] = lo;
+                pf[j] = __builtin_amdgcn_exp2f(fmaf(sc[j >> 2][t][j & 3], cs, moff));
+                psum += pf[j];
             }
+            split8(pf, ph[t], pl[t]);
             l_run[t] += psum;
         }
 #pragma unroll

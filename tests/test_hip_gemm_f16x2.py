@@ -34,6 +34,21 @@ def test_split_round_trip():
     assert ((back - x).abs() <= x.abs() * 2.0 ** -21 + 1e-7).all()  # 22 significant bits (f16 range permitting)
 
 
+def test_split_bits_match_the_definition():
+    """hi = f16(x) (round to nearest even), lo = f16((x - hi) * 2^11): the packed-convert / fma-mix form of the kernels
+    (common.h split2) must give exactly these bits - every producer (LayerNorm, GEMM / attention epilogues) relies on it."""
+    import numpy as np
+    g = torch.Generator().manual_seed(5)
+    x = torch.cat([torch.randn(64, 384, generator=g) * s for s in (1e-6, 1e-3, 1.0, 30.0, 3000.0)])
+    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0 / 2, 2.0 ** -14, 2.0 ** -24, 1.0 + 2.0 ** -11])
+    got = ops.split_f16x2(x.to(DEV)).cpu().contiguous().view(torch.float16).reshape(x.shape[0], -1, 2, 8).numpy()
+    xn = x.numpy()
+    hi = xn.astype(np.float16)
+    lo = ((xn - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    want = np.stack([hi.reshape(x.shape[0], -1, 8), lo.reshape(x.shape[0], -1, 8)], axis=2)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
 @pytest.mark.parametrize("tile", TILES, ids=[f"{a}x{b}" for a, b in TILES])
 @pytest.mark.parametrize("M,Nn,K,epi,osplit", [
     (197 * 3, 384, 384, N.EPI_RESIDUAL, False),   # proj-like, ragged M
