@@ -344,6 +344,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 
+#ifdef SM_TUNING  // in-kernel stamps (tuning build only; a buffer nothing else reads): prologue / K loop / epilogue of a tile
+__device__ unsigned long long g_gemm_stamps[2048 * 4];
+#define GEMM_STAMP(i) \
+    do { if (blockIdx.x < 2048 && tid == 0) g_gemm_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEMM_STAMP(i) do {} while (0)
+#endif
+
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS>
 __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gemm_args g) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
+    GEMM_STAMP(0);
 #pragma unroll
     for (int v = -(NST - 1); v < 0; ++v) issue_step(v);
     const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
@@ -420,6 +429,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         wait_vmcnt_w<(NST - 2) * NI>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) GEMM_STAMP(1);
         issue_step(kt);
         const char* sta = smemm + (kt % NST) * A_STAGE + a_base;
         const char* stw = smemm + W_RING + (kt % NST) * W_STAGE + w_base;
@@ -447,6 +457,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     wait_vmcnt_w<0>();
+    GEMM_STAMP(2);
 
     float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : 0) * g.strideC;
     const bool out_split = g.patch_n < 0;
@@ -460,6 +471,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
     auto run = [&](auto epi_tag, auto fmt_tag) {
         constexpr int EPI = decltype(epi_tag)::value;
         constexpr bool F = decltype(fmt_tag)::value;
+        // The rows added in the epilogue (residual stream / position table) are fetched a 32-row block ahead, all of a
+        // block's loads before any of its stores: C may alias R (in-place residual), so left in one loop every load would
+        // wait behind the previous store: 16-24 exposed memory latencies per tile (scripts/gemm_stamps.py).
+        constexpr int NIT = 32 * PIECES / 64;
+        constexpr bool HASR = EPI == SM_EPI_RESIDUAL || EPI == SM_EPI_PATCH;
+        constexpr bool AHEAD = WPS <= 2 && NIT <= 8;  // a second block of rows in registers only where the budget is 256
+        float4 res[HASR ? NIT : 1];
+        auto load_res = [&](int ib) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
+                const int m = m0 + wm * WTM + ib * 32 + row, n = n0 + wn * WTN + pc * 4;
+                res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < M && n < N) {
+                    if constexpr (EPI == SM_EPI_RESIDUAL) res[it] = *reinterpret_cast<const float4*>(g.R + (int64_t)m * g.ldr + n);
+                    else if constexpr (EPI == SM_EPI_PATCH) res[it] = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + m % g.patch_n) * g.ldr + n);
+                }
+            }
+        };
+        if constexpr (HASR) load_res(0);
 #pragma unroll
         for (int ib = 0; ib < TM / 2; ++ib) {  // 32 staged rows = two 16-row tiles
 #pragma unroll
@@ -488,23 +519,36 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int it = 0; it < 32 * PIECES / 64; ++it) {
+            auto store_piece = [&](int it, const float4& val) {
                 const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
                 int m = m0 + wm * WTM + ib * 32 + row;
                 const int n = n0 + wn * WTN + pc * 4;
                 if (m < M && n < N) {
-                    float4 v = *reinterpret_cast<const float4*>(ep + row * EPLD + pc * 16);
-                    if constexpr (EPI == SM_EPI_RESIDUAL) {
-                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)m * g.ldr + n);
-                        v.x = rr.x + v.x; v.y = rr.y + v.y; v.z = rr.z + v.z; v.w = rr.w + v.w;
-                    } else if constexpr (EPI == SM_EPI_PATCH) {
+                    if constexpr (EPI == SM_EPI_PATCH) {
                         const int img = m / g.patch_n, p = m - img * g.patch_n;
-                        const float4 rr = *reinterpret_cast<const float4*>(g.R + (int64_t)(1 + p) * g.ldr + n);
-                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                         m = img * (g.patch_n + 1) + 1 + p;
                     }
-                    *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = v;
+                    *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = val;
+                }
+            };
+            auto staged = [&](int it) {
+                const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
+                float4 val = *reinterpret_cast<const float4*>(ep + row * EPLD + pc * 16);
+                if constexpr (HASR) { val.x = res[it].x + val.x; val.y = res[it].y + val.y; val.z = res[it].z + val.z; val.w = res[it].w + val.w; }
+                return val;
+            };
+            if constexpr (HASR && AHEAD) {  // registers to spare: the next block's rows fly under this block's stores
+                float4 v[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) v[it] = staged(it);
+                if (ib + 1 < TM / 2) load_res(ib + 1);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) store_piece(it, v[it]);
+            } else {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) store_piece(it, staged(it));
+                if constexpr (HASR) {
+                    if (ib + 1 < TM / 2) load_res(ib + 1);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -519,6 +563,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         case SM_EPI_PATCH: run(std::integral_constant<int, SM_EPI_PATCH>{}, Fa{}); break;
         default: out_split ? run(std::integral_constant<int, SM_EPI_BIAS>{}, T{}) : run(std::integral_constant<int, SM_EPI_BIAS>{}, Fa{}); break;
     }
+#ifdef SM_TUNING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp sees the stores retired (tuning build only)
+    GEMM_STAMP(3);
+#endif
 }
 
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS>
@@ -894,6 +942,7 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 42: return sm::launch_gemm_m16<128, 128, 2, 2, 4, 4>(a, st);   // as 2
         case 44: return sm::launch_gemm_m16<64, 64, 3, 2, 2, 3>(a, st);     // as 4
         case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // as 7
+        case 46: return sm::launch_gemm_m16<128, 384, 2, 2, 4, 2>(a, st);   // full 384-wide rows: 8 waves of 64x96 (N = 384 GEMMs on 99 CUs)
         // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
         case 20: case 21: case 22: case 23: case 24: {
             SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
@@ -935,6 +984,7 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4>";
         case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3>";
         case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3>";
+        case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2>";
     }
     return nullptr;
 }
@@ -975,3 +1025,9 @@ extern "C" int sm_gemm_w16(const sm_gemm_args* g, int out_f16x2, void* stream) {
     if (v < 0) { sm::set_error("sm_gemm_w16: null arguments"); return SM_EINVAL; }
     return sm_gemm_w16_tile(g, out_f16x2, v, stream);
 }
+
+#ifdef SM_TUNING
+extern "C" int sm_gemm_stamps(unsigned long long* host_out, int count) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sm::g_gemm_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif

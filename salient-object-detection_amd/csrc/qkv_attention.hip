@@ -351,6 +351,14 @@ constexpr int QM_VLD = QA_WAVES * 128;           // V^T: [dim][32-key step][slot
 constexpr int QM_V_BYTES = 64 * QM_VLD;
 static_assert(QM_K_BYTES + QM_V_BYTES <= QA_LDS, "K and V^T overlay the ring");
 
+#ifdef SM_TUNING  // in-kernel stamps (tuning build only; written to a buffer nothing else reads): where a workgroup's life goes
+__device__ unsigned long long g_qkv_stamps[1024 * QA_WAVES * 8];
+#define QKV_STAMP(i) \
+    do { if (blockIdx.x < 1024 && lane == 0) g_qkv_stamps[(blockIdx.x * QA_WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QKV_STAMP(i) do {} while (0)
+#endif
+
 template <int NST>
 __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_qkv_attn_args a) {
     constexpr int ROWB = 128, XT = QA_TOK * ROWB, WT = 192 * ROWB, STAGE = XT + WT;
@@ -409,12 +417,14 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
     constexpr int NKT = SM_EMBED / 32;
+    QKV_STAMP(0);
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t, t);
     for (int kt = 0; kt < NKT; ++kt) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (kt == 0) QKV_STAMP(1);
         {
             const int t = kt + NST - 1;
             issue(t < NKT ? t : NKT - 1, t % NST);
@@ -446,8 +456,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    QKV_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the ring becomes K / V^T
+    QKV_STAMP(3);
 
     // ---- accumulators -> Q fragments (registers), K and V^T (LDS) ---------------------------------------------------------
     const float ws = a.w_scale;
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 1) * 16) = vl8;
     }
     __syncthreads();
+    QKV_STAMP(4);
 
     // ---- attention: this wave's two 16-query tiles against all keys, 32 keys per step ---------------------------------------
     const int q0 = wave * 32;
@@ -578,6 +591,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         }
     }
 
+    QKV_STAMP(5);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         float l = l_run[t];
@@ -598,6 +612,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
             }
         }
     }
+    QKV_STAMP(6);
 }
 
 }  // namespace sm
@@ -650,3 +665,9 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
     else hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 2>), grid, block, sm::QA_LDS, st, *a);
     return sm::check_launch("sm_qkv_attention_w16");
 }
+
+#ifdef SM_TUNING
+extern "C" int sm_qkv_stamps(unsigned long long* host_out, int count) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sm::g_qkv_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
+}
+#endif
