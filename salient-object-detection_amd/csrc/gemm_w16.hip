@@ -346,10 +346,20 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifdef SM_TUNING  // in-kernel stamps (tuning build only; a buffer nothing else reads): prologue / K loop / epilogue of a tile
 __device__ unsigned long long g_gemm_stamps[2048 * 4];
-#define GEMM_STAMP(i) \
-    do { if (blockIdx.x < 2048 && tid == 0) g_gemm_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ int g_gemm_stamp_filter[3];  // (N, K, M) of the launches that stamp; N = 0: every launch (sm_gemm_stamp_filter)
+// each workgroup keeps its stamps in registers and writes the record once, at the end: launches of several streams share the
+// buffer, and a record must come from ONE workgroup
+#define GEMM_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GEMM_STAMP_DECL unsigned long long stamp_[4] = {0, 0, 0, 0}
+#define GEMM_STAMP_FLUSH                                                                                                         \
+    do {                                                                                                                        \
+        if (blockIdx.x < 2048 && tid == 0 && (g_gemm_stamp_filter[0] == 0 || (g.N == g_gemm_stamp_filter[0] && g.K == g_gemm_stamp_filter[1] && g.M == g_gemm_stamp_filter[2]))) \
+            for (int i_ = 0; i_ < 4; ++i_) g_gemm_stamps[blockIdx.x * 4 + i_] = stamp_[i_];                                      \
+    } while (0)
 #else
 #define GEMM_STAMP(i) do {} while (0)
+#define GEMM_STAMP_DECL do {} while (0)
+#define GEMM_STAMP_FLUSH do {} while (0)
 #endif
 
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS>
@@ -420,6 +430,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[i][j][v] = 0.f;
+    GEMM_STAMP_DECL;
     GEMM_STAMP(0);
 #pragma unroll
     for (int v = -(NST - 1); v < 0; ++v) issue_step(v);
@@ -433,24 +444,21 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         issue_step(kt);
         const char* sta = smemm + (kt % NST) * A_STAGE + a_base;
         const char* stw = smemm + W_RING + (kt % NST) * W_STAGE + w_base;
-        f16x8 ah[TM], al[TM], wh[TN], wl[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            wh[j] = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_hi);
-            wl[j] = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_lo);
-        }
+        f16x8 ah[TM], al[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             ah[i] = *reinterpret_cast<const f16x8*>(sta + i * 16 * ROWB + off_hi);
             al[i] = *reinterpret_cast<const f16x8*>(sta + i * 16 * ROWB + off_lo);
         }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const f16x8 whs = wh[j] * down;
+        for (int j = 0; j < TN; ++j) {  // the W fragments one column tile at a time (register budget of the 128 x 64 wave tile)
+            const f16x8 wh = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_hi);
+            const f16x8 wl = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_lo);
+            const f16x8 whs = wh * down;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, al[i], acc[i][j], 0, 0, 0);
             }
         }
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         // wait behind the previous store: 16-24 exposed memory latencies per tile (scripts/gemm_stamps.py).
         constexpr int NIT = 32 * PIECES / 64;
         constexpr bool HASR = EPI == SM_EPI_RESIDUAL || EPI == SM_EPI_PATCH;
-        constexpr bool AHEAD = WPS <= 2 && NIT <= 8;  // a second block of rows in registers only where the budget is 256
+        constexpr bool AHEAD = WPS <= 2 && NIT <= 8 && TM * TN <= 16;  // a second block of rows in registers only where there is room
         float4 res[HASR ? NIT : 1];
         auto load_res = [&](int ib) {
 #pragma unroll
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
 #ifdef SM_TUNING
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp sees the stores retired (tuning build only)
     GEMM_STAMP(3);
+    GEMM_STAMP_FLUSH;
 #endif
 }
 
@@ -943,6 +952,8 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 44: return sm::launch_gemm_m16<64, 64, 3, 2, 2, 3>(a, st);     // as 4
         case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // as 7
         case 46: return sm::launch_gemm_m16<128, 384, 2, 2, 4, 2>(a, st);   // full 384-wide rows: 8 waves of 64x96 (N = 384 GEMMs on 99 CUs)
+        case 47: return sm::launch_gemm_m16<256, 128, 3, 4, 4, 4>(a, st);   // as 41 with 16 waves of 64x32 (four per SIMD hide the stage waits)
+        case 48: return sm::launch_gemm_m16<256, 128, 2, 4, 4, 4>(a, st);   // ... and a ring of two (96 KiB)
         // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
         case 20: case 21: case 22: case 23: case 24: {
             SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
@@ -985,6 +996,8 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3>";
         case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3>";
         case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2>";
+        case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4>";
+        case 48: return "gemm_w16m16_kernel<256, 128, 2, 4, 4, 4>";
     }
     return nullptr;
 }
@@ -1014,7 +1027,7 @@ extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     if (!narrow && forced_w >= 0) return forced_w;
     if (g->alt_from_n == 0 || g->alt_from_n % 256 == 0) {
         if (g->N % 256 == 0 && g->N >= 1024 && wg256 >= 128) return m32 ? 32 : 40;  // 256 x 256
-        if (wg256x128 >= 128) return m32 ? 31 : 41;                                  // 256 x 128, ring of three
+        if (wg256x128 >= 128) return m32 ? 31 : 47;                                  // 256 x 128, ring of three, 16 waves
     }
     if (wg128 >= 256) return m32 ? 2 : 42;
     return m32 ? 7 : 45;
@@ -1027,6 +1040,10 @@ extern "C" int sm_gemm_w16(const sm_gemm_args* g, int out_f16x2, void* stream) {
 }
 
 #ifdef SM_TUNING
+extern "C" int sm_gemm_stamp_filter(int N, int K, int M) {
+    const int f[3] = {N, K, M};
+    return hipMemcpyToSymbol(HIP_SYMBOL(sm::g_gemm_stamp_filter), f, sizeof(f)) == hipSuccess ? 0 : 1;
+}
 extern "C" int sm_gemm_stamps(unsigned long long* host_out, int count) {
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sm::g_gemm_stamps), sizeof(unsigned long long) * count) == hipSuccess ? 0 : 1;
 }

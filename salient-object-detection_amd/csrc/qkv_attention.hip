@@ -353,10 +353,14 @@ static_assert(QM_K_BYTES + QM_V_BYTES <= QA_LDS, "K and V^T overlay the ring");
 
 #ifdef SM_TUNING  // in-kernel stamps (tuning build only; written to a buffer nothing else reads): where a workgroup's life goes
 __device__ unsigned long long g_qkv_stamps[1024 * QA_WAVES * 8];
-#define QKV_STAMP(i) \
-    do { if (blockIdx.x < 1024 && lane == 0) g_qkv_stamps[(blockIdx.x * QA_WAVES + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define QKV_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)  // kept in registers, one record per wave
+#define QKV_STAMP_DECL unsigned long long stamp_[7] = {0, 0, 0, 0, 0, 0, 0}
+#define QKV_STAMP_FLUSH \
+    do { if (blockIdx.x < 1024 && lane == 0) for (int i_ = 0; i_ < 7; ++i_) g_qkv_stamps[(blockIdx.x * QA_WAVES + wave) * 8 + i_] = stamp_[i_]; } while (0)
 #else
 #define QKV_STAMP(i) do {} while (0)
+#define QKV_STAMP_DECL do {} while (0)
+#define QKV_STAMP_FLUSH do {} while (0)
 #endif
 
 template <int NST>
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};  // 2^-11
     constexpr int NKT = SM_EMBED / 32;
+    QKV_STAMP_DECL;
     QKV_STAMP(0);
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t, t);
@@ -516,9 +521,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
             for (int v = 0; v < 4; ++v) { om[dt][t][v] = 0.f; oc[dt][t][v] = 0.f; }
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     const int nsteps = (N + 31) >> 5;
-    for (int stp = 0; stp < nsteps; ++stp) {
-        // scores: S^T tile [key tile kt][query tile t] = sum over the two dim steps
-        f32x4q sc[2][2];
+    // scores of one 32-key step: S^T tile [key tile kt][query tile t] = sum over the two dim steps.  Software-pipelined one
+    // step ahead: the MFMAs of step s + 1 are independent of the softmax of step s and run in its shadow (a lone wave used
+    // to serialise 768 MFMA cycles and ~1000 VALU cycles per step).
+    auto scores = [&](int stp, f32x4q (&sc)[2][2]) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             const int key = stp * 32 + kt * 16 + c16;
@@ -538,12 +544,22 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                     cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], ql[t][s], cr, 0, 0, 0);
                     cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[s], qh[t][s], cr, 0, 0, 0);
                 }
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int kidx = stp * 32 + kt * 16 + 4 * kg + v;  // the key this register holds
-                    sc[kt][t][v] = kidx < N ? fmaf(cr[v], 1.0f / 2048.0f, mn[v]) : -INFINITY;
-                }
+                sc[kt][t] = cr * (1.0f / 2048.0f) + mn;
             }
+        }
+    };
+    f32x4q sc[2][2], sn[2][2];
+    scores(0, sc);
+    for (int stp = 0; stp < nsteps; ++stp) {
+        if (stp + 1 < nsteps) scores(stp + 1, sn);
+        if (stp == nsteps - 1) {  // only the last step can hold keys >= N (K rows 197..223 repeat the last token)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (stp * 32 + kt * 16 + 4 * kg + v >= N) sc[kt][t][v] = -INFINITY;
         }
         f16x8 ph[2], pl[2];
 #pragma unroll
@@ -568,9 +584,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
             }
             const float moff = -m_run[t] * cs;
             float psum = 0.f, pf[8];
+            const f32x4q e0 = sc[0][t] * cs + moff, e1 = sc[1][t] * cs + moff;  // packed fma
 #pragma unroll
             for (int j = 0; j < 8; ++j) {  // element j = key 16 (j >> 2) + 4 kg + (j & 3) of the step
-                pf[j] = __builtin_amdgcn_exp2f(fmaf(sc[j >> 2][t][j & 3], cs, moff));
+                pf[j] = __builtin_amdgcn_exp2f(j < 4 ? e0[j & 3] : e1[j & 3]);
                 psum += pf[j];
             }
             split8(pf, ph[t], pl[t]);
@@ -589,6 +606,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                 oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], oc[dt][t], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) sc[kt][t] = sn[kt][t];
     }
 
     QKV_STAMP(5);
@@ -613,6 +634,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         }
     }
     QKV_STAMP(6);
+    QKV_STAMP_FLUSH;
 }
 
 }  // namespace sm

@@ -17,8 +17,10 @@ SHAPES = [("qkv  (bias, F16X2 out)", 1152, 384, N.EPI_BIAS, True, 41), ("proj (r
           ("fc1  (GELU, F16X2 out)", 1536, 384, N.EPI_GELU, True, 40), ("fc1  (GELU, F16X2 out)", 1536, 384, N.EPI_GELU, True, 41),
           ("fc1-shaped, bias only", 1536, 384, N.EPI_BIAS, True, 40), ("fc2  (residual)", 384, 1536, N.EPI_RESIDUAL, False, 41),
           ("fc2  (residual)", 384, 1536, N.EPI_RESIDUAL, False, 42), ("proj (residual)", 384, 384, N.EPI_RESIDUAL, False, 46),
+          ("proj (residual)", 384, 384, N.EPI_RESIDUAL, False, 47), ("fc2  (residual)", 384, 1536, N.EPI_RESIDUAL, False, 47),
+          ("proj (residual)", 384, 384, N.EPI_RESIDUAL, False, 48), ("fc2  (residual)", 384, 1536, N.EPI_RESIDUAL, False, 48),
           ("fc2  (residual)", 384, 1536, N.EPI_RESIDUAL, False, 46)]
-TILE = {40: (256, 256), 41: (256, 128), 42: (128, 128), 46: (128, 384)}
+TILE = {40: (256, 256), 41: (256, 128), 42: (128, 128), 46: (128, 384), 47: (256, 128), 48: (256, 128)}
 print("variant / shape: tiles, then median ticks of the shader clock: prologue | K loop | epilogue | tile life   (launch us)")
 for name, Nn, K, epi, osplit, variant in SHAPES:
     a = ops.split_f16x2(torch.randn(M, K, device="cuda"))

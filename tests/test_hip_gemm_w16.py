@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from selfmask_amd import ops, _native as N  # noqa: E402
 
 DEV = "cuda:0"
-VARIANTS = [0, 1, 2, 3, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 20, 22, 30, 31, 32, 33, 34, 35, 36, 40, 41, 42, 44, 45, 46]  # 20+: persistent; 30+: deep rings
+VARIANTS = [0, 1, 2, 3, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 20, 22, 30, 31, 32, 33, 34, 35, 36, 40, 41, 42, 44, 45, 46, 47, 48]  # 20+: persistent; 30+: deep rings
 
 
 def _rand(*shape, seed=0, scale=1.0):
