@@ -26,6 +26,7 @@
 // (one barrier) the same memory becomes K (208 x 256 B) + V^T (64 x 848 B, 16 B of padding per row: conflict-free b128
 // reads) = 105 KiB.  N <= 208 tokens: the ViT-S/16 224^2 headline shape (197); other shapes take the unfused path.
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 #include <mutex>
 #include <stdlib.h>
@@ -425,42 +426,50 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     QKV_STAMP(0);
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t, t);
-    for (int kt = 0; kt < NKT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt == 0) QKV_STAMP(1);
-        {
-            const int t = kt + NST - 1;
-            issue(t < NKT ? t : NKT - 1, t % NST);
-        }
-        const char* st = smm + (kt % NST) * STAGE;
-        f16x8 xh[2], xl[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            xh[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_hi);
-            xl[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_lo);
-        }
-#pragma unroll
-        for (int d = 0; d < 12; ++d) {
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_hi);
-            const f16x8 wl = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_lo);
-            const f16x8 whs = wh * down;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (d < 8) {  // Q^T, K^T: D[dim][token]
-                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc[d][t], 0, 0, 0);
-                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[t], acc[d][t], 0, 0, 0);
-                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, xl[t], acc[d][t], 0, 0, 0);
-                } else {      // V: D[token][dim]
-                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wh, acc[d][t], 0, 0, 0);
-                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wl, acc[d][t], 0, 0, 0);
-                    acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], whs, acc[d][t], 0, 0, 0);
+    // A wave whose second 16-token tile lies wholly beyond N (wave 6 at N = 197: rows 208..223) skips that tile's MFMAs in
+    // both phases: its accumulators stay zero, so its K rows / V^T columns hold the bias (finite; those keys are masked).
+    const bool two_tiles = wave * 32 + 16 < N;
+    auto project = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        for (int kt = 0; kt < NKT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * PPW) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt == 0) QKV_STAMP(1);
+            {
+                const int t = kt + NST - 1;
+                issue(t < NKT ? t : NKT - 1, t % NST);
+            }
+            const char* st = smm + (kt % NST) * STAGE;
+            f16x8 xh[2], xl[2];
+    #pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xh[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_hi);
+                xl[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_lo);
+            }
+    #pragma unroll
+            for (int d = 0; d < 12; ++d) {
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_hi);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_lo);
+                const f16x8 whs = wh * down;
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (d < 8) {  // Q^T, K^T: D[dim][token]
+                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc[d][t], 0, 0, 0);
+                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[t], acc[d][t], 0, 0, 0);
+                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, xl[t], acc[d][t], 0, 0, 0);
+                    } else {      // V: D[token][dim]
+                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wh, acc[d][t], 0, 0, 0);
+                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wl, acc[d][t], 0, 0, 0);
+                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], whs, acc[d][t], 0, 0, 0);
+                    }
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    };
+    if (two_tiles) project(std::integral_constant<int, 2>{});
+    else project(std::integral_constant<int, 1>{});
     QKV_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the ring becomes K / V^T
@@ -521,118 +530,123 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
             for (int v = 0; v < 4; ++v) { om[dt][t][v] = 0.f; oc[dt][t][v] = 0.f; }
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
     const int nsteps = (N + 31) >> 5;
-    // scores of one 32-key step: S^T tile [key tile kt][query tile t] = sum over the two dim steps.  Software-pipelined one
-    // step ahead: the MFMAs of step s + 1 are independent of the softmax of step s and run in its shadow (a lone wave used
-    // to serialise 768 MFMA cycles and ~1000 VALU cycles per step).
-    auto scores = [&](int stp, f32x4q (&sc)[2][2]) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int key = stp * 32 + kt * 16 + c16;
-            f16x8 kh[2], kl[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
-                kh[s] = *reinterpret_cast<const f16x8*>(kp + m16_slot(key, kg, 0) * 16);
-                kl[s] = *reinterpret_cast<const f16x8*>(kp + m16_slot(key, kg, 1) * 16);
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4q mn = {0.f, 0.f, 0.f, 0.f}, cr = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    auto attend = [&](auto nt_tag) {
+        constexpr int NT = decltype(nt_tag)::value;
+        // scores of one 32-key step: S^T tile [key tile kt][query tile t] = sum over the two dim steps.  Software-pipelined one
+        // step ahead: the MFMAs of step s + 1 are independent of the softmax of step s and run in its shadow (a lone wave used
+        // to serialise 768 MFMA cycles and ~1000 VALU cycles per step).
+        auto scores = [&](int stp, f32x4q (&sc)[2][2]) {  // NT: query tiles of this wave
+    #pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const int key = stp * 32 + kt * 16 + c16;
+                f16x8 kh[2], kl[2];
+    #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    mn = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], qh[t][s], mn, 0, 0, 0);
-                    cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], ql[t][s], cr, 0, 0, 0);
-                    cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[s], qh[t][s], cr, 0, 0, 0);
+                    const char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
+                    kh[s] = *reinterpret_cast<const f16x8*>(kp + m16_slot(key, kg, 0) * 16);
+                    kl[s] = *reinterpret_cast<const f16x8*>(kp + m16_slot(key, kg, 1) * 16);
                 }
-                sc[kt][t] = cr * (1.0f / 2048.0f) + mn;
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4q mn = {0.f, 0.f, 0.f, 0.f}, cr = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        mn = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], qh[t][s], mn, 0, 0, 0);
+                        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], ql[t][s], cr, 0, 0, 0);
+                        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[s], qh[t][s], cr, 0, 0, 0);
+                    }
+                    sc[kt][t] = cr * (1.0f / 2048.0f) + mn;
+                }
+            }
+        };
+        f32x4q sc[2][2], sn[2][2];
+        scores(0, sc);
+        for (int stp = 0; stp < nsteps; ++stp) {
+            if (stp + 1 < nsteps) scores(stp + 1, sn);
+            if (stp == nsteps - 1) {  // only the last step can hold keys >= N (K rows 197..223 repeat the last token)
+    #pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+    #pragma unroll
+                    for (int t = 0; t < NT; ++t)
+    #pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (stp * 32 + kt * 16 + 4 * kg + v >= N) sc[kt][t][v] = -INFINITY;
+            }
+            f16x8 ph[2], pl[2];
+    #pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float cmax = -INFINITY;
+    #pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+    #pragma unroll
+                    for (int v = 0; v < 4; ++v) cmax = fmaxf(cmax, sc[kt][t][v]);
+                cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+                cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+                const float lim = 8.0f / cs;  // lazy running maximum: p <= 2^8 between moves
+                if (__builtin_amdgcn_ballot_w64(cmax > m_run[t] + lim) != 0) {
+                    const float m_new = fmaxf(m_run[t], cmax);
+                    const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * cs);
+                    m_run[t] = m_new;
+                    l_run[t] *= alpha;
+    #pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+    #pragma unroll
+                        for (int v = 0; v < 4; ++v) { om[dt][t][v] *= alpha; oc[dt][t][v] *= alpha; }
+                }
+                const float moff = -m_run[t] * cs;
+                float psum = 0.f, pf[8];
+                const f32x4q e0 = sc[0][t] * cs + moff, e1 = sc[1][t] * cs + moff;  // packed fma
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {  // element j = key 16 (j >> 2) + 4 kg + (j & 3) of the step
+                    pf[j] = __builtin_amdgcn_exp2f(j < 4 ? e0[j & 3] : e1[j & 3]);
+                    psum += pf[j];
+                }
+                split8(pf, ph[t], pl[t]);
+                l_run[t] += psum;
+            }
+    #pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int d = 16 * dt + c16;
+                const char* vp = smm + QM_K_BYTES + d * QM_VLD + stp * 128;
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(vp + m16_slot(d, kg, 0) * 16);
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + m16_slot(d, kg, 1) * 16);
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    om[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[t], om[dt][t], 0, 0, 0);
+                    oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t], oc[dt][t], 0, 0, 0);
+                    oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], oc[dt][t], 0, 0, 0);
+                }
+            }
+    #pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+    #pragma unroll
+                for (int t = 0; t < NT; ++t) sc[kt][t] = sn[kt][t];
+        }
+
+        QKV_STAMP(5);
+    #pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float l = l_run[t];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.0f / l;
+            const int q = q0 + t * 16 + c16;
+            if (q < N) {
+                float* Orow = a.O + ((int64_t)b * N + q) * a.ldo;
+    #pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float x[4];
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = (om[dt][t][e] + oc[dt][t][e] * (1.0f / 2048.0f)) * inv;
+                    const int d = head * SM_HEAD_DIM + 16 * dt + 4 * kg;  // this lane's four consecutive head-dims
+                    if (a.out_f16x2) store_f16x2_4(Orow, d, x);
+                    else *reinterpret_cast<float4*>(Orow + d) = make_float4(x[0], x[1], x[2], x[3]);
+                }
             }
         }
     };
-    f32x4q sc[2][2], sn[2][2];
-    scores(0, sc);
-    for (int stp = 0; stp < nsteps; ++stp) {
-        if (stp + 1 < nsteps) scores(stp + 1, sn);
-        if (stp == nsteps - 1) {  // only the last step can hold keys >= N (K rows 197..223 repeat the last token)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v)
-                        if (stp * 32 + kt * 16 + 4 * kg + v >= N) sc[kt][t][v] = -INFINITY;
-        }
-        f16x8 ph[2], pl[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float cmax = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) cmax = fmaxf(cmax, sc[kt][t][v]);
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-            const float lim = 8.0f / cs;  // lazy running maximum: p <= 2^8 between moves
-            if (__builtin_amdgcn_ballot_w64(cmax > m_run[t] + lim) != 0) {
-                const float m_new = fmaxf(m_run[t], cmax);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * cs);
-                m_run[t] = m_new;
-                l_run[t] *= alpha;
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) { om[dt][t][v] *= alpha; oc[dt][t][v] *= alpha; }
-            }
-            const float moff = -m_run[t] * cs;
-            float psum = 0.f, pf[8];
-            const f32x4q e0 = sc[0][t] * cs + moff, e1 = sc[1][t] * cs + moff;  // packed fma
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {  // element j = key 16 (j >> 2) + 4 kg + (j & 3) of the step
-                pf[j] = __builtin_amdgcn_exp2f(j < 4 ? e0[j & 3] : e1[j & 3]);
-                psum += pf[j];
-            }
-            split8(pf, ph[t], pl[t]);
-            l_run[t] += psum;
-        }
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const int d = 16 * dt + c16;
-            const char* vp = smm + QM_K_BYTES + d * QM_VLD + stp * 128;
-            const f16x8 vh = *reinterpret_cast<const f16x8*>(vp + m16_slot(d, kg, 0) * 16);
-            const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + m16_slot(d, kg, 1) * 16);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                om[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[t], om[dt][t], 0, 0, 0);
-                oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t], oc[dt][t], 0, 0, 0);
-                oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], oc[dt][t], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) sc[kt][t] = sn[kt][t];
-    }
-
-    QKV_STAMP(5);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        float l = l_run[t];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float inv = 1.0f / l;
-        const int q = q0 + t * 16 + c16;
-        if (q < N) {
-            float* Orow = a.O + ((int64_t)b * N + q) * a.ldo;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                float x[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[e] = (om[dt][t][e] + oc[dt][t][e] * (1.0f / 2048.0f)) * inv;
-                const int d = head * SM_HEAD_DIM + 16 * dt + 4 * kg;  // this lane's four consecutive head-dims
-                if (a.out_f16x2) store_f16x2_4(Orow, d, x);
-                else *reinterpret_cast<float4*>(Orow + d) = make_float4(x[0], x[1], x[2], x[3]);
-            }
-        }
-    }
+    if (two_tiles) attend(std::integral_constant<int, 2>{});
+    else attend(std::integral_constant<int, 1>{});
     QKV_STAMP(6);
     QKV_STAMP_FLUSH;
 }
