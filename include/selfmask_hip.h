@@ -353,7 +353,7 @@ typedef struct sm_weights {
     const float *enc_norm_w, *enc_norm_b;
     sm_dec_layer dec[SM_MAX_DEC_LAYERS];
     const float *dec_norm_w, *dec_norm_b;
-    const float *ffn0_w, *ffn0_b, *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b; /* objectness MLP 384->384->384->1 */
+    const float *ffn0_w, *ffn0_b, *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b; /* objectness MLP 384->384->384->1 (or the mask head, see mask_head_ffn) */
     const float* dec_kv_w; /* packed by the host from the state_dict: rows [384:1152) of every decoder layer's      */
     const float* dec_kv_b; /*   multihead_attn.in_proj_{weight,bias}, concatenated -> (L*768, 384) / (L*768): the   */
                            /*   cross-attention K/V of ALL layers is one GEMM over the encoder memory               */
@@ -367,6 +367,12 @@ typedef struct sm_weights {
     int32_t n_queries;
     int32_t n_dec_layers;
     float patch_s, ffn0_s, ffn1_s, dec_kv_s; /* gemm_mode 2: 2^-s of patch_w, ffn0_w, ffn1_w, dec_kv_w */
+    float ffn2_s;          /* gemm_mode 2, mask_head_ffn only: 2^-s of ffn2_w */
+    int32_t mask_head_ffn; /* 0: use_binary_classifier=True - ffn is the objectness MLP 384->384->384->1, ffn2_w (1,384)
+                              fp32 (maskformer.py:55-58,227-239).  1: return_intermediate=True with
+                              use_binary_classifier=False - ffn is a 384->384->384->384 MLP applied to the decoder
+                              queries BEFORE the mask einsum (maskformer.py:59-66,225); ffn2_w (384,384) is then a GEMM
+                              weight in the gemm_mode's format, no objectness is produced (io->objectness may be NULL) */
 } sm_weights;
 
 typedef struct sm_forward_io {

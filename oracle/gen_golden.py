@@ -154,6 +154,43 @@ def gen_forward3d():
           f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
 
 
+def gen_forward_ffnhead():
+    """The 5-D path with use_binary_classifier=False (maskformer.py:225): mask = sigmoid(einsum(ffn(queries), up)), no
+    objectness.  The reference returns only the sigmoid; the pre-sigmoid logits the gate is stated on are taken from the
+    real modules' own sub-calls (forward_encoder / forward_transformer_decoder / ffn / forward_pixel_decoder) and checked
+    to reproduce the forward's output bit for bit."""
+    vits, mf = _import_reference()
+    torch.set_num_threads(N_THREADS)
+    patch, (B, Hh, Ww), wseed, style, xseed = 16, (2, 224, 224), 8, "soft", 1251
+    sd = synthetic_state_dict(wseed, style, patch_size=patch, use_binary_classifier=False)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    outs = {}
+    for dtype in (torch.float32, torch.float64):
+        model = mf.MaskFormer(n_queries=20, arch="vit_small", patch_size=patch, n_decoder_layers=6,
+                              return_intermediate=True, scale_factor=2, use_binary_classifier=False).eval()
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dtype)
+        with torch.no_grad():
+            o = model(x.to(dtype))
+            assert set(o.keys()) == {"mask_pred", "features"}
+            feats = model.forward_encoder(x.to(dtype))
+            last = feats[:, -1, ...]
+            q = model.forward_transformer_decoder(last)
+            up = model.forward_pixel_decoder(patch_tokens=last, input_size=(Hh // patch, Ww // patch))
+            logits = torch.einsum("bdqn,bnhw->bdqhw", model.ffn(q), up)
+            assert torch.equal(torch.sigmoid(logits), o["mask_pred"])
+        outs[dtype] = {"mask_pred": o["mask_pred"], "features": o["features"], "mask_logits": logits}
+    o32, o64 = outs[torch.float32], outs[torch.float64]
+    err = (o32["mask_logits"].double() - o64["mask_logits"]).abs().max().item()
+    fp = os.path.join(GOLD, "ffnhead_p16_224_soft.npz")
+    np.savez_compressed(fp, meta=np.array([patch, B, Hh, Ww, wseed, xseed, N_THREADS]), style=np.array(style),
+                        mask_pred=o32["mask_pred"].numpy(), mask_logits=o32["mask_logits"].numpy(),
+                        mask_logits_f64=o64["mask_logits"].numpy(), features=o32["features"].numpy(),
+                        logit_absmax=np.array(o32["mask_logits"].abs().max().item()), f32_vs_f64_maxabs=np.array(err))
+    print(f"forward_ffnhead: shape={tuple(o32['mask_pred'].shape)} max|logit|={o32['mask_logits'].abs().max().item():.2f} "
+          f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
+
+
 def _voting_cases():
     """Candidate sets shaped like the generator's (k-way one-hot cluster maps at image resolution): 9 masks per case, with
     full-height / full-width strips, an empty mask, a tiny and a near-full one, on non-multiple-of-64 sizes."""
@@ -306,6 +343,8 @@ if __name__ == "__main__":
         gen_forward()
     if a.only in (None, "forward3d"):
         gen_forward3d()
+    if a.only in (None, "forward_ffnhead"):
+        gen_forward_ffnhead()
     if a.only in (None, "voting"):
         gen_voting()
     if a.only in (None, "metrics"):

@@ -192,5 +192,21 @@ def forward_3d(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int = 16, n_
     return {"mask_pred": torch.einsum("bqn,bnhw->bqhw", queries, up), "features": queries.mean(dim=1)}
 
 
+@torch.no_grad()
+def forward_ffn_head(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int = 16, n_layers: int = 6,
+                     scale_factor: int = 2) -> Dict[str, torch.Tensor]:
+    """MaskFormer.forward (maskformer.py:164-251), 5-D path with use_binary_classifier=False: the einsum takes
+    ``ffn(queries)`` - a 384->384->384->384 MLP, ReLU between the layers (:59-66, :225, MLP.forward :265-268) - and the
+    output dict carries no objectness (:246-249).  ``mask_logits`` is the pre-sigmoid einsum."""
+    tokens, grid = encoder_forward(x, sd, patch)
+    queries = decoder_forward(tokens, sd, n_layers)
+    q = F.relu(_lin(queries, sd, "ffn.layers.0"))
+    q = F.relu(_lin(q, sd, "ffn.layers.1"))
+    q = _lin(q, sd, "ffn.layers.2")
+    up = pixel_decoder(tokens, grid, scale_factor)
+    logits = torch.einsum("bdqn,bnhw->bdqhw", q, up)
+    return {"mask_logits": logits, "mask_pred": torch.sigmoid(logits), "features": queries[:, -1].mean(dim=1)}
+
+
 def cast_state(sd, dtype):
     return {k: v.to(dtype) for k, v in sd.items()}

@@ -379,6 +379,14 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
 
     // ---- heads --------------------------------------------------------------------------------------------------
     TRY(sm_query_mean_f32(QD, io->features, s.B, s.L, s.nq, st));
+    if (w->mask_head_ffn) {
+        // return_intermediate=True with use_binary_classifier=False (maskformer.py:225): the mask einsum takes
+        // ffn(queries), a 384->384->384->384 MLP with ReLU between the layers (MLP.forward :265-268), not the queries
+        TRY(linear(c, qd_a, D, w->ffn0_w, w->ffn0_s, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
+        TRY(linear(c, ws.O1, D, w->ffn1_w, w->ffn1_s, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
+        TRY(linear(c, ws.O2, D, w->ffn2_w, w->ffn2_s, w->ffn2_b, ws.O1, D, s.Mo, D, D, SM_EPI_BIAS, nullptr, 0, S));
+        qd_a = ws.O1;
+    }
     if (s.n % 4 == 0) {
         // mask_pred = sigmoid(up(Q . tok^T)): the einsum of maskformer.py:223 commutes with the bilinear x2 of the pixel
         // decoder (:144-162) - both linear - so the GEMM runs on the token grid (N = n instead of 4n) and the (B, 4n,
@@ -401,6 +409,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         g.batch = s.B; g.epilogue = SM_EPI_SIGMOID2;
         TRY(gemm(c, g));
     }
+    if (w->mask_head_ffn) return SM_OK;  // no objectness on this path (maskformer.py:246-249)
     TRY(linear(c, qd_a, D, w->ffn0_w, w->ffn0_s, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
     TRY(linear(c, ws.O1, D, w->ffn1_w, w->ffn1_s, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0));
     TRY(sm_rowdot_sigmoid_f32(ws.O2, w->ffn2_w, w->ffn2_b, io->objectness, (int)s.Mo, st));
@@ -421,7 +430,7 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
         SM_REQUIRE((4 * gh * gw) % 4 == 0, "sm_maskformer_forward: mask width must be a multiple of 4");
     }
     if (!io->encoder_only)
-        SM_REQUIRE(io->mask_pred && io->objectness && io->features, "sm_maskformer_forward: null output");
+        SM_REQUIRE(io->mask_pred && (io->objectness || w->mask_head_ffn) && io->features, "sm_maskformer_forward: null output");
     else
         SM_REQUIRE(io->patch_tokens, "sm_maskformer_forward: encoder_only needs patch_tokens");
     return SM_OK;

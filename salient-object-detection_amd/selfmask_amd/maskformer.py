@@ -127,9 +127,11 @@ class MaskFormer(nn.Module):
                                       f"(resnet50 backbones are out of scope, SURVEY.md section 2 #11)")
         if patch_size not in (8, 16):
             raise ValueError(f"patch_size={patch_size}: ViT-S/8 and ViT-S/16 are supported")
-        if normalize_before or learnable_pixel_decoder or lateral_connection or scale_factor != 2:
-            raise NotImplementedError("normalize_before / learnable_pixel_decoder / lateral_connection / "
-                                      "scale_factor != 2 are not used by the shipped config and not implemented")
+        if normalize_before or scale_factor != 2:
+            raise NotImplementedError("normalize_before / scale_factor != 2 are not used by the shipped config and "
+                                      "not implemented")
+        # learnable_pixel_decoder is stored and never read by the reference's forward (maskformer.py:71,144-162): accepted,
+        # no effect.  lateral_connection=True is accepted here as there and fails in forward as there (see forward()).
         if not 1 <= n_decoder_layers <= N.MAX_DEC_LAYERS:
             raise ValueError(f"n_decoder_layers={n_decoder_layers} (1..{N.MAX_DEC_LAYERS})")
         d = N.EMBED
@@ -243,7 +245,11 @@ class MaskFormer(nn.Module):
         f = self.ffn.layers
         (w.ffn0_w, w.ffn0_s), w.ffn0_b = gws("ffn0", f[0].weight), f[0].bias.data_ptr()
         (w.ffn1_w, w.ffn1_s), w.ffn1_b = gws("ffn1", f[1].weight), f[1].bias.data_ptr()
-        w.ffn2_w, w.ffn2_b = f[2].weight.data_ptr(), f[2].bias.data_ptr()
+        if self.use_binary_classifier:  # objectness MLP: the last layer is a (1, 384) row, applied as a row dot product
+            w.ffn2_w, w.ffn2_b, w.mask_head_ffn = f[2].weight.data_ptr(), f[2].bias.data_ptr(), 0
+        else:  # 384 -> 384 mask head (maskformer.py:59-66): a GEMM weight like the others; used on the 5-D path only
+            (w.ffn2_w, w.ffn2_s), w.ffn2_b = gws("ffn2", f[2].weight), f[2].bias.data_ptr()
+            w.mask_head_ffn = 1 if self.return_intermediate else 0
         (w.dec_kv_w, w.dec_kv_s), w.dec_kv_b = gws("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
         w.gemm_mode = 2 if w16 else (1 if split else 0)
         self._packed = packed
@@ -294,9 +300,11 @@ class MaskFormer(nn.Module):
             raise RuntimeError("MaskFormer (MI355X) needs its input on a HIP device; there is no CPU fallback")
         if self.training:
             raise RuntimeError("inference-only implementation: call model.eval()")
-        if self.return_intermediate and not self.use_binary_classifier:
-            raise NotImplementedError("return_intermediate=True with use_binary_classifier=False (ffn-projected "
-                                      "queries, maskformer.py:225) is not implemented")
+        if self.lateral_connection:
+            # the reference hands the 5-D (b, depth, n_dims, hw) stack to forward_pixel_decoder, whose own
+            # `assert len(patch_tokens.shape) == 4` (maskformer.py:160) then fails for every input: same outcome here
+            raise AssertionError("lateral_connection=True: forward_pixel_decoder expects 4-D patch tokens "
+                                 "(the reference asserts at maskformer.py:160)")
         if not self.return_intermediate and self.use_binary_classifier:
             # the reference permutes a 3-D tensor with 4 indices at maskformer.py:229 and raises
             raise RuntimeError("use_binary_classifier=True requires loss_every_decoder_layer/return_intermediate=True")
@@ -336,6 +344,8 @@ class MaskFormer(nn.Module):
                 "sm_maskformer_forward")
         if not self.return_intermediate:  # 3-D path: last layer, un-sigmoided (maskformer.py:219-220)
             out = {"mask_pred": extras["mask_logits"][:, -1], "features": features}
+        elif not self.use_binary_classifier:  # 5-D path with the ffn mask head: no objectness (maskformer.py:225,246-249)
+            out = {"mask_pred": mask_pred, "features": features}
         else:
             out = {"objectness": objectness, "mask_pred": mask_pred, "features": features}
         if return_logits:

@@ -273,6 +273,41 @@ def test_3d_path_values_match_reference_vectors(mode):
     assert np.abs(o3["features"].cpu().numpy() - g["features"]).max() <= 5e-5
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_ffn_mask_head_matches_reference(mode):
+    """return_intermediate=True with use_binary_classifier=False (maskformer.py:59-66,225): the mask einsum takes
+    ffn(queries), the dict has no objectness - against the REAL reference's output (tests/golden/ffnhead_*.npz)."""
+    g = np.load(os.path.join(GOLD, "ffnhead_p16_224_soft.npz"))
+    patch, B, Hh, Ww, wseed, xseed, _ = [int(v) for v in g["meta"]]
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch, use_binary_classifier=False)
+    m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True,
+                   use_binary_classifier=False, learnable_pixel_decoder=True, gemm_mode=mode)  # the flag is a no-op there too
+    m.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    o = m.to(DEV)(x.to(DEV), return_logits=True)
+    assert set(m.to(DEV)(x.to(DEV)).keys()) == {"mask_pred", "features"}
+    got = o["mask_logits"].cpu().numpy()
+    d32, d64 = np.abs(got - g["mask_logits"]).max(), np.abs(got - g["mask_logits_f64"]).max()
+    ref64 = float(g["f32_vs_f64_maxabs"])
+    print(f"\n[{mode}] ffn mask head: |logit|max={float(g['logit_absmax']):.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e}")
+    ledger.record("forward_ffn_mask_head", mode, {"logit_absmax": float(g["logit_absmax"]), "hip_minus_ref32": float(d32),
+                                                  "hip_minus_ref64": float(d64), "ref32_minus_ref64": ref64, "rule": "hip-ref32 <= 1e-4"})
+    assert ref64 <= STRICT_BELOW and d32 <= ABS_TOL and d64 <= max(ref64, 0.5 * ABS_TOL)
+    assert np.abs(o["mask_pred"].cpu().numpy() - g["mask_pred"]).max() <= 3e-5
+    assert np.abs(o["features"].cpu().numpy() - g["features"]).max() <= 5e-5
+    # the hip result thresholds like the reference's
+    assert ((o["mask_pred"].cpu().numpy() > 0.5) != (g["mask_pred"] > 0.5)).sum() <= 2
+
+
+def test_lateral_connection_fails_like_the_reference():
+    """lateral_connection=True constructs, and forward fails on the pixel decoder's 4-D assertion (maskformer.py:160)."""
+    m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True,
+                   lateral_connection=True)
+    m.load_state_dict(synthetic_state_dict(0, "calib", patch_size=16), strict=True)
+    with pytest.raises(AssertionError):
+        m.to(DEV)(torch.zeros(1, 3, 224, 224, device=DEV))
+
+
 def test_cpu_input_is_refused():
     m = _model(16, 0, "soft")
     with pytest.raises(RuntimeError, match="no CPU fallback"):

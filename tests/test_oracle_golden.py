@@ -70,3 +70,22 @@ def test_oracle_3d_path_matches_reference_vectors():
     assert np.abs(out["features"].numpy() - g["features"]).max() <= 2e-5
     o64 = O.forward_3d(x.double(), O.cast_state(sd, torch.float64), patch)
     assert np.abs(o64["mask_pred"].numpy() - g["mask_pred_f64"]).max() <= 1e-10
+
+
+def test_oracle_ffn_mask_head_matches_reference_vectors():
+    """forward_ffn_head (return_intermediate=True, use_binary_classifier=False; maskformer.py:225) against the real
+    reference's output: sigmoid(einsum(ffn(queries), up)), no objectness."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ffnhead_p16_224_soft.npz"))
+    patch, B, Hh, Ww, wseed, xseed, nthreads = [int(v) for v in g["meta"]]
+    torch.set_num_threads(min(nthreads, os.cpu_count() or 1))
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch, use_binary_classifier=False)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    out = O.forward_ffn_head(x, sd, patch)
+    assert "objectness" not in out
+    scale = float(g["logit_absmax"])
+    assert np.abs(out["mask_logits"].numpy() - g["mask_logits"]).max() <= 2e-6 * scale + 1e-6
+    assert np.abs(out["mask_pred"].numpy() - g["mask_pred"]).max() <= 1e-6
+    assert np.abs(out["features"].numpy() - g["features"]).max() <= 2e-5
+    o64 = O.forward_ffn_head(x.double(), O.cast_state(sd, torch.float64), patch)
+    assert np.abs(o64["mask_logits"].numpy() - g["mask_logits_f64"]).max() <= 1e-10
+
