@@ -147,7 +147,7 @@ def cpu_baseline(P, S, budget_s=7.0):
                                               "sample": f"{n_b1} images at batch 1 (the reference evaluator's operating point) in {t_b1:.1f}s"}}
 
 
-def end_to_end(model, dev, P, S, B, streams, n_images=384):
+def end_to_end(model, dev, P, S, B, streams, n_images=768):
     """The real Evaluator over a generated DUTS-layout tree of JPEG / PNG files (300-400 px): decode on the
     host pool, resize + normalise + forward + metrics on the device."""
     import shutil
