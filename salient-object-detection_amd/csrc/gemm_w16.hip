@@ -499,6 +499,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
             }
         };
         if constexpr (HASR) load_res(0);
+        // this lane's bias values (columns 16 j + 4 kg .. + 3 of the wave's slice), fetched ONCE and all together: read per
+        // element inside the loops below they were TM x TN x 4 guarded scalar loads, each waited for in its own branch
+        float brow[TN][4];
+        {
+            const bool vec = g.bias && (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + 4 * kg;
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (vec && n + 3 < N) {
+                    bv = *reinterpret_cast<const float4*>(g.bias + n);
+                } else if (g.bias) {
+                    if (n < N) bv.x = g.bias[n];
+                    if (n + 1 < N) bv.y = g.bias[n + 1];
+                    if (n + 2 < N) bv.z = g.bias[n + 2];
+                    if (n + 3 < N) bv.w = g.bias[n + 3];
+                }
+                brow[j][0] = bv.x; brow[j][1] = bv.y; brow[j][2] = bv.z; brow[j][3] = bv.w;
+            }
+        }
 #pragma unroll
         for (int ib = 0; ib < TM / 2; ++ib) {  // 32 staged rows = two 16-row tiles
 #pragma unroll
@@ -510,8 +530,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                     float t[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float b = (g.bias && n < N) ? g.bias[n + e] : 0.f;
-                        t[e] = acc[i][j][e] * ws + b;
+                        t[e] = acc[i][j][e] * ws + brow[j][e];
                         if constexpr (EPI == SM_EPI_RELU) t[e] = fmaxf(t[e], 0.f);
                     }
                     if constexpr (EPI == SM_EPI_GELU) gelu4(t);
