@@ -349,7 +349,12 @@ __device__ unsigned long long g_gemm_stamps[2048 * 4];
 __device__ int g_gemm_stamp_filter[3];  // (N, K, M) of the launches that stamp; N = 0: every launch (sm_gemm_stamp_filter)
 // each workgroup keeps its stamps in registers and writes the record once, at the end: launches of several streams share the
 // buffer, and a record must come from ONE workgroup
-#define GEMM_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GEMM_STAMP(i)                                                                                                          \
+    do {                                                                                                                       \
+        asm volatile("" ::: "memory"); /* no load or store moves across a stamp */                                             \
+        stamp_[i] = __builtin_amdgcn_s_memtime();                                                                              \
+        asm volatile("" ::: "memory");                                                                                         \
+    } while (0)
 #define GEMM_STAMP_DECL unsigned long long stamp_[4] = {0, 0, 0, 0}
 #define GEMM_STAMP_FLUSH                                                                                                         \
     do {                                                                                                                        \
@@ -444,22 +449,34 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         issue_step(kt);
         const char* sta = smemm + (kt % NST) * A_STAGE + a_base;
         const char* stw = smemm + W_RING + (kt % NST) * W_STAGE + w_base;
-        f16x8 ah[TM], al[TM];
+        // Register plan: the W fragments of the step stay live (TN x 12 registers), the A fragments come in blocks of at most
+        // four row tiles (32 registers) - with TM = 8 all sixteen A fragments do not fit beside 64 accumulator registers in a
+        // 128-register budget, and left to itself the compiler re-read some of them from LDS in an order that changed from
+        // build to build (a K loop of 42.5k or 51.6k cycles for the same source, scripts/gemm_stamps.py)
+        f16x8 wh[TN], wl[TN], whs[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ah[i] = *reinterpret_cast<const f16x8*>(sta + i * 16 * ROWB + off_hi);
-            al[i] = *reinterpret_cast<const f16x8*>(sta + i * 16 * ROWB + off_lo);
+        for (int j = 0; j < TN; ++j) {
+            wh[j] = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_hi);
+            wl[j] = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_lo);
         }
+        constexpr int IB = TM > 4 ? 4 : TM;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {  // the W fragments one column tile at a time (register budget of the 128 x 64 wave tile)
-            const f16x8 wh = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_hi);
-            const f16x8 wl = *reinterpret_cast<const f16x8*>(stw + j * 16 * ROWB + off_lo);
-            const f16x8 whs = wh * down;
+        for (int i0 = 0; i0 < TM; i0 += IB) {
+            f16x8 ah[IB], al[IB];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, ah[i], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, al[i], acc[i][j], 0, 0, 0);
+            for (int ii = 0; ii < IB; ++ii) {
+                ah[ii] = *reinterpret_cast<const f16x8*>(sta + (i0 + ii) * 16 * ROWB + off_hi);
+                al[ii] = *reinterpret_cast<const f16x8*>(sta + (i0 + ii) * 16 * ROWB + off_lo);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (i0 == 0) whs[j] = wh[j] * down;
+#pragma unroll
+                for (int ii = 0; ii < IB; ++ii) {
+                    acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[ii], acc[i0 + ii][j], 0, 0, 0);
+                    acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[ii], acc[i0 + ii][j], 0, 0, 0);
+                    acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs[j], al[ii], acc[i0 + ii][j], 0, 0, 0);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

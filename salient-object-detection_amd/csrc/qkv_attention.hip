@@ -354,7 +354,8 @@ static_assert(QM_K_BYTES + QM_V_BYTES <= QA_LDS, "K and V^T overlay the ring");
 
 #ifdef SM_TUNING  // in-kernel stamps (tuning build only; written to a buffer nothing else reads): where a workgroup's life goes
 __device__ unsigned long long g_qkv_stamps[1024 * QA_WAVES * 8];
-#define QKV_STAMP(i) do { stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)  // kept in registers, one record per wave
+#define QKV_STAMP(i) /* kept in registers, one record per wave; no load or store moves across a stamp */ \
+    do { asm volatile("" ::: "memory"); stamp_[i] = __builtin_amdgcn_s_memtime(); asm volatile("" ::: "memory"); } while (0)
 #define QKV_STAMP_DECL unsigned long long stamp_[7] = {0, 0, 0, 0, 0, 0, 0}
 #define QKV_STAMP_FLUSH \
     do { if (blockIdx.x < 1024 && lane == 0) for (int i_ = 0; i_ < 7; ++i_) g_qkv_stamps[(blockIdx.x * QA_WAVES + wave) * 8 + i_] = stamp_[i_]; } while (0)

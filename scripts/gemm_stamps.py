@@ -5,7 +5,7 @@ Stamps: 0 kernel entry (addresses set up) | 1 first stage landed | 2 K loop done
 import ctypes, os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SM_HIP_LIB"] = os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so")
+os.environ.setdefault("SM_HIP_LIB", os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so"))
 sys.path[:0] = [os.path.join(REPO, "salient-object-detection_amd"), REPO]
 import torch
 from selfmask_amd import ops, _native as N

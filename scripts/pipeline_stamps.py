@@ -5,7 +5,7 @@ usage: pipeline_stamps.py N K [bench args]   (N, K of the GEMM launches to stamp
 import ctypes, os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SM_HIP_LIB"] = os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so")
+os.environ.setdefault("SM_HIP_LIB", os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so"))
 sys.path[:0] = [os.path.join(REPO, "salient-object-detection_amd"), REPO]
 Nf, Kf = int(sys.argv[1]), int(sys.argv[2])
 from selfmask_amd import _native as N

@@ -6,7 +6,7 @@ Stamps: 0 start | 1 first stage landed | 2 projection loop done | 3 ring drained
 import ctypes, os, sys
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["SM_HIP_LIB"] = os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so")
+os.environ.setdefault("SM_HIP_LIB", os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so"))
 sys.path[:0] = [os.path.join(REPO, "salient-object-detection_amd"), REPO]
 import torch
 from selfmask_amd import ops, _native as N
