@@ -288,6 +288,9 @@ def main():
                     help="diagnostic: every step copies its batch from pinned host memory first (PCIe-inclusive rate; "
                          "the metric keeps inputs resident in HBM)")
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: skip the evaluator kernels (not the metric)")
+    ap.add_argument("--zero-data", action="store_true",
+                    help="diagnostic: all-zero weights and images - the same instruction stream with (almost) no switching "
+                         "activity in the matrix cores; how far the result rises above the metric is how power-limited it is")
     ap.add_argument("--gemm-mode", default=None, choices=["w16", "f16x2", "fp32"], help="GEMM back end (default w16)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, no GPU): same spawn, barrier, gather and "
@@ -325,6 +328,12 @@ def main():
     model = model.to(dev)
     # every rank owns a different shard of the (synthetic) image list: rank-strided seeds
     x = torch.from_numpy(synthetic_images(1234 + rank, (B, 3, S, S))).to(dev)
+    if a.zero_data:
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.zero_()
+        model.refresh_packed()
+        x.zero_()
     # synthetic ground truth at DUTS-like native sizes (300-400 px ellipses), packed once and resident in HBM
     import numpy as np
     from selfmask_amd import ops
@@ -446,7 +455,7 @@ def main():
             "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if model.gemm_mode == "fp32" else "f32 (GEMM operands split into two f16 halves, 3 f16 MFMAs per product, f32 accumulate)",
-            "data": "synthetic",
+            "data": "synthetic" if not a.zero_data else "all zeros (diagnostic, not the metric)",
             "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
                                    f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
                        "patch": P, "image_size": S, "batch_per_gpu": B, "n_queries": 20, "gemm_mode": model.gemm_mode,
