@@ -44,12 +44,16 @@ for tag, frag in want.items():
     if wc:
         for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
             if c in vals: print(f"   {c + ' / SQ_WAVE_CYCLES':48s} {vals[c] / wc:6.3f}")
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "SQ_BUSY_CYCLES" in vals:
-        print(f"   {'SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES':48s} {vals['SQ_VALU_MFMA_BUSY_CYCLES'] / vals['SQ_BUSY_CYCLES']:6.3f}   (matrix pipe busy while the SQ is busy; both summed the same way)")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in vals and "GRBM_GUI_ACTIVE" in vals:
+        kc = vals["GRBM_GUI_ACTIVE"] / 8.0  # kernel duration in shader-clock cycles (the counter sums the 8 XCDs)
+        print(f"   {'kernel duration (GRBM_GUI_ACTIVE / 8 XCDs), cycles':48s} {kc:9.0f}")
+        print(f"   {'matrix-pipe utilisation = MFMA_BUSY / (1024 SIMDs x duration)':48s} {vals['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024.0 * kc):6.3f}")
     if "SQ_LDS_BANK_CONFLICT" in vals and vals.get("SQ_LDS_IDX_ACTIVE"):
         print(f"   {'SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE':48s} {vals['SQ_LDS_BANK_CONFLICT'] / vals['SQ_LDS_IDX_ACTIVE']:6.3f}")
-    if "SQ_INSTS_VALU" in vals and "SQ_INSTS_VALU_MFMA_MOPS_F16" in vals:
-        print(f"   {'VALU instructions per MFMA (MOPS_F16 / 512 per 16x16x32)':48s} {vals['SQ_INSTS_VALU'] / (vals['SQ_INSTS_VALU_MFMA_MOPS_F16'] / 512 * 64 / 64):6.2f}   (rough: MOPS unit per guide)")
+    if "SQ_INSTS_VALU" in vals and "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+        mf = vals["SQ_VALU_MFMA_BUSY_CYCLES"] / 16.0  # v_mfma_f32_16x16x32_f16: 16 cycles each
+        print(f"   {'MFMA instructions (MFMA_BUSY / 16)':48s} {mf:9.0f}")
+        print(f"   {'VALU instructions (MFMA included) per MFMA':48s} {vals['SQ_INSTS_VALU'] / mf:6.2f}")
     print()
 PY
 cat gpurun_out/r02_pmc_sq_counters.txt
