@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, s[kb][v]);
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        cmax = halves_max(cmax);
         // Lazy running maximum: the reference point m_run only moves when some query's new maximum exceeds it by more
         // than 2^8 in probability (p <= 256 then - harmless in fp32 and in the f16 split), which after the first chunk
         // is rare; the 64-register rescale of O runs only then (wave-uniform branch).
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS allocation
     if (!active) return;
 
-    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float l = halves_sum(l_run);
     const float inv = 1.0f / l;
     if (q0 + r < a.n_q) {
         float* Orow = a.O + b * a.sOb + (int64_t)(q0 + r) * a.sOr;

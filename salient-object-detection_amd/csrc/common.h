@@ -57,6 +57,27 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_off) {
         : "memory");
 }
 
+// Reductions across the 16-lane rows / the two halves of a wave by register swaps (gfx950 v_permlane16_swap / v_permlane32_swap)
+// instead of ds_bpermute round trips through the LDS: swapping a value with itself leaves rows {0,0,2,2} in one result and
+// {1,1,3,3} in the other (halves: {lo,lo} and {hi,hi}), so one max / add per step gives every lane the same reduced value,
+// summed in the same order on every lane.
+__device__ __forceinline__ float halves_max(float x) {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(s[0]) + __uint_as_float(s[1]);
+}
+__device__ __forceinline__ float rows4_max(float x) {  // over lanes l, l ^ 16, l ^ 32, l ^ 48
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return halves_max(fmaxf(__uint_as_float(s[0]), __uint_as_float(s[1])));
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+    const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return halves_sum(__uint_as_float(s[0]) + __uint_as_float(s[1]));
+}
+
 // ---- F16X2 split format (see gemm_f16x2.hip): hi = f16(x), lo = f16((x - hi) * 2^11) ---------------------------------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int v = 0; v < 16; ++v) cmax = fmaxf(cmax, s[kb][v]);
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        cmax = halves_max(cmax);
         const float lim = 8.0f / cs;  // lazy running maximum (attention_f16x2.hip): p <= 2^8 between moves
         if (__builtin_amdgcn_ballot_w64(cmax > m_run + lim) != 0) {
             const float m_new = fmaxf(m_run, cmax);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
             }
     }
 
-    const float l = l_run + __shfl_xor(l_run, 32, 64);
+    const float l = halves_sum(l_run);
     const float inv = 1.0f / l;
     if (q0 + r < N) {
         float* Orow = a.O + ((int64_t)b * N + q0 + r) * a.ldo;
@@ -581,8 +581,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                 for (int kt = 0; kt < 2; ++kt)
     #pragma unroll
                     for (int v = 0; v < 4; ++v) cmax = fmaxf(cmax, sc[kt][t][v]);
-                cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
-                cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+                cmax = rows4_max(cmax);
                 const float lim = 8.0f / cs;  // lazy running maximum: p <= 2^8 between moves
                 if (__builtin_amdgcn_ballot_w64(cmax > m_run[t] + lim) != 0) {
                     const float m_new = fmaxf(m_run[t], cmax);
@@ -628,8 +627,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float l = l_run[t];
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
+            l = rows4_sum(l);
             const float inv = 1.0f / l;
             const int q = q0 + t * 16 + c16;
             if (q < N) {
