@@ -80,9 +80,11 @@ class Evaluator(BaseStructure):
             else:
                 from .pipeline import PrefetchingLoader, preprocess_on_device
                 s = 0
-                for rgbs, gts, _ in PrefetchingLoader(dataset, mine, batch_size, workers=workers, depth=len(ring.streams) + 1):
-                    yield s, (rgbs, preprocess_on_device), [torch.from_numpy(g) for g in gts]
-                    s += len(rgbs)
+                # decode on the worker threads, packing into page-locked staging on one more thread, a batch ahead
+                for (packed, shapes), gts, _ in PrefetchingLoader(dataset, mine, batch_size, workers=workers,
+                                                                 depth=len(ring.streams) + 1, pack=True, pack_size=img_size):
+                    yield s, (shapes, lambda sh, S, dev, packed=packed, **kw: preprocess_on_device(sh, S, dev, packed=packed, **kw)), gts
+                    s += len(shapes)
 
         for s, x, gts in batches():
             with ring.next():
@@ -98,15 +100,15 @@ class Evaluator(BaseStructure):
                 mask_pred, obj = out["mask_pred"], out.get("objectness")
                 if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
                     mask_pred, obj = mask_pred[:, -1], obj[:, -1]
-                gtb = ops.GtBatch([g.to(device) for g in gts], device)
+                gtb = ops.GtBatch.from_packed(gts, device) if isinstance(gts, tuple) else ops.GtBatch(gts, device)
                 rows = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gtb, scale=scale)
-                rows_local[s:s + len(gts)] = rows
+                rows_local[s:s + gtb.B] = rows
                 if refine:
                     from .bilateral_solver import bilateral_solver_batch_device
                     target = ops.upsample_selected(mask_pred, rows, (img_size, img_size), "pick")
                     _, binary = bilateral_solver_batch_device(u8, target)
                     refined = ops.mask_u8_to_f32(binary).unsqueeze(1)  # one "query" per image; its objectness is moot
-                    rows_refined[s:s + len(gts)] = ops.evaluate_masks(refined, rows[:, 0:1], gtb, scale=0.0)
+                    rows_refined[s:s + gtb.B] = ops.evaluate_masks(refined, rows[:, 0:1], gtb, scale=0.0)
         ring.join()
         self.graph_stats = {"captures": self._graphed.captures, "replays": self._graphed.replays,
                             "failed": self._graphed.failed}

@@ -308,6 +308,21 @@ class GtBatch:
         self.images = torch.frombuffer(bytearray(bytes(descr)), dtype=torch.uint8).to(device)
 
 
+def _gtbatch_from_packed(packed, device) -> "GtBatch":
+    """GtBatch from pipeline.pack_gts' page-locked buffers: two asynchronous H2D copies on the current stream."""
+    from .pipeline import _POOL
+    flat, descr, shapes = packed
+    gb = GtBatch.__new__(GtBatch)
+    gb.B, gb.shapes = len(shapes), shapes
+    gb.gt_all = flat.to(device, non_blocking=True)
+    gb.images = descr.to(device, non_blocking=True)
+    _POOL.release_after((flat, descr), torch.cuda.current_stream(device))
+    return gb
+
+
+GtBatch.from_packed = staticmethod(_gtbatch_from_packed)
+
+
 def evaluate_masks(mask_pred_last: torch.Tensor, objectness_last: torch.Tensor, gts, scale: float = 0.0,
                    return_ious: bool = False):
     """Evaluator post-processing + 14 metrics per image on the device (sm_evaluate_masks_f32).

@@ -91,8 +91,12 @@ class PinnedPool:
     milliseconds) of hipHostMalloc; the pool hands out a buffer again once the event recorded behind its last H2D copy has
     completed, and grows only when every buffer of a size class is still in flight."""
 
+    _BUSY = object()  # handed out, release_after not called yet
+
     def __init__(self):
-        self._free = {}  # (dtype, rounded size) -> list of [tensor, event or None]
+        import threading
+        self._free = {}  # (dtype, rounded size) -> list of [tensor, None (free) | _BUSY | event behind the last copy]
+        self._lock = threading.Lock()
 
     @staticmethod
     def _round(n: int) -> int:
@@ -102,25 +106,27 @@ class PinnedPool:
         return r
 
     def get(self, n: int, dtype) -> torch.Tensor:
+        """Thread-safe: the loader's packing thread fills buffers for batch k + 1 while the consumer still owns batch k's."""
         key = (dtype, self._round(max(n, 1)))
-        for ent in self._free.setdefault(key, []):
-            if ent[1] is None or ent[1].query():
-                ent[1] = None
-                self._last = ent
-                return ent[0][:n]
-        ent = [torch.empty(key[1], dtype=dtype).pin_memory(), None]
-        self._free[key].append(ent)
-        self._last = ent
-        return ent[0][:n]
+        with self._lock:
+            for ent in self._free.setdefault(key, []):
+                if ent[1] is None or (ent[1] is not self._BUSY and ent[1].query()):
+                    ent[1] = self._BUSY
+                    return ent[0][:n]
+            ent = [torch.empty(key[1], dtype=dtype).pin_memory(), self._BUSY]
+            self._free[key].append(ent)
+            return ent[0][:n]
 
     def release_after(self, tensors, stream) -> None:
         """The buffers behind ``tensors`` may be reused once the work queued on ``stream`` so far has finished."""
         ev = torch.cuda.Event()
         ev.record(stream)
-        for lst in self._free.values():
-            for ent in lst:
-                if any(t.data_ptr() == ent[0].data_ptr() for t in tensors):
-                    ent[1] = ev
+        ptrs = {t.data_ptr() for t in tensors}
+        with self._lock:
+            for lst in self._free.values():
+                for ent in lst:
+                    if ent[0].data_ptr() in ptrs:
+                        ent[1] = ev
 
 
 _POOL = PinnedPool()
@@ -179,14 +185,40 @@ def _lut(device):
     return t
 
 
-def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device, pinned: bool = False, return_u8: bool = False):
+def pack_gts(gts: Sequence[np.ndarray]):
+    """Ground-truth masks of a batch -> (flat uint8 pinned tensor, descriptor bytes pinned tensor, shapes): the host half of
+    ops.GtBatch, done on the loader's packing thread."""
+    import ctypes
+    B = len(gts)
+    descr = (N.EvalImage * B)()
+    off = 0
+    for b, g in enumerate(gts):
+        assert g.dtype == np.uint8 and g.ndim == 2, "ground-truth masks must be 2-D uint8 arrays"
+        descr[b].gt_off, descr[b].H, descr[b].W = off, g.shape[0], g.shape[1]
+        off += g.size
+    flat = _POOL.get(max(off, 1), torch.uint8)
+    fv = flat.numpy()
+    o = 0
+    for g in gts:
+        fv[o:o + g.size] = g.reshape(-1)
+        o += g.size
+    dt = _POOL.get(ctypes.sizeof(descr), torch.uint8)
+    dt.numpy()[:] = np.frombuffer(bytes(descr), np.uint8)
+    return flat, dt, [(int(g.shape[0]), int(g.shape[1])) for g in gts]
+
+
+def preprocess_on_device(images, S: Optional[int], device, pinned: bool = False, return_u8: bool = False, packed=None):
     """Decoded uint8 images -> normalised fp32 model input on ``device``.  S given: (B, 3, S, S) after the PIL-exact
     bilinear resize (``return_u8``: also the resized uint8 images (B, S, S, 3)); S None: a list of (1, 3, H, W) tensors at
     native resolution (views of one buffer)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("the input pipeline's resize / normalise kernels run on a HIP device (no CPU fallback)")
-    pixels, coef, descr, max_h, max_px, out_elems = pack_images(images, S, pinned)
+    # ``packed``: the result of pack_images(images, S, pinned=True) prepared ahead of time (PrefetchingLoader(pack_size=...));
+    # ``images`` then only needs the (H, W) of every image (arrays or shape tuples)
+    if packed is not None:
+        pinned = True
+    pixels, coef, descr, max_h, max_px, out_elems = packed if packed is not None else pack_images(images, S, pinned)
     st = torch.cuda.current_stream(device).cuda_stream
     pd, cd, dd = (t.to(device, non_blocking=True) for t in (pixels, coef, descr))
     if pinned:
@@ -206,7 +238,7 @@ def preprocess_on_device(images: Sequence[np.ndarray], S: Optional[int], device,
             "sm_preprocess_normalize_u8")
     views, o = [], 0
     for im in images:
-        h, w = im.shape[:2]
+        h, w = (im.shape[:2] if hasattr(im, "shape") else im[:2])
         views.append(out[o:o + 3 * h * w].view(1, 3, h, w))
         o += 3 * h * w
     return views
@@ -228,8 +260,14 @@ class PrefetchingLoader:
     """Batches of a SaliencyTestDataset decoded by ``workers`` host threads, ``depth`` batches ahead of the consumer.
     Iterating yields (list of rgb uint8 arrays, list of GT uint8 arrays, list of dataset indices)."""
 
-    def __init__(self, dataset, indices: Sequence[int], batch_size: int, workers: Optional[int] = None, depth: int = 3):
+    def __init__(self, dataset, indices: Sequence[int], batch_size: int, workers: Optional[int] = None, depth: int = 3,
+                 pack: bool = False, pack_size: Optional[int] = None):
+        """``pack``: one more host thread assembles every decoded batch into the page-locked staging buffers of the device
+        pipeline (pack_images(..., pack_size, pinned=True) + pack_gts) while the consumer is still busy with the previous
+        batch; iterating then yields ((packed images, image shapes), packed GTs, indices) for
+        ``preprocess_on_device(shapes, S, device, packed=...)`` / ``ops.GtBatch.from_packed``."""
         self.ds, self.idx, self.bs, self.depth = dataset, list(indices), batch_size, max(1, depth)
+        self.pack, self.pack_size = pack, pack_size
         if workers is None:
             try:
                 workers = len(os.sched_getaffinity(0))
@@ -246,10 +284,30 @@ class PrefetchingLoader:
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
             def submit(k):
                 return [pool.submit(decode_item, self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]]
-            inflight = [submit(k) for k in range(min(self.depth, len(batches)))]
-            for k in range(len(batches)):
-                futs = inflight.pop(0)
-                if k + self.depth < len(batches):
-                    inflight.append(submit(k + self.depth))
+            if not self.pack:
+                inflight = [submit(k) for k in range(min(self.depth, len(batches)))]
+                for k in range(len(batches)):
+                    futs = inflight.pop(0)
+                    if k + self.depth < len(batches):
+                        inflight.append(submit(k + self.depth))
+                    items = [f.result() for f in futs]
+                    yield [it[0] for it in items], [it[1] for it in items], batches[k]
+                return
+
+            def assemble(futs):  # runs on the packing thread: waits for the batch's decodes, copies into pinned staging
                 items = [f.result() for f in futs]
-                yield [it[0] for it in items], [it[1] for it in items], batches[k]
+                rgbs = [it[0] for it in items]
+                shapes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
+                gts = [it[1] for it in items]
+                return (pack_images(rgbs, self.pack_size, pinned=True), shapes), (pack_gts(gts) if gts[0] is not None else None)
+
+            with ThreadPoolExecutor(max_workers=1) as packer:
+                def submit_packed(k):
+                    return packer.submit(assemble, submit(k))
+                inflight = [submit_packed(k) for k in range(min(self.depth, len(batches)))]
+                for k in range(len(batches)):
+                    fut = inflight.pop(0)
+                    if k + self.depth < len(batches):
+                        inflight.append(submit_packed(k + self.depth))
+                    imgs, gts = fut.result()
+                    yield imgs, gts, batches[k]
