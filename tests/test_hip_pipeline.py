@@ -56,3 +56,24 @@ def test_evaluator_rows_do_not_depend_on_the_pipeline(tmp_path, img_size, bs):
     r_dev = ev("ecssd", dir_ckpt=str(tmp_path / "d"), img_size=img_size, batch_size=bs, device=torch.device(DEV),
                input_pipeline="device", workers=3)
     assert np.array_equal(rows_host, ev.last_rows) and r_host == r_dev
+
+
+def test_loader_pack_mode_matches_direct_packing(tmp_path):
+    """PrefetchingLoader(pack=True): batches assembled into page-locked staging on the packing thread give the same device
+    tensors (images and ground truths) as packing in the consumer."""
+    from selfmask_amd import ops
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 7, seed=9, size_range=(120, 200))
+    ds = DS.get_dataset(str(tmp_path), "ecssd", eval_img_size=224)
+    plain = list(P.PrefetchingLoader(ds, range(len(ds)), batch_size=3, workers=2, depth=2))
+    packed = list(P.PrefetchingLoader(ds, range(len(ds)), batch_size=3, workers=2, depth=2, pack=True, pack_size=224))
+    assert len(plain) == len(packed) == 3
+    for (rgbs, gts, idx), ((pk, shapes), pg, idx2) in zip(plain, packed):
+        assert idx == idx2 and shapes == [r.shape[:2] for r in rgbs]
+        a = P.preprocess_on_device(rgbs, 224, DEV)
+        b = P.preprocess_on_device(shapes, 224, DEV, packed=pk)
+        assert torch.equal(a, b)
+        g1 = ops.GtBatch([torch.from_numpy(g) for g in gts], torch.device(DEV))
+        g2 = ops.GtBatch.from_packed(pg, torch.device(DEV))
+        torch.cuda.synchronize()
+        assert g1.shapes == g2.shapes and torch.equal(g1.gt_all, g2.gt_all) and torch.equal(g1.images, g2.images)
+
