@@ -373,6 +373,9 @@ typedef struct sm_weights {
                               use_binary_classifier=False - ffn is a 384->384->384->384 MLP applied to the decoder
                               queries BEFORE the mask einsum (maskformer.py:59-66,225); ffn2_w (384,384) is then a GEMM
                               weight in the gemm_mode's format, no objectness is produced (io->objectness may be NULL) */
+    int32_t normalize_before; /* 1: TransformerDecoderLayer.forward_pre in every decoder layer (transformer_decoder.py:299-327):
+                                 each sub-block normalises its input, the residual stream is only normalised by the shared
+                                 decoder.norm; 0 (the shipped config): forward_post (:260-297) */
 } sm_weights;
 
 typedef struct sm_forward_io {

@@ -191,6 +191,40 @@ def gen_forward_ffnhead():
           f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
 
 
+def gen_forward_prenorm():
+    """normalize_before=True: TransformerDecoderLayer.forward_pre (transformer_decoder.py:299-327) in every decoder layer,
+    5-D path with the binary classifier; the real reference in fp32 and fp64 (pre-sigmoid logits from the module's own
+    sub-calls, checked to reproduce the forward's mask bit for bit)."""
+    vits, mf = _import_reference()
+    torch.set_num_threads(N_THREADS)
+    patch, (B, Hh, Ww), wseed, style, xseed = 16, (2, 224, 224), 9, "calib", 1261
+    sd = synthetic_state_dict(wseed, style, patch_size=patch)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    outs = {}
+    for dtype in (torch.float32, torch.float64):
+        model = mf.MaskFormer(n_queries=20, arch="vit_small", patch_size=patch, n_decoder_layers=6, normalize_before=True,
+                              return_intermediate=True, scale_factor=2, use_binary_classifier=True).eval()
+        model.load_state_dict(sd, strict=True)
+        model = model.to(dtype)
+        with torch.no_grad():
+            o = model(x.to(dtype))
+            last = model.forward_encoder(x.to(dtype))[:, -1, ...]
+            q = model.forward_transformer_decoder(last)
+            up = model.forward_pixel_decoder(patch_tokens=last, input_size=(Hh // patch, Ww // patch))
+            logits = torch.einsum("bdqn,bnhw->bdqhw", q, up)
+            assert torch.equal(torch.sigmoid(logits), o["mask_pred"])
+        outs[dtype] = {"mask_logits": logits, "objectness": o["objectness"], "features": o["features"], "queries": q}
+    o32, o64 = outs[torch.float32], outs[torch.float64]
+    err = (o32["mask_logits"].double() - o64["mask_logits"]).abs().max().item()
+    fp = os.path.join(GOLD, "prenorm_p16_224_calib.npz")
+    np.savez_compressed(fp, meta=np.array([patch, B, Hh, Ww, wseed, xseed, N_THREADS]), style=np.array(style),
+                        mask_logits=o32["mask_logits"].numpy(), mask_logits_f64=o64["mask_logits"].numpy(),
+                        objectness=o32["objectness"].numpy(), features=o32["features"].numpy(),
+                        logit_absmax=np.array(o32["mask_logits"].abs().max().item()), f32_vs_f64_maxabs=np.array(err))
+    print(f"forward_prenorm: shape={tuple(o32['mask_logits'].shape)} max|logit|={o32['mask_logits'].abs().max().item():.2f} "
+          f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
+
+
 def _voting_cases():
     """Candidate sets shaped like the generator's (k-way one-hot cluster maps at image resolution): 9 masks per case, with
     full-height / full-width strips, an empty mask, a tiny and a near-full one, on non-multiple-of-64 sizes."""
@@ -345,6 +379,8 @@ if __name__ == "__main__":
         gen_forward3d()
     if a.only in (None, "forward_ffnhead"):
         gen_forward_ffnhead()
+    if a.only in (None, "forward_prenorm"):
+        gen_forward_prenorm()
     if a.only in (None, "voting"):
         gen_voting()
     if a.only in (None, "metrics"):

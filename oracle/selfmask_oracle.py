@@ -129,7 +129,20 @@ def decoder_layer(tgt, memory, qpos, sd, j: int) -> torch.Tensor:
     return F.layer_norm(tgt + t2, (D,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
 
 
-def decoder_forward(patch_tokens: torch.Tensor, sd, n_layers: int = 6) -> torch.Tensor:
+def decoder_layer_pre(tgt, memory, qpos, sd, j: int) -> torch.Tensor:
+    """TransformerDecoderLayer.forward_pre (normalize_before=True), transformer_decoder.py:299-327: every sub-block
+    normalises its input, the residual stream itself is never normalised inside the layer."""
+    p = f"decoder.layers.{j}."
+    t2 = F.layer_norm(tgt, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+    qk = t2 + qpos
+    tgt = tgt + _mha(qk, qk, t2, sd, p + "self_attn", same_kv=False)
+    t2 = F.layer_norm(tgt, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    tgt = tgt + _mha(t2 + qpos, memory, memory, sd, p + "multihead_attn", same_kv=True)
+    t2 = F.layer_norm(tgt, (D,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
+    return tgt + _lin(F.relu(_lin(t2, sd, p + "linear1")), sd, p + "linear2")
+
+
+def decoder_forward(patch_tokens: torch.Tensor, sd, n_layers: int = 6, normalize_before: bool = False) -> torch.Tensor:
     """MaskFormer.forward_transformer_decoder (maskformer.py:118-142) + TransformerDecoder.forward
     (transformer_decoder.py:112-150) with return_intermediate=True.  patch_tokens (B, n, 384) ->
     queries (B, n_layers, nq, 384), every layer passed through the shared final ``decoder.norm``."""
@@ -139,7 +152,7 @@ def decoder_forward(patch_tokens: torch.Tensor, sd, n_layers: int = 6) -> torch.
     out = torch.zeros_like(qpos)
     inter = []
     for j in range(n_layers):
-        out = decoder_layer(out, memory, qpos, sd, j)
+        out = (decoder_layer_pre if normalize_before else decoder_layer)(out, memory, qpos, sd, j)
         inter.append(F.layer_norm(out, (D,), sd["decoder.norm.weight"], sd["decoder.norm.bias"], 1e-5))
     return torch.stack(inter).permute(2, 0, 1, 3)
 
@@ -160,13 +173,13 @@ def objectness_head(queries: torch.Tensor, sd) -> torch.Tensor:
 
 @torch.no_grad()
 def forward(x: torch.Tensor, sd: Dict[str, torch.Tensor], patch: int = 16, n_layers: int = 6,
-            scale_factor: int = 2) -> Dict[str, torch.Tensor]:
+            scale_factor: int = 2, normalize_before: bool = False) -> Dict[str, torch.Tensor]:
     """MaskFormer.forward (maskformer.py:164-251), 5-D path (return_intermediate + use_binary_classifier).
 
     Returns the reference's dict plus ``mask_logits`` (the pre-sigmoid einsum the 1e-4 gate is stated on).
     """
     tokens, grid = encoder_forward(x, sd, patch)
-    queries = decoder_forward(tokens, sd, n_layers)
+    queries = decoder_forward(tokens, sd, n_layers, normalize_before)
     features = queries[:, -1].mean(dim=1)  # maskformer.py:198-203
     up = pixel_decoder(tokens, grid, scale_factor)
     logits = torch.einsum("bdqn,bnhw->bdqhw", queries, up)  # maskformer.py:223

@@ -314,7 +314,59 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // (B*n x 384) x (384 x L*768) instead of L small ones on the critical chain
     const int KVW = s.L * 2 * D;
     TRY(linear(c, tok_a, D, w->dec_kv_w, w->dec_kv_s, w->dec_kv_b, ws.KV, KVW, s.Mp, KVW, D, SM_EPI_BIAS, nullptr, 0, S));
-    for (int l = 0; l < s.L; ++l) {
+    for (int l = 0; l < s.L && w->normalize_before; ++l) {
+        // forward_pre (transformer_decoder.py:299-327): tgt2 = norm_k(tgt) feeds the sub-block, tgt += sub-block(tgt2); the
+        // residual stream ws.TGT (fp32) is updated in place by the RESIDUAL epilogues and never normalised in the layer
+        const sm_dec_layer& d = w->dec[l];
+        float* nrm = S ? nullptr : ws.T2;                 // fp32 copy of the normed tgt (fp32 mode only)
+        const float* nrm_a = S ? ws.TGTs : ws.T2;         // its GEMM-operand view
+        {
+            LnOpt o;  // norm1 -> tgt2 (value operand) and tgt2 + query_pos (q = k operand)
+            o.ys = S ? ws.TGTs : nullptr; o.y2 = ws.TGTQ; o.y2_s = S; o.add = qpos; o.add_rows = s.nq;
+            TRY(ln(c, ws.TGT, d.norm1_w, d.norm1_b, nrm, s.Md, 1e-5f, o));
+        }
+        {
+            sm_gemm_args g = {};
+            g.A = ws.TGTQ; g.A_alt = nrm_a; g.alt_from_n = 2 * D; g.W = d.sa_in_w; g.bias = d.sa_in_b; g.C = ws.QK;
+            g.M = (int)s.Md; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D; g.ldc = 3 * D; g.batch = 1; g.epilogue = SM_EPI_BIAS;
+            g.w_scale = d.sa_in_s;
+            TRY(gemm(c, g, S));
+        }
+        sm_attn_args a = {};
+        a.Q = ws.QK; a.K = ws.QK + D; a.V = ws.QK + 2 * D; a.O = ws.AOd;
+        a.sQb = a.sKb = a.sVb = (int64_t)s.nq * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
+        a.sOb = (int64_t)s.nq * D; a.sOr = D;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.nq; a.scale = 0.125f;
+        TRY(attn(c, a));
+        TRY(linear(c, ws.AOd, D, d.sa_out_w, d.sa_out_s, d.sa_out_b, ws.TGT, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
+        {
+            LnOpt o;  // norm2 -> only tgt2 + query_pos is needed (cross-attention query; key = value = memory)
+            o.ys = S ? ws.TGTs : nullptr; o.y2 = ws.TGTQ; o.y2_s = S; o.add = qpos; o.add_rows = s.nq;
+            TRY(ln(c, ws.TGT, d.norm2_w, d.norm2_b, nrm, s.Md, 1e-5f, o));
+        }
+        TRY(linear(c, ws.TGTQ, D, d.ca_in_w, d.ca_in_s, d.ca_in_b, ws.Qc, D, s.Md, D, D, SM_EPI_BIAS, nullptr, 0, S));
+        a = {};
+        a.Q = ws.Qc; a.K = ws.KV + (int64_t)l * 2 * D; a.V = a.K + D; a.O = ws.AOd;
+        a.sQb = (int64_t)s.nq * D; a.sQr = D; a.sKb = a.sVb = (int64_t)s.n * KVW; a.sKr = a.sVr = KVW;
+        a.sOb = (int64_t)s.nq * D; a.sOr = D;
+        a.batch = s.B; a.heads = SM_HEADS; a.n_q = s.nq; a.n_k = s.n; a.scale = 0.125f;
+        TRY(attn(c, a));
+        TRY(linear(c, ws.AOd, D, d.ca_out_w, d.ca_out_s, d.ca_out_b, ws.TGT, D, s.Md, D, D, SM_EPI_RESIDUAL, ws.TGT, D));
+        {
+            LnOpt o;  // norm3 -> operand of linear1
+            o.ys = S ? ws.TGTs : nullptr;
+            TRY(ln(c, ws.TGT, d.norm3_w, d.norm3_b, nrm, s.Md, 1e-5f, o));
+        }
+        TRY(linear(c, nrm_a, D, d.lin1_w, d.lin1_s, d.lin1_b, ws.HIDd, SM_MLP, s.Md, SM_MLP, D, SM_EPI_RELU, nullptr, 0, S));
+        TRY(linear(c, ws.HIDd, SM_MLP, d.lin2_w, d.lin2_s, d.lin2_b, ws.TGT, D, s.Md, D, SM_MLP, SM_EPI_RESIDUAL, ws.TGT, D));
+        {
+            LnOpt o;  // intermediate.append(self.norm(output)) (:138-139), scattered into (B, L, nq, 384) (+ F16X2 copy)
+            o.out_map = {s.nq, s.L * s.nq, l * s.nq};
+            o.ys = S ? ws.QDs : nullptr;
+            TRY(ln(c, ws.TGT, w->dec_norm_w, w->dec_norm_b, QD, s.Md, 1e-5f, o));
+        }
+    }
+    for (int l = 0; l < s.L && !w->normalize_before; ++l) {
         const sm_dec_layer& d = w->dec[l];
         const float* tgt_a = S ? ws.TGTs : ws.TGT;  // GEMM-operand view of tgt (TGT / T2 swap roles every layer)
         // self-attention: q = k = tgt + query_pos, v = tgt  ->  ONE launch: columns [0,768) read TGTQ, [768,1152) TGT

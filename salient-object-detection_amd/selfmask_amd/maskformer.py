@@ -127,9 +127,8 @@ class MaskFormer(nn.Module):
                                       f"(resnet50 backbones are out of scope, SURVEY.md section 2 #11)")
         if patch_size not in (8, 16):
             raise ValueError(f"patch_size={patch_size}: ViT-S/8 and ViT-S/16 are supported")
-        if normalize_before or scale_factor != 2:
-            raise NotImplementedError("normalize_before / scale_factor != 2 are not used by the shipped config and "
-                                      "not implemented")
+        if scale_factor != 2:
+            raise NotImplementedError("scale_factor != 2 is not used by the shipped config and not implemented")
         # learnable_pixel_decoder is stored and never read by the reference's forward (maskformer.py:71,144-162): accepted,
         # no effect.  lateral_connection=True is accepted here as there and fails in forward as there (see forward()).
         if not 1 <= n_decoder_layers <= N.MAX_DEC_LAYERS:
@@ -150,6 +149,7 @@ class MaskFormer(nn.Module):
         self.lateral_connection = lateral_connection
         self.learnable_pixel_decoder = learnable_pixel_decoder
         self.scale_factor = scale_factor
+        self.normalize_before = bool(normalize_before)  # TransformerDecoderLayer.forward_pre (transformer_decoder.py:299-327)
         self.return_intermediate = return_intermediate
         self.n_queries = n_queries
         self.n_decoder_layers = n_decoder_layers
@@ -252,6 +252,7 @@ class MaskFormer(nn.Module):
             w.mask_head_ffn = 1 if self.return_intermediate else 0
         (w.dec_kv_w, w.dec_kv_s), w.dec_kv_b = gws("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
         w.gemm_mode = 2 if w16 else (1 if split else 0)
+        w.normalize_before = 1 if self.normalize_before else 0
         self._packed = packed
         w.patch = e.patch_size
         w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))

@@ -299,6 +299,29 @@ def test_forward_ffn_mask_head_matches_reference(mode):
     assert ((o["mask_pred"].cpu().numpy() > 0.5) != (g["mask_pred"] > 0.5)).sum() <= 2
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_prenorm_decoder_matches_reference(mode):
+    """normalize_before=True: TransformerDecoderLayer.forward_pre (transformer_decoder.py:299-327) in every decoder layer -
+    against the REAL reference's output (tests/golden/prenorm_*.npz)."""
+    g = np.load(os.path.join(GOLD, "prenorm_p16_224_calib.npz"))
+    patch, B, Hh, Ww, wseed, xseed, _ = [int(v) for v in g["meta"]]
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch)
+    m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, normalize_before=True, return_intermediate=True,
+                   use_binary_classifier=True, gemm_mode=mode)
+    m.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    o = m.to(DEV)(x.to(DEV), return_logits=True)
+    got = o["mask_logits"].cpu().numpy()
+    d32, d64 = np.abs(got - g["mask_logits"]).max(), np.abs(got - g["mask_logits_f64"]).max()
+    ref64 = float(g["f32_vs_f64_maxabs"])
+    print(f"\n[{mode}] pre-norm decoder: |logit|max={float(g['logit_absmax']):.1f} hip-ref32={d32:.2e} hip-ref64={d64:.2e} ref32-ref64={ref64:.2e}")
+    ledger.record("forward_prenorm_decoder", mode, {"logit_absmax": float(g["logit_absmax"]), "hip_minus_ref32": float(d32),
+                                                    "hip_minus_ref64": float(d64), "ref32_minus_ref64": ref64, "rule": "hip-ref32 <= 1e-4"})
+    assert ref64 <= STRICT_BELOW and d32 <= ABS_TOL and d64 <= max(ref64, 0.5 * ABS_TOL)
+    assert np.abs(o["objectness"].cpu().numpy() - g["objectness"]).max() <= 2e-5
+    assert np.abs(o["features"].cpu().numpy() - g["features"]).max() <= 5e-5
+
+
 def test_lateral_connection_fails_like_the_reference():
     """lateral_connection=True constructs, and forward fails on the pixel decoder's 4-D assertion (maskformer.py:160)."""
     m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True,

@@ -89,3 +89,20 @@ def test_oracle_ffn_mask_head_matches_reference_vectors():
     o64 = O.forward_ffn_head(x.double(), O.cast_state(sd, torch.float64), patch)
     assert np.abs(o64["mask_logits"].numpy() - g["mask_logits_f64"]).max() <= 1e-10
 
+
+def test_oracle_prenorm_decoder_matches_reference_vectors():
+    """normalize_before=True (TransformerDecoderLayer.forward_pre, transformer_decoder.py:299-327) against the real
+    reference's output."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "prenorm_p16_224_calib.npz"))
+    patch, B, Hh, Ww, wseed, xseed, nthreads = [int(v) for v in g["meta"]]
+    torch.set_num_threads(min(nthreads, os.cpu_count() or 1))
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch)
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+    out = O.forward(x, sd, patch, normalize_before=True)
+    scale = float(g["logit_absmax"])
+    assert np.abs(out["mask_logits"].numpy() - g["mask_logits"]).max() <= 2e-6 * scale + 1e-6
+    assert np.abs(out["objectness"].numpy() - g["objectness"]).max() <= 2e-6
+    assert np.abs(out["features"].numpy() - g["features"]).max() <= 2e-5
+    o64 = O.forward(x.double(), O.cast_state(sd, torch.float64), patch, normalize_before=True)
+    assert np.abs(o64["mask_logits"].numpy() - g["mask_logits_f64"]).max() <= 1e-10
+
