@@ -376,6 +376,8 @@ typedef struct sm_weights {
     int32_t normalize_before; /* 1: TransformerDecoderLayer.forward_pre in every decoder layer (transformer_decoder.py:299-327):
                                  each sub-block normalises its input, the residual stream is only normalised by the shared
                                  decoder.norm; 0 (the shipped config): forward_post (:260-297) */
+    int32_t no_objectness;    /* 1: use_binary_classifier=False without the mask head (the 3-D path, maskformer.py:219-220): the
+                                 objectness tail is skipped and io->objectness may be NULL; ffn2_w is not read */
 } sm_weights;
 
 typedef struct sm_forward_io {
@@ -388,6 +390,8 @@ typedef struct sm_forward_io {
     float* queries;     /* (B,L,nq,384) decoder outputs after decoder.norm, or NULL (debug/parity tap)           */
     float* patch_tokens;/* (B,gh*gw,384) final-LN'd encoder tokens, or NULL (debug/parity tap; encoder_only)     */
     int32_t encoder_only;
+    int32_t last_layer_only; /* 1: return_intermediate=False (maskformer.py:219-220) - only the last decoder layer reaches the mask
+                                einsum; mask_logits / mask_pred are then (B,1,nq,2gh,2gw).  features / queries keep all L layers */
 } sm_forward_io;
 
 /* bytes of workspace MaskFormer.forward needs for this shape */

@@ -242,6 +242,12 @@ def _voting_cases():
         ms.append((yy > 3) & (yy < 9) & (xx > 5) & (xx < 12))            # tiny
         ms.append((yy >= 1) & (yy < h - 1) & (xx >= 1) & (xx < w - 1))   # nearly everything, not touching the border
         cases.append(np.stack(ms).astype(np.uint8))
+    # every candidate spans the full height or width (or is empty): with remove_long_masks the reference's filter drops them
+    # all, catches the empty torch.stack and hands back ALL masks with the identity map (utils/misc.py:311-314)
+    h, w = 64, 80
+    yy, xx = np.mgrid[:h, :w]
+    cases.append(np.stack([xx < 20, yy < 9, np.ones((h, w), bool), np.zeros((h, w), bool), xx >= 50, (yy > 30) | (xx < 3)])
+                 .astype(np.uint8))
     return cases
 
 

@@ -40,6 +40,8 @@ def filter_masks(dt_masks: torch.Tensor, remove_long_masks: bool = True, remove_
                 continue
         new_to_prev[len(kept)] = idx
         kept.append(dt_masks[idx])
+    if not kept:  # misc.py:311-314: "rare case where all predictions are filtered" -> everything back, identity map
+        return dt_masks, {i: i for i in range(len(dt_masks))}
     return torch.stack(kept, dim=0), new_to_prev
 
 

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void eval_transpose_kernel(sm_eval_args a, flo
 // batch, TA-bound); ds_read_b128 from LDS is an order of magnitude cheaper.  Integer counts go to global memory with
 // integer atomics (deterministic).
 constexpr int EV_LDS_ROWS = 8;  // low-res rows staged per chunk (falls back to global loads if the chunk needs more)
-constexpr int EV_LDS_BYTES = 64 * 1024;  // staging budget: wide masks stage fewer rows (lds_rows = budget / row bytes)
+constexpr int EV_LDS_BYTES = 60 * 1024;  // staging budget: wide masks stage fewer rows (lds_rows = budget / row bytes); with the
+                                         // kernel's ~1.1 KiB of static LDS (red_u, red_g) the workgroup stays under the 64-KiB default limit
 
 __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, const float* __restrict__ maskT_all,
                                                                 QueryStats* qpart, GtStats* gpart, int nchunk, int lds_rows) {
@@ -585,8 +586,8 @@ extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
     const int nchunk = (a->max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK;
     const sm::EvalWs w = sm::carve_eval(a->B, a->nq, nchunk, a->mh * a->mw, (char*)a->workspace);
     const int npass = (a->nq + sm::EV_MAXQ - 1) / sm::EV_MAXQ;
-    // tap staging: up to EV_LDS_ROWS low-res rows of [mw][32 queries] floats inside a 64-KiB budget; masks too wide for
-    // even one row (mw > 512) read their taps from global memory (the kernel's fallback path)
+    // tap staging: up to EV_LDS_ROWS low-res rows of [mw][32 queries] floats inside a 60-KiB budget; masks too wide for
+    // even one row (mw > 480) read their taps from global memory (the kernel's fallback path)
     const size_t row_bytes = (size_t)a->mw * sm::EV_QS * sizeof(float);
     const int lds_rows = (int)(sm::EV_LDS_BYTES / row_bytes) < sm::EV_LDS_ROWS ? (int)(sm::EV_LDS_BYTES / row_bytes) : sm::EV_LDS_ROWS;
     const int red_threads = ((a->nq + 1 + 63) / 64) * 64;  // one thread per query + a spare last lane for the GT sums

@@ -8,6 +8,7 @@
 //      produced directly in the F16X2 format by its producer (LayerNorm, attention, GELU/ReLU epilogues, im2col,
 //      up-sample); tensors that are also residuals / outputs exist in fp32 as well.  "(S)" marks them below.
 #include "common.h"
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -119,6 +120,10 @@ static int linear(const Ctx& c, const float* A, int lda, const float* W, float w
     return gemm(c, g, out_s);
 }
 static bool use_w16(const Ctx& c, const sm_gemm_args& g) { return c.W16 && g.w_scale > 0.f; }
+static bool pow2(float s) {
+    int ex = 0;
+    return s > 0.f && frexpf(s, &ex) == 0.5f;
+}
 static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
     if (!g_timing) return std::string();
     char buf[64];
@@ -439,29 +444,33 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         TRY(linear(c, ws.O2, D, w->ffn2_w, w->ffn2_s, w->ffn2_b, ws.O1, D, s.Mo, D, D, SM_EPI_BIAS, nullptr, 0, S));
         qd_a = ws.O1;
     }
+    // return_intermediate=False (the 3-D path, maskformer.py:219-220): the decoder hands back its last layer only, so only that
+    // layer's queries reach the mask einsum; the outputs are then (B, 1, nq, 2gh, 2gw)
+    const int Lm = io->last_layer_only ? 1 : s.L;
+    const float* qm_a = qd_a + (io->last_layer_only ? (int64_t)(s.L - 1) * s.nq * D : 0);
     if (s.n % 4 == 0) {
         // mask_pred = sigmoid(up(Q . tok^T)): the einsum of maskformer.py:223 commutes with the bilinear x2 of the pixel
         // decoder (:144-162) - both linear - so the GEMM runs on the token grid (N = n instead of 4n) and the (B, 4n,
         // 384) up-sampled feature map is never built
         sm_gemm_args g = {};
-        g.A = qd_a; g.W = tok_a; g.C = ws.LOG;
-        g.M = s.L * s.nq; g.N = s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = s.n;
-        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)s.n * D; g.strideC = (int64_t)s.L * s.nq * s.n;
+        g.A = qm_a; g.W = tok_a; g.C = ws.LOG;
+        g.M = Lm * s.nq; g.N = s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = s.n;
+        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)s.n * D; g.strideC = (int64_t)Lm * s.nq * s.n;
         g.batch = s.B; g.epilogue = SM_EPI_BIAS;
         TRY(gemm(c, g));
-        TRY(sm_upsample2x_logits_sigmoid_f32(ws.LOG, io->mask_logits, io->mask_pred, (int64_t)s.B * s.L * s.nq, s.gh, s.gw, st));
+        TRY(sm_upsample2x_logits_sigmoid_f32(ws.LOG, io->mask_logits, io->mask_pred, (int64_t)s.B * Lm * s.nq, s.gh, s.gw, st));
     } else {  // token counts that are not a multiple of 4 (float4 rows of the GEMM output): the literal order
         TRY(S ? sm_upsample2x_tokens_f16x2(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st)
               : sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
         // mask_pred[b] = sigmoid(Q[b] (L*nq x 384) . up[b]^T (384 x 4n))   (maskformer.py:223)
         sm_gemm_args g = {};
-        g.A = qd_a; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;
-        g.M = s.L * s.nq; g.N = 4 * s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = 4 * s.n;
-        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)4 * s.n * D; g.strideC = (int64_t)s.L * s.nq * 4 * s.n;
+        g.A = qm_a; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;
+        g.M = Lm * s.nq; g.N = 4 * s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = 4 * s.n;
+        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)4 * s.n * D; g.strideC = (int64_t)Lm * s.nq * 4 * s.n;
         g.batch = s.B; g.epilogue = SM_EPI_SIGMOID2;
         TRY(gemm(c, g));
     }
-    if (w->mask_head_ffn) return SM_OK;  // no objectness on this path (maskformer.py:246-249)
+    if (w->mask_head_ffn || w->no_objectness) return SM_OK;  // no objectness on these paths (maskformer.py:246-249, :219-220)
     TRY(linear(c, qd_a, D, w->ffn0_w, w->ffn0_s, w->ffn0_b, ws.O1, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0, S));
     TRY(linear(c, ws.O1, D, w->ffn1_w, w->ffn1_s, w->ffn1_b, ws.O2, D, s.Mo, D, D, SM_EPI_RELU, nullptr, 0));
     TRY(sm_rowdot_sigmoid_f32(ws.O2, w->ffn2_w, w->ffn2_b, io->objectness, (int)s.Mo, st));
@@ -481,10 +490,24 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
         const int gh = (io->H + w->patch - 1) / w->patch, gw = (io->W + w->patch - 1) / w->patch;
         SM_REQUIRE((4 * gh * gw) % 4 == 0, "sm_maskformer_forward: mask width must be a multiple of 4");
     }
+    if (w->gemm_mode == 2) {
+        // W16 weights carry their 2^-s in the *_s fields; a zero (a caller that filled the pointers but not the scales) would
+        // otherwise send W16 bytes through the F16X2 kernel: wrong results, no error
+        bool ok = pow2(w->patch_s) && pow2(w->dec_kv_s) && pow2(w->ffn0_s) && pow2(w->ffn1_s) && (!w->mask_head_ffn || pow2(w->ffn2_s));
+        for (int i = 0; i < SM_ENC_DEPTH && ok; ++i)
+            ok = pow2(w->enc[i].qkv_s) && pow2(w->enc[i].proj_s) && pow2(w->enc[i].fc1_s) && pow2(w->enc[i].fc2_s);
+        for (int l = 0; l < w->n_dec_layers && ok; ++l) {
+            const sm_dec_layer& d = w->dec[l];
+            ok = pow2(d.sa_in_s) && pow2(d.sa_out_s) && pow2(d.ca_in_s) && pow2(d.ca_out_s) && pow2(d.lin1_s) && pow2(d.lin2_s);
+        }
+        SM_REQUIRE(ok, "sm_maskformer_forward: gemm_mode 2 needs every weight's 2^-s (*_s fields) to be a positive power of two");
+    }
     if (!io->encoder_only)
-        SM_REQUIRE(io->mask_pred && (io->objectness || w->mask_head_ffn) && io->features, "sm_maskformer_forward: null output");
+        SM_REQUIRE(io->mask_pred && (io->objectness || w->mask_head_ffn || w->no_objectness) && io->features,
+                   "sm_maskformer_forward: null output");
     else
         SM_REQUIRE(io->patch_tokens, "sm_maskformer_forward: encoder_only needs patch_tokens");
+    SM_REQUIRE(!(io->last_layer_only && w->mask_head_ffn), "sm_maskformer_forward: last_layer_only is the 3-D path (no ffn mask head)");
     return SM_OK;
 }
 

@@ -88,7 +88,17 @@ __global__ __launch_bounds__(64) void vote_finalize_kernel(const VoteBox* __rest
             else if ((double)((b.xmax - b.xmin) * (b.ymax - b.ymin)) > 0.95 * H * W) k = 0;
         }
         skeep[t] = k;
-        keep[t] = k;
+    }
+    __syncthreads();
+    // "rare case where all predictions are filtered" (misc.py:311-314): torch.stack of the empty list raises, the reference
+    // catches it and returns dt_masks UNFILTERED with the identity index map - the vote then runs over all M candidates
+    // (empty ones included: their IoU entries are 0 / (0 + 1e-7) = 0)
+    int any = 0;
+    for (int j = 0; j < M; ++j) any |= skeep[j];
+    __syncthreads();
+    if (t < M) {
+        if (!any) skeep[t] = 1;
+        keep[t] = skeep[t];
     }
     __syncthreads();
     if (t < M) {

@@ -72,13 +72,14 @@ class Weights(C.Structure):
                 ("ffn0_w", fp), ("ffn0_b", fp), ("ffn1_w", fp), ("ffn1_b", fp), ("ffn2_w", fp), ("ffn2_b", fp),
                 ("dec_kv_w", fp), ("dec_kv_b", fp), ("gemm_mode", C.c_int32), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
                 ("n_dec_layers", C.c_int32), ("patch_s", C.c_float), ("ffn0_s", C.c_float), ("ffn1_s", C.c_float),
-                ("dec_kv_s", C.c_float), ("ffn2_s", C.c_float), ("mask_head_ffn", C.c_int32), ("normalize_before", C.c_int32)]
+                ("dec_kv_s", C.c_float), ("ffn2_s", C.c_float), ("mask_head_ffn", C.c_int32), ("normalize_before", C.c_int32),
+                ("no_objectness", C.c_int32)]
 
 
 class ForwardIO(C.Structure):
     _fields_ = [("x", fp), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("mask_logits", fp), ("mask_pred", fp), ("objectness", fp), ("features", fp), ("queries", fp),
-                ("patch_tokens", fp), ("encoder_only", C.c_int32)]
+                ("patch_tokens", fp), ("encoder_only", C.c_int32), ("last_layer_only", C.c_int32)]
 
 
 class KernelTime(C.Structure):

@@ -9,6 +9,7 @@ around it (Flask, base64 PNG encoding, LANCZOS resize to the upload's size, jet 
 path: ``predict()`` still returns the reference's response keys, built on the host from ``predict_tensors()``.
 """
 import base64
+import threading
 from argparse import Namespace
 from io import BytesIO
 from typing import Optional, Union
@@ -48,6 +49,9 @@ class SelfMaskInference:
         self.input_size = 224  # T.Resize((224, 224)), app.py:199
         # batch 1, one shape: capture at the first call, replay ever after
         self.base_structure._graphed = GraphedForward(self.model, enabled=hip_graph, max_graphs=2, admit_after=0)
+        # The replayed graph owns ONE static input and ONE set of outputs per (shape, stream); Flask's server is threaded
+        # (app.py:3927), so requests are serialised from the copy into the static input to the last D2H copy
+        self._lock = threading.Lock()
 
     # ---- host: whatever arrives -> (H, W, 3) uint8 ------------------------------------------------------------------------
     @staticmethod
@@ -70,7 +74,12 @@ class SelfMaskInference:
     @torch.no_grad()
     def predict_tensors(self, image) -> dict:
         """The arithmetic of ``predict`` (app.py:241-284): {"best_idx", "objectness_scores" (nq,), "mask" (2g, 2g) in [0, 1]}."""
-        x = self.preprocess_image(image)
+        rgb = self._to_rgb_array(image)  # decode outside the lock: host work of the request itself
+        with self._lock:
+            return self._predict_locked(rgb)
+
+    def _predict_locked(self, rgb: np.ndarray) -> dict:
+        x = self.preprocess_image(rgb)
         out = self.base_structure._forward({"x": x})
         mask_pred, obj = out["mask_pred"], out.get("objectness")
         if obj is None:

@@ -161,7 +161,8 @@ class MaskFormer(nn.Module):
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
         self.weights_generation = 0  # bumped whenever the packed weights are dropped: captured hipGraphs hold raw
                                      # pointers into them, graphs.GraphedForward destroys its graphs when this changes
-        self._workspace = {}     # (device, B, H, W, stream) -> uint8 tensor
+        self._workspace = {}     # (device, B, H, W, stream) -> uint8 tensor, least recently used first
+        self.max_workspaces = 12  # shapes x streams kept resident (native-resolution evaluation walks many shapes)
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.refresh_packed())
         self.eval()
 
@@ -250,6 +251,7 @@ class MaskFormer(nn.Module):
         else:  # 384 -> 384 mask head (maskformer.py:59-66): a GEMM weight like the others; used on the 5-D path only
             (w.ffn2_w, w.ffn2_s), w.ffn2_b = gws("ffn2", f[2].weight), f[2].bias.data_ptr()
             w.mask_head_ffn = 1 if self.return_intermediate else 0
+            w.no_objectness = 1  # no binary classifier: forward.hip stops before the objectness tail
         (w.dec_kv_w, w.dec_kv_s), w.dec_kv_b = gws("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
         w.gemm_mode = 2 if w16 else (1 if split else 0)
         w.normalize_before = 1 if self.normalize_before else 0
@@ -282,10 +284,12 @@ class MaskFormer(nn.Module):
             nbytes = N.load().sm_forward_workspace_bytes(w, B, H, W)
             if nbytes == 0:
                 raise RuntimeError("sm_forward_workspace_bytes returned 0 (bad shape)")
-            if len(self._workspace) > 8:  # keep a few shapes resident, not an unbounded set
-                self._workspace.clear()
+            while len(self._workspace) >= self.max_workspaces:  # least recently used first (dicts keep insertion order)
+                self._workspace.pop(next(iter(self._workspace)))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-            self._workspace[k] = ws
+        else:
+            del self._workspace[k]
+        self._workspace[k] = ws  # (re-)inserted last: most recently used
         return ws
 
     # ---- forward ----------------------------------------------------------------------------------------------
@@ -328,7 +332,9 @@ class MaskFormer(nn.Module):
             N.check(lib.sm_maskformer_forward(w, io, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream),
                     "sm_maskformer_forward")
             return {"patch_tokens": tokens.view(B, gh, gw, N.EMBED)}
-        mask_pred = torch.empty((B, L, nq, 2 * gh, 2 * gw), device=dev, dtype=torch.float32)
+        Lm = L if self.return_intermediate else 1  # the 3-D path only builds the last layer's masks (maskformer.py:219-220)
+        io.last_layer_only = 0 if self.return_intermediate else 1
+        mask_pred = torch.empty((B, Lm, nq, 2 * gh, 2 * gw), device=dev, dtype=torch.float32)
         objectness = torch.empty((B, L, nq, 1), device=dev, dtype=torch.float32)
         features = torch.empty((B, N.EMBED), device=dev, dtype=torch.float32)
         io.mask_pred, io.objectness, io.features = mask_pred.data_ptr(), objectness.data_ptr(), features.data_ptr()

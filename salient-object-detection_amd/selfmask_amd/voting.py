@@ -13,7 +13,8 @@ from . import _native as N
 def vote_mask(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False):
     """batch_pred_masks (M, H, W) 0/1 on a HIP device -> (best mask (H, W), best index among the SURVIVORS,
     new_index_to_prev_index) as the reference returns them, plus the device tensors under ``vote_mask.last`` for inspection.
-    Raises ValueError when every candidate is filtered (the reference's ``torch.stack`` of an empty list raises too)."""
+    When every candidate is filtered the reference catches the empty ``torch.stack`` and votes over ALL candidates with the
+    identity index map (utils/misc.py:311-314); the kernel does the same (``keep`` comes back all ones)."""
     if not batch_pred_masks.is_cuda:
         raise RuntimeError("vote_mask (MI355X) needs its candidates on a HIP device; there is no CPU fallback")
     m = batch_pred_masks.to(torch.uint8).contiguous()
@@ -33,8 +34,8 @@ def vote_mask(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, re
                                  torch.cuda.current_stream(dev).cuda_stream), "sm_vote_masks_u8")
     keep_h, best_h = keep.cpu().tolist(), int(best.cpu()[0])
     vote_mask.last = {"keep": keep, "iou": iou, "row_sums": sums, "best": best}
-    if best_h < 0:
-        raise ValueError("every candidate mask was filtered")
+    if best_h < 0:  # unreachable since the all-filtered fallback (kept as a guard against a broken launch)
+        raise RuntimeError("sm_vote_masks_u8 returned no winner")
     new_to_prev: Dict[int, int] = {}
     for prev, k in enumerate(keep_h):
         if k:

@@ -62,3 +62,34 @@ def test_predict_response_keys_and_input_kinds(tmp_path):
     b = inf.predict(Image.fromarray(rgb))
     assert set(a) >= {"original", "mask", "heatmap", "objectness_scores"} and a["mask"].startswith("data:image/png;base64,")
     assert a["mask"] == b["mask"] and a["best_idx"] == b["best_idx"] and len(a["objectness_scores"]) == 20
+
+
+def test_concurrent_requests_get_their_own_results():
+    """Flask serves requests on threads (app.py:3927): the shared hipGraph's static input / outputs must not interleave.
+    Eight threads x six requests over four different images; every response equals the single-threaded one."""
+    import threading
+    m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(5, "soft", patch_size=16), strict=True)
+    inf = SelfMaskInference(None, Namespace(**CFG), device=DEV, model=m)
+    rng = np.random.Generator(np.random.PCG64(11))
+    imgs = [rng.integers(0, 256, size=(200 + 37 * k, 260 - 21 * k, 3), dtype=np.uint8) for k in range(4)]
+    want = [inf.predict_tensors(im) for im in imgs]
+    errors = []
+
+    def worker(t):
+        try:
+            for k in range(6):
+                i = (t + k) % 4
+                got = inf.predict_tensors(imgs[i])
+                if got["best_idx"] != want[i]["best_idx"] or not np.array_equal(got["mask"], want[i]["mask"]) \
+                        or not np.array_equal(got["objectness_scores"], want[i]["objectness_scores"]):
+                    errors.append((t, k, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import voting_oracle as V  # noqa: E402  (checker only)
 from selfmask_amd.voting import vote_mask  # noqa: E402
+from vote_known_answers import KNOWN_ANSWERS  # noqa: E402
 
 DEV = "cuda:0"
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "voting.npz")
@@ -50,6 +51,22 @@ def test_27_candidates_like_the_generator():
     assert new_to_prev == ref_map and best == ref_best and torch.equal(best_mask.cpu(), ref_mask)
 
 
-def test_everything_filtered_raises():
-    with pytest.raises(ValueError, match="filtered"):
-        vote_mask(torch.zeros(3, 40, 40, dtype=torch.uint8, device=DEV))
+def test_everything_filtered_votes_over_all_candidates():
+    """utils/misc.py:311-314: nothing survives -> dt_masks unfiltered + identity map (golden case 3 pins it with the real
+    filter_masks); all-empty candidates: every IoU is 0 / (0 + 1e-7) = 0, the first index wins."""
+    masks = torch.zeros(3, 40, 40, dtype=torch.uint8)
+    best_mask, best, new_to_prev = vote_mask(masks.to(DEV))
+    assert best == 0 and new_to_prev == {0: 0, 1: 1, 2: 2} and not best_mask.any()
+    ref_mask, ref_best, ref_map, _, _ = V.vote_mask(masks)
+    assert ref_best == best and ref_map == new_to_prev
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN_ANSWERS))
+def test_vote_known_answers(name):
+    """Hand-computed answers (tests/vote_known_answers.py): a tie, a single survivor, the all-filtered fallback."""
+    masks, flags, want_best, want_map, want_table = KNOWN_ANSWERS[name]()
+    best_mask, best, new_to_prev = vote_mask(torch.from_numpy(masks).to(DEV), *flags)
+    assert best == want_best and new_to_prev == want_map
+    assert np.array_equal(best_mask.cpu().numpy(), masks[want_map[want_best]])
+    kept = [new_to_prev[k] for k in range(len(new_to_prev))]
+    assert np.array_equal(vote_mask.last["iou"].cpu().numpy()[kept][:, kept], np.asarray(want_table, np.float32))

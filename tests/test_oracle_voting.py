@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import voting_oracle as V
+from vote_known_answers import KNOWN_ANSWERS
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "voting.npz")
 FLAGS = {"long": (True, False), "both": (True, True), "none": (False, False)}
@@ -24,7 +25,26 @@ def test_filter_matches_reference(tag):
 
 def test_vote_picks_the_consensus_mask():
     g = np.load(GOLD)
-    for i in range(int(g["n_cases"])):
+    for i in range(3):  # the three blob cases (case 3 is the all-filtered set)
         best_mask, best, new_to_prev, table, ious = V.vote_mask(torch.from_numpy(g[f"masks_{i}"]))
         assert new_to_prev[best] in (0, 1, 2, 3)  # one of the blobs around the common object
         assert torch.allclose(torch.diagonal(table), torch.ones(table.shape[0]), atol=1e-6)
+
+
+def test_all_filtered_returns_everything_like_the_reference():
+    """golden case 3: the real filter_masks filtered every candidate and returned all six with the identity map."""
+    g = np.load(GOLD)
+    masks = torch.from_numpy(g["masks_3"])
+    assert g["kept_3_long"].tolist() == list(range(masks.shape[0]))
+    kept, new_to_prev = V.filter_masks(masks, True, False)
+    assert torch.equal(kept, masks) and new_to_prev == {i: i for i in range(masks.shape[0])}
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN_ANSWERS))
+def test_vote_known_answers(name):
+    """vote_mask exists in the reference as bytecode only: hand-computed cases pin the restatement (tests/vote_known_answers.py)."""
+    masks, flags, want_best, want_map, want_table = KNOWN_ANSWERS[name]()
+    best_mask, best, new_to_prev, table, ious = V.vote_mask(torch.from_numpy(masks), *flags)
+    assert best == want_best and new_to_prev == want_map
+    assert np.array_equal(best_mask.numpy(), masks[want_map[want_best]])
+    assert np.array_equal(table.numpy(), np.asarray(want_table, np.float32))
