@@ -102,7 +102,7 @@ def _cores():
     return min(cores, int(os.environ.get("SM_CPU_BASELINE_THREADS", "16")))  # a 1-GPU box's CPU share is 16 cores
 
 
-def cpu_baseline(P, S, budget_s=7.0):
+def cpu_baseline(P, S, budget_s=7.0, legs=("step", "forward", "one_thread", "batch1"), Bc=16):
     """The CPU oracle (torch-CPU restatement, fp32) on this host: bounded samples of the same workload."""
     import numpy as np
     from oracle import selfmask_oracle as O  # measured as the BASELINE only, never on the product path
@@ -110,7 +110,6 @@ def cpu_baseline(P, S, budget_s=7.0):
     from selfmask_amd import synthetic_state_dict, synthetic_images
     cores = _cores()
     sd = synthetic_state_dict(0, "soft", patch_size=P)
-    Bc = 16
     x = torch.from_numpy(synthetic_images(1234, (Bc, 3, S, S)))
     rng = np.random.Generator(np.random.PCG64(99))
     gts = []
@@ -135,16 +134,21 @@ def cpu_baseline(P, S, budget_s=7.0):
             E.all_metrics(pm[q], gts[b]); E.all_metrics(pm[ub], gts[b])
 
     n_all, t_all = timed(step_all, Bc, cores)
-    n_fwd, t_fwd = timed(lambda: O.forward(x, sd, P), Bc, cores)
-    n_one, t_one = timed(lambda: O.forward(x[:4], sd, P), 4, 1)
-    n_b1, t_b1 = timed(lambda: O.forward(x[:1], sd, P), 1, cores)
-    return {"value": round(n_all / t_all, 2), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n_all} images (batches of {Bc}, ViT-S/{P} {S}x{S}: fp32 torch-CPU oracle forward + post-processing + "
-                      f"14 metrics per image) in {t_all:.1f}s",
-            "forward_only_all_cores": {"value": round(n_fwd / t_fwd, 2), "cores": cores, "sample": f"{n_fwd} images in {t_fwd:.1f}s"},
-            "forward_only_one_thread": {"value": round(n_one / t_one, 2), "cores": 1, "sample": f"{n_one} images (batches of 4) in {t_one:.1f}s"},
-            "forward_only_batch1_all_cores": {"value": round(n_b1 / t_b1, 2), "cores": cores,
-                                              "sample": f"{n_b1} images at batch 1 (the reference evaluator's operating point) in {t_b1:.1f}s"}}
+    res = {"value": round(n_all / t_all, 2), "unit": "images/sec", "cores": cores, "kind": "port",
+           "sample": f"{n_all} images (batches of {Bc}, ViT-S/{P} {S}x{S}: fp32 torch-CPU oracle forward + post-processing + "
+                     f"14 metrics per image) in {t_all:.1f}s"}
+    if "forward" in legs:
+        n_fwd, t_fwd = timed(lambda: O.forward(x, sd, P), Bc, cores)
+        res["forward_only_all_cores"] = {"value": round(n_fwd / t_fwd, 2), "cores": cores, "sample": f"{n_fwd} images in {t_fwd:.1f}s"}
+    if "one_thread" in legs:
+        n_one, t_one = timed(lambda: O.forward(x[:4], sd, P), 4, 1)
+        res["forward_only_one_thread"] = {"value": round(n_one / t_one, 2), "cores": 1, "sample": f"{n_one} images (batches of 4) in {t_one:.1f}s"}
+    if "batch1" in legs:
+        n_b1, t_b1 = timed(lambda: O.forward(x[:1], sd, P), 1, cores)
+        res["forward_only_batch1_all_cores"] = {"value": round(n_b1 / t_b1, 2), "cores": cores,
+                                                "sample": f"{n_b1} images at batch 1 (the reference evaluator's operating point) in {t_b1:.1f}s"}
+    torch.set_num_threads(cores)
+    return res
 
 
 def end_to_end(model, dev, P, S, B, streams, n_images=768):
@@ -207,6 +211,152 @@ def serving_latency(model, dev, n=200):
             "with_jpeg_decode_p99_ms": q(lat_jpeg, 99), "hip_graph_replays": g.replays, "hip_graph_failed": g.failed,
             "what": "SelfMaskInference.predict_tensors: 300x400 RGB -> resize 224 + normalise (HIP) -> graph-replayed forward -> "
                     "arg-max objectness + mask (HIP) -> D2H"}
+
+
+class Workload:
+    """One configuration of the step loop: model + a resident batch + synthetic ground truth + graphs + stream ring."""
+
+    def __init__(self, dev, P, S, B, rank=0, gemm_mode=None, streams=3, graph=True, zero_data=False, host_input=False,
+                 forward_only=False):
+        import numpy as np
+        from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images, ops
+        from selfmask_amd.graphs import GraphedForward
+        from selfmask_amd.streams import StreamRing
+        self.dev, self.P, self.S, self.B, self.ops, self.forward_only = dev, P, S, B, ops, forward_only
+        model = MaskFormer(n_queries=20, patch_size=P, n_decoder_layers=6, return_intermediate=True,
+                           use_binary_classifier=True, gemm_mode=gemm_mode)
+        model.load_state_dict(synthetic_state_dict(0, "soft", patch_size=P), strict=True)
+        self.model = model.to(dev)
+        # every rank owns a different shard of the (synthetic) image list: rank-strided seeds
+        self.x = torch.from_numpy(synthetic_images(1234 + rank, (B, 3, S, S))).to(dev)
+        if zero_data:
+            with torch.no_grad():
+                for p_ in self.model.parameters():
+                    p_.zero_()
+            self.model.refresh_packed()
+            self.x.zero_()
+        # synthetic ground truth at DUTS-like native sizes (300-400 px ellipses), packed once and resident in HBM
+        rng = np.random.Generator(np.random.PCG64(99 + rank))
+        gts = []
+        for _ in range(B):
+            h, w = (int(v) for v in rng.integers(300, 401, size=2))
+            yy, xx = np.mgrid[:h, :w]
+            gts.append(torch.from_numpy(((((yy - h * rng.uniform(.3, .7)) / (h * rng.uniform(.1, .3))) ** 2 +
+                                          ((xx - w * rng.uniform(.3, .7)) / (w * rng.uniform(.1, .3))) ** 2) <= 1)
+                                        .astype(np.uint8)))
+        self.gt_batch = ops.GtBatch(gts, dev)
+        self.x_host = self.x.cpu().pin_memory() if host_input else None
+        self.fwd = GraphedForward(self.model, enabled=graph)
+        self.ring = StreamRing(dev, max(1, streams))
+
+    def step(self):
+        # one evaluator iteration over a batch (evaluator.pyc@L193-228, batched mode): forward, last decoder
+        # layer, up-sample to each GT's size, upper-bound + arg-max-objectness query, 7 metrics x 2 -> 16 floats/image
+        out = self.fwd(self.x_host.to(self.dev, non_blocking=True) if self.x_host is not None else self.x)
+        if self.forward_only:
+            return out["objectness"][:, -1, :16, 0]
+        return self.ops.evaluate_masks(out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0], self.gt_batch, scale=0.0)
+
+    def run_steps(self, n, dst=None):
+        self.ring.fork()
+        for k in range(n):
+            with self.ring.next():
+                r = self.step()
+                if dst is not None:
+                    dst[k * self.B:(k + 1) * self.B] = r
+        self.ring.join()
+
+    def prime(self, warmup):
+        # untimed, not part of W: every stream sees the batch shape often enough to be admitted to the graph cache, so its
+        # hipGraph is captured here and never inside the timed region, whatever --warmup is
+        self.run_steps((self.fwd.policy.admit_after + 1) * len(self.ring.streams))
+        self.run_steps(warmup)
+
+    def timed(self, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        self.run_steps(steps)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+
+def roofline_of(kern, gemm_mode, name=None):
+    """roofline dict of one tapped kernel (default: the one holding the largest share of the forward)."""
+    peak = F32_MFMA_PEAK_TFLOPS if gemm_mode == "fp32" else F16_MFMA_PEAK_TFLOPS
+    issue = 3.0 if gemm_mode in ("w16", "f16x2") else 1.0  # MFMA FLOPs issued per algorithmic FLOP (hi*hi, hi*lo, lo*hi)
+    if name is None:
+        name = next(iter(kern))
+    v = kern[name]
+    # An event pair around a launch also measures the command processor's event handling (event_overhead_us, what an EMPTY
+    # pair reads); it is subtracted, and a launch shorter than three times that overhead is below what the taps resolve:
+    # no rate is quoted for it (rocprofv3's kernel trace under profiles/ is the source for such kernels)
+    resolved = v["avg_launch_us"] >= 3.0 * v["event_overhead_us"]
+    if "layernorm" in name:
+        r = {"bound": "hbm", "achieved": round(v["achieved_gbs"], 1) if resolved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(v["achieved_gbs"] / HBM_PEAK_GBS, 4) if resolved else None}
+    else:
+        r = {"bound": "mfma", "achieved": round(v["achieved_tflops"], 2) if resolved else None, "peak": peak, "unit": "TFLOP/s",
+             "frac": round(v["achieved_tflops"] / peak, 4) if resolved else None,
+             "mfma_issued_tflops": round(v["achieved_tflops"] * issue, 2) if resolved else None}
+        if "attention" in name and resolved:  # 49 FLOP/B at N=197, d=64: below the machine balance (312), so also quote bytes
+            r.update(hbm_gbs=round(v["achieved_gbs"], 1), hbm_frac=round(v["achieved_gbs"] / HBM_PEAK_GBS, 4))
+    if not resolved:
+        r["note"] = "launch shorter than 3x the event-pair overhead: below the taps' resolution, no rate quoted"
+    r.update(kernel=name, avg_launch_us=round(v["avg_launch_us"], 2), launches_per_forward=v["launches_per_forward"],
+             flops_per_launch=v["flops_per_launch"], event_overhead_us=round(v["event_overhead_us"], 2),
+             share_of_forward=round(v["total_ms_per_forward"] / sum(u["total_ms_per_forward"] for u in kern.values()), 3))
+    return r
+
+
+def shape_leg(dev, P, S, B, streams, steps=20, warmup=5, cpu=True):
+    """The same step loop at another shape of BASELINE.json / the shipped YAML (ViT-S/8 224^2: the shipped checkpoint's
+    patch size, N = 785; 384^2: configs[2], N = 577): images/s, the dominant kernel's roofline, the CPU oracle beside it."""
+    w = Workload(dev, P, S, B, streams=streams)
+    w.prime(warmup)
+    dt = w.timed(steps)
+    kern = time_forward_kernels(w.model, w.x)
+    value = steps * B / dt
+    flops_img = forward_flops_per_image(P, S)
+    res = {"workload": f"ViT-S/{P} {S}x{S}, nq=20, batch={B}, forward + evaluator post-processing and metrics",
+           "tokens": (S // P) ** 2 + 1, "value": round(value, 1), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+           "model_tflops": round(value * flops_img / 1e12, 2), "roofline": roofline_of(kern, w.model.gemm_mode),
+           "roofline_other_kernels": {k: roofline_of(kern, w.model.gemm_mode, k) for k in list(kern)[1:]}}
+    if cpu:
+        res["cpu_baseline"] = cpu_baseline(P, S, budget_s=4.0, legs=("step",), Bc=8)
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
+def throughput_mode_leg(dev, ref, steps=30, warmup=6):
+    """SURVEY.md 7.2 (b) diagnostic - NOT the metric: the same pipeline with ONE f16 MFMA per product in the weight GEMMs and the
+    encoder attention (gemm_mode "f16": plain f16 operands, fp32 accumulate, fp32 LayerNorm / softmax statistics, fp32-grade
+    mask einsum).  Reported: images/s, the dominant kernel's fraction of the f16 roof (what the kernel STRUCTURE reaches with
+    the x3 removed), and how far the results move from the fp32-grade path on the bench batch."""
+    w = Workload(dev, ref.P, ref.S, ref.B, gemm_mode="f16", streams=len(ref.ring.streams))
+    w.prime(warmup)
+    dt = w.timed(steps)
+    kern = time_forward_kernels(w.model, w.x)
+    a = ref.model(ref.x, return_logits=True)
+    b = w.model(w.x, return_logits=True)
+    la, lb = a["mask_logits"][:, -1], b["mask_logits"][:, -1]
+    rows_a = ref.ops.evaluate_masks(a["mask_pred"][:, -1], a["objectness"][:, -1, :, 0], ref.gt_batch, scale=0.0)
+    rows_b = w.ops.evaluate_masks(b["mask_pred"][:, -1], b["objectness"][:, -1, :, 0], w.gt_batch, scale=0.0)
+    torch.cuda.synchronize()
+    iou_a, iou_b = rows_a[:, 0].double().mean().item(), rows_b[:, 0].double().mean().item()  # arg-max-objectness query's IoU
+    res = {"what": "diagnostic, not the metric: gemm_mode='f16' (one MFMA per product); headline stays fp32-grade (w16)",
+           "value": round(steps * w.B / dt, 1), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+           "roofline": roofline_of(kern, "f16"),
+           "roofline_other_kernels": {k: roofline_of(kern, "f16", k) for k in list(kern)[1:4]},
+           "vs_fp32_grade_on_bench_batch": {
+               "max_abs_logit_diff": float((la - lb).abs().max()), "logit_absmax": float(la.abs().max()),
+               "pixel_flip_rate": float(((la >= 0) != (lb >= 0)).float().mean()),
+               "argmax_objectness_changed": int((rows_a[:, 14] != rows_b[:, 14]).sum()),
+               "mean_iou_fp32_grade": round(iou_a, 3), "mean_iou_f16": round(iou_b, 3),
+               "iou_identical_to_3dp": round(iou_a, 3) == round(iou_b, 3)}}
+    del w
+    torch.cuda.empty_cache()
+    return res
 
 
 def spawn_ranks(n: int, argv) -> int:
@@ -279,7 +429,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="batches in flight per GPU: step k runs on HIP stream k %% streams (own workspace), so one "
                          "batch's latency-bound decoder / metrics kernels fill CUs beside another's encoder GEMMs")
-    ap.add_argument("--no-graph", action="store_true", help="launch the forward's 171 kernels eagerly instead of replaying "
+    ap.add_argument("--no-graph", action="store_true", help="launch the forward's kernels eagerly instead of replaying "
                                                             "one captured hipGraph per stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustained-steps", type=int, default=500, help="extra untimed-by-the-contract leg: the same loop for this many steps")
@@ -291,7 +441,9 @@ def main():
     ap.add_argument("--zero-data", action="store_true",
                     help="diagnostic: all-zero weights and images - the same instruction stream with (almost) no switching "
                          "activity in the matrix cores; how far the result rises above the metric is how power-limited it is")
-    ap.add_argument("--gemm-mode", default=None, choices=["w16", "f16x2", "fp32"], help="GEMM back end (default w16)")
+    ap.add_argument("--gemm-mode", default=None, choices=["w16", "f16x2", "fp32", "f16"],
+                    help="GEMM back end (default w16; f16 = the one-MFMA-per-product diagnostic, not the metric)")
+    ap.add_argument("--no-other-shapes", action="store_true", help="skip the ViT-S/8 224^2 and ViT-S/16 384^2 legs")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, no GPU): same spawn, barrier, gather and "
                          "max-over-ranks timing around a trivial step; used by tests/test_bench_launcher_cpu.py")
@@ -320,56 +472,10 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
 
-    from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images
     P, S, B = a.patch, a.size, a.batch
-    model = MaskFormer(n_queries=20, patch_size=P, n_decoder_layers=6, return_intermediate=True,
-                       use_binary_classifier=True, gemm_mode=a.gemm_mode)
-    model.load_state_dict(synthetic_state_dict(0, "soft", patch_size=P), strict=True)
-    model = model.to(dev)
-    # every rank owns a different shard of the (synthetic) image list: rank-strided seeds
-    x = torch.from_numpy(synthetic_images(1234 + rank, (B, 3, S, S))).to(dev)
-    if a.zero_data:
-        with torch.no_grad():
-            for p_ in model.parameters():
-                p_.zero_()
-        model.refresh_packed()
-        x.zero_()
-    # synthetic ground truth at DUTS-like native sizes (300-400 px ellipses), packed once and resident in HBM
-    import numpy as np
-    from selfmask_amd import ops
-    rng = np.random.Generator(np.random.PCG64(99 + rank))
-    gts = []
-    for _ in range(B):
-        h, w = (int(v) for v in rng.integers(300, 401, size=2))
-        yy, xx = np.mgrid[:h, :w]
-        gts.append(torch.from_numpy(((((yy - h * rng.uniform(.3, .7)) / (h * rng.uniform(.1, .3))) ** 2 +
-                                      ((xx - w * rng.uniform(.3, .7)) / (w * rng.uniform(.1, .3))) ** 2) <= 1)
-                                    .astype(np.uint8)))
-    gt_batch = ops.GtBatch(gts, dev)
-    x_host = x.cpu().pin_memory() if a.host_input else None
-
-    from selfmask_amd.graphs import GraphedForward
-    fwd = GraphedForward(model, enabled=not a.no_graph)
-
-    def step():
-        # one evaluator iteration over a batch (evaluator.pyc@L193-228, batched mode): forward, last decoder
-        # layer, up-sample to each GT's size, upper-bound + arg-max-objectness query, 7 metrics x 2 -> 16 floats/image
-        out = fwd(x_host.to(dev, non_blocking=True) if a.host_input else x)
-        if a.forward_only:
-            return out["objectness"][:, -1, :16, 0]
-        return ops.evaluate_masks(out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0], gt_batch, scale=0.0)
-
-    from selfmask_amd.streams import StreamRing
-    ring = StreamRing(dev, max(1, a.streams))
-
-    def run_steps(n, dst=None):
-        ring.fork()
-        for k in range(n):
-            with ring.next():
-                r = step()
-                if dst is not None:
-                    dst[k * B:(k + 1) * B] = r
-        ring.join()
+    wl = Workload(dev, P, S, B, rank=rank, gemm_mode=a.gemm_mode, streams=a.streams, graph=not a.no_graph, zero_data=a.zero_data,
+                  host_input=a.host_input, forward_only=a.forward_only)
+    model, x, fwd, ring, run_steps = wl.model, wl.x, wl.fwd, wl.ring, wl.run_steps
 
     # priming (untimed, not part of W): every stream sees the batch shape often enough to be admitted to the graph
     # cache, so its hipGraph is captured here and never inside the timed region, whatever --warmup is
@@ -421,40 +527,29 @@ def main():
         flops_img = forward_flops_per_image(P, S)
         dom_name, dom = next(iter(kern.items()))
         # HBM bytes per launch from the PMC passes of this same command (scripts/pmc_traffic.sh writes
-        # profiles/r02_pmc_traffic.json with the hash of the kernel sources it ran on).  A profiler cannot run inside the
+        # profiles/r03_pmc_traffic.json with the hash of the kernel sources it ran on).  A profiler cannot run inside the
         # timed process, so the committed measurement is quoted - only if it was taken on exactly these sources, else null.
         traffic, traffic_note = None, "no PMC file for these kernel sources"
         try:
-            with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             if pmc.get("source_hash") == source_hash():
                 traffic = pmc["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
-                traffic_note = "profiles/r02_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950)"
+                traffic_note = "profiles/r03_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950)"
             else:
-                traffic_note = "profiles/r02_pmc_traffic.json was taken on other kernel sources (hash mismatch): not quoted"
+                traffic_note = "profiles/r03_pmc_traffic.json was taken on other kernel sources (hash mismatch): not quoted"
         except (OSError, ValueError, KeyError):
             pass
-        gemm = "gemm" in dom_name or "attention" in dom_name
         peak = F32_MFMA_PEAK_TFLOPS if model.gemm_mode == "fp32" else F16_MFMA_PEAK_TFLOPS
         issue = 3.0 if model.gemm_mode in ("w16", "f16x2") else 1.0  # MFMA FLOPs issued per algorithmic FLOP (hi*hi, hi*lo, lo*hi)
-
-        def roof(v, name):
-            if "layernorm" in name:
-                return {"bound": "hbm", "achieved": round(v["achieved_gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(v["achieved_gbs"] / HBM_PEAK_GBS, 4)}
-            r = {"bound": "mfma", "achieved": round(v["achieved_tflops"], 2), "peak": peak, "unit": "TFLOP/s",
-                 "frac": round(v["achieved_tflops"] / peak, 4),
-                 "mfma_issued_tflops": round(v["achieved_tflops"] * issue, 2)}
-            if "attention" in name:  # 49 FLOP/B at N=197, d=64: below the machine balance (312), so also quote bytes
-                r.update(hbm_gbs=round(v["achieved_gbs"], 1), hbm_frac=round(v["achieved_gbs"] / HBM_PEAK_GBS, 4))
-            return r
 
         res = {
             "metric": "images/sec (224^2, nq=20)", "value": round(value, 1), "unit": "images/sec", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "host_enqueue_ms_per_step": round(t_enqueued / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if model.gemm_mode == "fp32" else "f32 (GEMM operands split into two f16 halves, 3 f16 MFMAs per product, f32 accumulate)",
+            "dtype": "f32" if model.gemm_mode == "fp32" else "f16 (diagnostic throughput mode: one MFMA per product)" if model.gemm_mode == "f16"
+                     else "f32 (GEMM operands split into two f16 halves, 3 f16 MFMAs per product, f32 accumulate)",
             "data": "synthetic" if not a.zero_data else "all zeros (diagnostic, not the metric)",
             "config": {"workload": f"DUTS-TE-shaped synthetic images, ViT-S/{P} {S}x{S}, nq=20, batch={B}/GPU, "
                                    f"MaskFormer.forward + evaluator post-processing and metrics (BASELINE.json configs[1])",
@@ -463,12 +558,7 @@ def main():
                        "hip_graph": {"captures": fwd.captures, "replays": fwd.replays, "failed": fwd.failed},
                        "parallelism": f"images sharded x{world}, one all-gather of result rows"},
             "model_tflops": round(value * flops_img / 1e12, 2),
-            "roofline": dict(roof(dom, dom_name), kernel=dom_name, traffic=traffic, traffic_source=traffic_note,
-                             avg_launch_us=round(dom["avg_launch_us"], 2),
-                             launches_per_forward=dom["launches_per_forward"],
-                             flops_per_launch=dom["flops_per_launch"],
-                             share_of_forward=round(dom["total_ms_per_forward"] / sum(v["total_ms_per_forward"] for v in kern.values()), 3),
-                             event_overhead_us=round(dom["event_overhead_us"], 2),
+            "roofline": dict(roofline_of(kern, model.gemm_mode, dom_name), traffic=traffic, traffic_source=traffic_note,
                              how="HIP events around every launch of this kernel inside 3 real forwards on ONE stream "
                                  "(sm_forward_timing); an empty event pair's time (event_overhead_us) is subtracted per launch",
                              whole_step={"achieved": round(value / world * flops_img / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
@@ -477,14 +567,18 @@ def main():
                                          "what": "algorithmic FLOPs of the forward x images/s of the timed region, per GPU: the rate the "
                                                  "three-batches-in-flight pipeline sustains (the tile shapes are chosen for THIS figure; "
                                                  "a lone launch of the dominant kernel is slower than with smaller tiles)"}),
-            "roofline_other_kernels": {k: dict(roof(v, k), avg_launch_us=round(v["avg_launch_us"], 2),
-                                               launches_per_forward=v["launches_per_forward"])
-                                       for k, v in list(kern.items())[1:]},
+            "roofline_other_kernels": {k: roofline_of(kern, model.gemm_mode, k) for k in list(kern)[1:]},
         }
         res["sustained"] = sustained
         if world == 1 and not a.quick:
             res["end_to_end"] = end_to_end(model, dev, P, S, B, len(ring.streams))
             res["serving"] = serving_latency(model, dev)
+            if model.gemm_mode == "w16" and not a.zero_data:
+                res["throughput_mode"] = throughput_mode_leg(dev, wl)
+            if (P, S) == (16, 224) and not a.no_other_shapes:
+                # the shapes the shipped checkpoint (ViT-S/8, configs/duts-...yaml:39) and configs[2] (384^2) run at
+                res["other_shapes"] = {"vit_s8_224": shape_leg(dev, 8, 224, 16, len(ring.streams), cpu=not a.no_cpu_baseline),
+                                       "vit_s16_384": shape_leg(dev, 16, 384, 32, len(ring.streams), cpu=not a.no_cpu_baseline)}
         if world == 1 and not a.no_cpu_baseline and not a.quick:
             res["cpu_baseline"] = cpu_baseline(P, S)
         print(json.dumps(res), flush=True)

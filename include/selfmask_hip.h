@@ -76,6 +76,9 @@ typedef struct sm_gemm_args {
     float ln_eps;
     float w_scale;         /* sm_gemm_w16 only: 2^-s of the W16 weight tensor (sm_split_w16 scale = 2^s); the accumulator
                               is multiplied by it before the bias                                                       */
+    int32_t mfma_terms;    /* sm_gemm_w16 only: 0 or 3 = the fp32-grade product (three f16 MFMAs per 32-k step); 1 = "throughput
+                              mode" (SURVEY.md 7.2 (b)): hi x hi only, plain f16 operands, fp32 accumulate - a diagnostic of the
+                              kernel structure without the x3, two orders of magnitude outside the 1e-4 gate, never the metric */
 } sm_gemm_args;
 
 /* C = epilogue(A W^T): replaces every F.linear / conv-as-GEMM / bmm on the path
@@ -184,6 +187,7 @@ typedef struct sm_qkv_attn_args {
     float w_scale;      /* 2^-s of Wqkv */
     float scale;        /* softmax scale: head_dim ** -0.5 = 0.125 (vision_transformer.py:104) */
     int32_t out_f16x2;
+    int32_t mfma_terms; /* 0 or 3: fp32-grade products; 1: throughput-mode diagnostic (hi x hi only), see sm_gemm_args */
 } sm_qkv_attn_args;
 int sm_qkv_attention_w16(const sm_qkv_attn_args* args, void* stream);
 int sm_qkv_attention_max_tokens(void);
@@ -357,7 +361,9 @@ typedef struct sm_weights {
     const float* dec_kv_w; /* packed by the host from the state_dict: rows [384:1152) of every decoder layer's      */
     const float* dec_kv_b; /*   multihead_attn.in_proj_{weight,bias}, concatenated -> (L*768, 384) / (L*768): the   */
                            /*   cross-attention K/V of ALL layers is one GEMM over the encoder memory               */
-    int32_t gemm_mode;     /* 0: exact-fp32 MFMA GEMMs; 1: split-operand f16 GEMMs - every GEMM weight pointer above
+    int32_t gemm_mode;     /* (3: as 2 with ONE MFMA per product in the weight GEMMs and the encoder attention - the throughput-mode
+                              diagnostic of SURVEY.md 7.2 (b), outside the 1e-4 gate, never the metric)
+                              0: exact-fp32 MFMA GEMMs; 1: split-operand f16 GEMMs - every GEMM weight pointer above
                               (patch_w, qkv/proj/fc1/fc2, decoder in/out projections, linear1/2, dec_kv_w, ffn0/1)
                               then holds the F16X2 copy of the tensor (sm_split_f16x2), biases / norms stay fp32;
                               2: as 1 with the weights in the W16 format (sm_split_w16) and their 2^-s in the *_s

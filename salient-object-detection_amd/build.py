@@ -46,16 +46,20 @@ def needs_build(tuning: bool = False) -> bool:
     return _stale(lib, [os.path.join(CSRC, s) for s in _sources()] + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = True, tuning: bool = False) -> str:
+def build(force: bool = False, verbose: bool = True, tuning: bool = False, variant: str = "", defines=()) -> str:
+    """``variant`` + ``defines``: an experiment build (A/B runs, scripts/ab_libs.sh): lib/libselfmask_hip_<variant>.so compiled
+    with the given -D flags, objects under build/<variant>/; never loaded unless SM_HIP_LIB points at it."""
     tuning = tuning or os.environ.get("SM_TUNING") == "1"
     lib = LIB_TUNING if tuning else LIB
+    if variant:
+        lib, force = os.path.join(LIB_DIR, f"libselfmask_hip_{variant}.so"), True
     if not force and not needs_build(tuning):
         return lib
     os.makedirs(LIB_DIR, exist_ok=True)
-    odir = os.path.join(OBJ_DIR, "tuning" if tuning else "product")
+    odir = os.path.join(OBJ_DIR, variant or ("tuning" if tuning else "product"))
     os.makedirs(odir, exist_ok=True)
     hipcc = _hipcc()
-    extra = ["-DSM_TUNING=1"] if tuning else []
+    extra = (["-DSM_TUNING=1"] if tuning else []) + [f"-D{d}" for d in defines]
 
     def compile_one(src):
         obj = os.path.join(odir, src.replace(".hip", ".o"))
@@ -76,4 +80,6 @@ def build(force: bool = False, verbose: bool = True, tuning: bool = False) -> st
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv))
+    var = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")]
+    print(build(force="--force" in sys.argv, tuning="--tuning" in sys.argv, variant=var[0] if var else "",
+                defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

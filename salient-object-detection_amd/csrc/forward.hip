@@ -106,6 +106,7 @@ struct Ctx {
     bool S;    // split-operand GEMM mode (activations that only feed GEMMs are F16X2)
     bool W16;  // ... with the weights in the W16 format: weight GEMMs run the single-accumulator kernel (gemm_w16.hip)
     hipStream_t st;
+    int terms;  // MFMAs per product in the W16 kernels: 3 (fp32-grade) or 1 (gemm_mode 3: the throughput-mode diagnostic)
 };
 
 // `ws` = the weight tensor's 2^-s (W16 mode; 0 = W is not a W16 weight: an activation operand, or another mode)
@@ -143,7 +144,11 @@ static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
 }
 static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s) {
     TapScope tap(c.st, gemm_name(c, g), 2.0 * g.M * g.N * g.K * (g.batch > 0 ? g.batch : 1), 0.0);
-    if (use_w16(c, g)) return sm_gemm_w16(&g, out_s ? 1 : 0, c.st);
+    if (use_w16(c, g)) {
+        sm_gemm_args gt = g;
+        gt.mfma_terms = c.terms;
+        return sm_gemm_w16(&gt, out_s ? 1 : 0, c.st);
+    }
     return c.S ? sm_gemm_f16x2(&g, out_s ? 1 : 0, c.st) : sm_gemm_f32(&g, c.st);
 }
 // split mode, N = 384: C = R + (A W^T + b) in place on the residual stream AND the next pre-norm of it (F16X2) in one
@@ -222,7 +227,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     const Shape s = make_shape(w, io->B, io->H, io->W);
     Ws ws = carve(s, wsbase);
     const int D = SM_EMBED;
-    const Ctx c = {w->gemm_mode >= 1, w->gemm_mode == 2, st};
+    const Ctx c = {w->gemm_mode >= 1, w->gemm_mode >= 2, st, w->gemm_mode == 3 ? 1 : 3};
     const bool S = c.S;
 
     // ---- tokens: patch embedding + cls + position (vision_transformer.py:269-281) ----------------------------
@@ -263,7 +268,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         if (fused_qkv) {
             sm_qkv_attn_args q = {};
             q.Xn = ws.Xn; q.Wqkv = e.qkv_w; q.bias = e.qkv_b; q.O = ws.AO; q.ldx = D; q.ldo = D;
-            q.B = s.B; q.N = s.N; q.w_scale = e.qkv_s; q.scale = 0.125f; q.out_f16x2 = 1;
+            q.B = s.B; q.N = s.N; q.w_scale = e.qkv_s; q.scale = 0.125f; q.out_f16x2 = 1; q.mfma_terms = c.terms;
             // algorithmic work of SURVEY.md 8d: 2 N 384 1152 + 4 N^2 384 FLOPs, x in + o out bytes per image
             TapScope tap(c.st, sm_qkv_attention_kernel_name(), (double)s.B * (2.0 * s.N * D * 3 * D + 4.0 * s.N * s.N * D),
                          2.0 * s.M * D * 4);
@@ -480,7 +485,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
 static int validate(const sm_weights* w, const sm_forward_io* io) {
     SM_REQUIRE(w && io, "sm_maskformer_forward: null arguments");
     SM_REQUIRE(w->patch == 8 || w->patch == 16, "sm_maskformer_forward: patch=%d (8 or 16)", w->patch);
-    SM_REQUIRE(w->gemm_mode >= 0 && w->gemm_mode <= 2, "sm_maskformer_forward: gemm_mode=%d (0, 1 or 2)", w->gemm_mode);
+    SM_REQUIRE(w->gemm_mode >= 0 && w->gemm_mode <= 3, "sm_maskformer_forward: gemm_mode=%d (0..3)", w->gemm_mode);
     SM_REQUIRE(w->n_dec_layers >= 1 && w->n_dec_layers <= SM_MAX_DEC_LAYERS, "sm_maskformer_forward: n_dec_layers=%d",
                w->n_dec_layers);
     SM_REQUIRE(w->n_queries >= 1 && w->pos_grid >= 1, "sm_maskformer_forward: bad n_queries/pos_grid");
@@ -490,7 +495,7 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
         const int gh = (io->H + w->patch - 1) / w->patch, gw = (io->W + w->patch - 1) / w->patch;
         SM_REQUIRE((4 * gh * gw) % 4 == 0, "sm_maskformer_forward: mask width must be a multiple of 4");
     }
-    if (w->gemm_mode == 2) {
+    if (w->gemm_mode >= 2) {
         // W16 weights carry their 2^-s in the *_s fields; a zero (a caller that filled the pointers but not the scales) would
         // otherwise send W16 bytes through the F16X2 kernel: wrong results, no error
         bool ok = pow2(w->patch_s) && pow2(w->dec_kv_s) && pow2(w->ffn0_s) && pow2(w->ffn1_s) && (!w->mask_head_ffn || pow2(w->ffn2_s));
@@ -500,7 +505,7 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
             const sm_dec_layer& d = w->dec[l];
             ok = pow2(d.sa_in_s) && pow2(d.sa_out_s) && pow2(d.ca_in_s) && pow2(d.ca_out_s) && pow2(d.lin1_s) && pow2(d.lin2_s);
         }
-        SM_REQUIRE(ok, "sm_maskformer_forward: gemm_mode 2 needs every weight's 2^-s (*_s fields) to be a positive power of two");
+        SM_REQUIRE(ok, "sm_maskformer_forward: gemm_mode 2/3 needs every weight's 2^-s (*_s fields) to be a positive power of two");
     }
     if (!io->encoder_only)
         SM_REQUIRE(io->mask_pred && (io->objectness || w->mask_head_ffn || w->no_objectness) && io->features,

@@ -365,11 +365,18 @@ __device__ unsigned long long g_qkv_stamps[1024 * QA_WAVES * 8];
 #define QKV_STAMP_FLUSH do {} while (0)
 #endif
 
-template <int NST>
+// TERMS = 3: fp32-grade products everywhere (three MFMAs each).  TERMS = 1: throughput-mode diagnostic (hi x hi only in the
+// projection, in K Q^T and in P V; softmax statistics stay fp32) - see gemm_w16.hip
+// LOADERS = waves that issue the LDS-DMA pieces of the ring (the first LOADERS waves, pieces dealt round-robin over them).
+// 7: every wave (round 2).  4: waves 0-3 - one per SIMD - feed the ring, waves 4-6 only compute: every wave leaves the stage
+// barrier at the same moment, a stage is 52 pieces = ~830 cycles of the CU's one address unit, and with all seven waves queued on
+// it the matrix pipe idled at the top of every stage (stage = DMA issue + MFMA instead of their maximum: 3.2k cycles for 2.3k
+// of MFMA work).  With the younger wave of each SIMD free of DMA, its MFMAs run while the older one feeds the ring.
+template <int NST, int TERMS = 3, int LOADERS = QA_WAVES>
 __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_qkv_attn_args a) {
     constexpr int ROWB = 128, XT = QA_TOK * ROWB, WT = 192 * ROWB, STAGE = XT + WT;
-    constexpr int XP = XT / 1024, NP = STAGE / 1024, PPW = (NP + QA_WAVES - 1) / QA_WAVES, DUMP = NST * STAGE;
-    static_assert(DUMP + (PPW * QA_WAVES - NP) * 1024 <= QA_LDS, "ring + dump zone must fit in LDS");
+    constexpr int XP = XT / 1024, NP = STAGE / 1024, PPW = (NP + LOADERS - 1) / LOADERS, DUMP = NST * STAGE;
+    static_assert(DUMP + (PPW * LOADERS - NP) * 1024 <= QA_LDS, "ring + dump zone must fit in LDS");
     extern __shared__ __attribute__((aligned(16))) char smm[];
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smm;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -387,10 +394,11 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     const char* X = reinterpret_cast<const char*>(a.Xn + (int64_t)b * N * a.ldx);
     const char* W = reinterpret_cast<const char*>(a.Wqkv);
 
+    const bool loader = wave < LOADERS;
     const char* src[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int p = wave + QA_WAVES * j;
+        const int p = wave + LOADERS * j;
         const int prow = lane >> 3;
         if (p < XP) {
             const int row = p * 8 + prow;
@@ -403,9 +411,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         }
     }
     auto issue = [&](int kt, int slot) {
+        if (!loader) return;  // wave-uniform: the compute-only waves have no piece in flight, their vmcnt waits pass at once
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int p = wave + QA_WAVES * j;
+            const int p = wave + LOADERS * j;
             const unsigned d = p < NP ? lds0 + slot * STAGE + p * 1024 : lds0 + DUMP + (p - NP) * 1024;
             lds_dma16(src[j] + kt * ROWB, __builtin_amdgcn_readfirstlane(d));
         }
@@ -446,23 +455,30 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 xh[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_hi);
-                xl[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_lo);
+                if constexpr (TERMS == 3) xl[t] = *reinterpret_cast<const f16x8*>(st + (wave * 32 + t * 16) * ROWB + f_lo);
             }
     #pragma unroll
             for (int d = 0; d < 12; ++d) {
                 const f16x8 wh = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_hi);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_lo);
-                const f16x8 whs = wh * down;
+                f16x8 wl = wh, whs = wh;
+                if constexpr (TERMS == 3) {
+                    wl = *reinterpret_cast<const f16x8*>(st + XT + d * 16 * ROWB + f_lo);
+                    whs = wh * down;
+                }
     #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     if (d < 8) {  // Q^T, K^T: D[dim][token]
                         acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[t], acc[d][t], 0, 0, 0);
-                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[t], acc[d][t], 0, 0, 0);
-                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, xl[t], acc[d][t], 0, 0, 0);
+                        if constexpr (TERMS == 3) {
+                            acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[t], acc[d][t], 0, 0, 0);
+                            acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs, xl[t], acc[d][t], 0, 0, 0);
+                        }
                     } else {      // V: D[token][dim]
                         acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wh, acc[d][t], 0, 0, 0);
-                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wl, acc[d][t], 0, 0, 0);
-                        acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], whs, acc[d][t], 0, 0, 0);
+                        if constexpr (TERMS == 3) {
+                            acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[t], wl, acc[d][t], 0, 0, 0);
+                            acc[d][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[t], whs, acc[d][t], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -553,10 +569,13 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         mn = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], qh[t][s], mn, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], ql[t][s], cr, 0, 0, 0);
-                        cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[s], qh[t][s], cr, 0, 0, 0);
+                        if constexpr (TERMS == 3) {
+                            cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[s], ql[t][s], cr, 0, 0, 0);
+                            cr = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[s], qh[t][s], cr, 0, 0, 0);
+                        }
                     }
-                    sc[kt][t] = cr * (1.0f / 2048.0f) + mn;
+                    if constexpr (TERMS == 3) sc[kt][t] = cr * (1.0f / 2048.0f) + mn;
+                    else sc[kt][t] = mn;
                 }
             }
         };
@@ -613,8 +632,10 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     om[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[t], om[dt][t], 0, 0, 0);
-                    oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t], oc[dt][t], 0, 0, 0);
-                    oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], oc[dt][t], 0, 0, 0);
+                    if constexpr (TERMS == 3) {
+                        oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[t], oc[dt][t], 0, 0, 0);
+                        oc[dt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[t], oc[dt][t], 0, 0, 0);
+                    }
                 }
             }
     #pragma unroll
@@ -657,12 +678,13 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
 static int qkv_mode() {
     static const char* ring = getenv("SM_QKV_RING");
     return !ring ? 4 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : !strcmp(ring, "32x2") ? 0 :
-           !strcmp(ring, "m16x3") ? 5 : 4;
+           !strcmp(ring, "m16x3") ? 5 : !strcmp(ring, "m16x2L4") ? 6 : !strcmp(ring, "m16x3L4") ? 7 : 4;
 }
 // name rocprofv3 reports for the selected kernel (labels the in-situ taps of forward.hip)
 const char* sm_qkv_attention_kernel_name() {
     static const char* names[] = {"qkv_attention_kernel<32, 2>", "qkv_attention_kernel<32, 3>", "qkv_attention_kernel<16, 2>",
-                                  "qkv_attention_kernel<16, 6>", "qkv_attention_m16_kernel<2>", "qkv_attention_m16_kernel<3>"};
+                                  "qkv_attention_kernel<16, 6>", "qkv_attention_m16_kernel<2>", "qkv_attention_m16_kernel<3>",
+                                  "qkv_attention_m16_kernel<2, 3, 4>", "qkv_attention_m16_kernel<3, 3, 4>"};
     return names[qkv_mode()];
 }
 
@@ -673,6 +695,7 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
     SM_REQUIRE(a->B > 0 && a->N > 0 && a->N <= sm::QA_KROWS, "sm_qkv_attention_w16: N=%d tokens (1..%d: K and V of a head stay in LDS)",
                a ? a->N : 0, sm::QA_KROWS);
     SM_REQUIRE(a->scale > 0.f, "sm_qkv_attention_w16: scale must be positive");
+    SM_REQUIRE(a->mfma_terms == 0 || a->mfma_terms == 1 || a->mfma_terms == 3, "sm_qkv_attention_w16: mfma_terms must be 0/3 or 1");
     int ex = 0;
     SM_REQUIRE(a->w_scale > 0.f && frexpf(a->w_scale, &ex) == 0.5f, "sm_qkv_attention_w16: w_scale must be the weight's 2^-s");
     SM_REQUIRE(a->ldx % 8 == 0 && a->ldx >= SM_EMBED && a->ldo % 8 == 0 && a->ldo >= SM_EMBED &&
@@ -685,6 +708,9 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
         (void)hipGetLastError();
     });
     // stage shape of the projection phase: tuning knob (same results), "<k per stage>x<ring stages>"; measured on MI355X with
@@ -692,8 +718,11 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
     const int mode = qkv_mode();
     const dim3 grid(a->B * SM_HEADS), block(sm::QA_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (mode == 4) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2>), grid, block, sm::QA_LDS, st, *a);
+    if (a->mfma_terms == 1) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 1>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 4) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 5) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 6) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 3, 4>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 7) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3, 3, 4>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 1) hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 3>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 2) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 2>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 3) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 6>), grid, block, sm::QA_LDS, st, *a);

@@ -22,7 +22,8 @@ class GemmArgs(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("batch", C.c_int32), ("epilogue", C.c_int32), ("alt_from_n", C.c_int32), ("split_k", C.c_int32),
-                ("patch_n", C.c_int32), ("ln_gamma", fp), ("ln_beta", fp), ("ln_eps", C.c_float), ("w_scale", C.c_float)]
+                ("patch_n", C.c_int32), ("ln_gamma", fp), ("ln_beta", fp), ("ln_eps", C.c_float), ("w_scale", C.c_float),
+                ("mfma_terms", C.c_int32)]
 
 
 class RowMap(C.Structure):
@@ -46,7 +47,8 @@ class AttnArgs(C.Structure):
 
 class QkvAttnArgs(C.Structure):
     _fields_ = [("Xn", fp), ("Wqkv", fp), ("bias", fp), ("O", fp), ("ldx", C.c_int64), ("ldo", C.c_int64),
-                ("B", C.c_int32), ("N", C.c_int32), ("w_scale", C.c_float), ("scale", C.c_float), ("out_f16x2", C.c_int32)]
+                ("B", C.c_int32), ("N", C.c_int32), ("w_scale", C.c_float), ("scale", C.c_float), ("out_f16x2", C.c_int32),
+                ("mfma_terms", C.c_int32)]
 
 
 ENC_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",

@@ -120,7 +120,10 @@ class MaskFormer(nn.Module):
         """Same arguments as the reference.  ``gemm_mode`` (extra, keyword-only) picks the GEMM back end:
         "w16" (default; f16 matrix cores, split operands, weights pre-scaled per tensor so every weight GEMM sums in ONE
         fp32 accumulator - fp32-grade results), "f16x2" (the same arithmetic with two accumulators and unscaled weights)
-        or "fp32" (exact fp32 MFMA).  The environment variable SM_GEMM_MODE overrides the default."""
+        or "fp32" (exact fp32 MFMA).  "f16" is the throughput-mode DIAGNOSTIC of SURVEY.md 7.2 (b): the w16 kernels with ONE
+        f16 MFMA per product (plain f16 operands, fp32 accumulate, fp32 LayerNorm / softmax statistics, fp32-grade mask
+        einsum) - two orders of magnitude outside the 1e-4 logit gate, reported beside the metric, never as it.  The
+        environment variable SM_GEMM_MODE overrides the default."""
         super().__init__()
         if arch != "vit_small":
             raise NotImplementedError(f"arch={arch!r}: only the DINO ViT-S encoder is on the MI355X hot path "
@@ -155,8 +158,8 @@ class MaskFormer(nn.Module):
         self.n_decoder_layers = n_decoder_layers
         import os
         self.gemm_mode = gemm_mode or os.environ.get("SM_GEMM_MODE", "w16")
-        if self.gemm_mode not in ("w16", "f16x2", "fp32"):
-            raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'w16', 'f16x2' or 'fp32'")
+        if self.gemm_mode not in ("w16", "f16x2", "fp32", "f16"):
+            raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'w16', 'f16x2', 'fp32' (or the 'f16' throughput-mode diagnostic)")
         self._table = None       # (Weights struct, key) cache
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
         self.weights_generation = 0  # bumped whenever the packed weights are dropped: captured hipGraphs hold raw
@@ -192,8 +195,8 @@ class MaskFormer(nn.Module):
                                    f"(got {p.device}, {p.dtype}); the product path has no CPU fallback")
         w = N.Weights()
         e = self.encoder
-        split = self.gemm_mode in ("f16x2", "w16")
-        w16 = self.gemm_mode == "w16"
+        split = self.gemm_mode in ("f16x2", "w16", "f16")
+        w16 = self.gemm_mode in ("w16", "f16")
         packed = {}
         d = N.EMBED
         # cross-attention K/V projections of all layers packed into one (L*768, 384) weight: rows [384:1152) of each
@@ -253,7 +256,7 @@ class MaskFormer(nn.Module):
             w.mask_head_ffn = 1 if self.return_intermediate else 0
             w.no_objectness = 1  # no binary classifier: forward.hip stops before the objectness tail
         (w.dec_kv_w, w.dec_kv_s), w.dec_kv_b = gws("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
-        w.gemm_mode = 2 if w16 else (1 if split else 0)
+        w.gemm_mode = 3 if self.gemm_mode == "f16" else 2 if w16 else (1 if split else 0)
         w.normalize_before = 1 if self.normalize_before else 0
         self._packed = packed
         w.patch = e.patch_size

@@ -90,6 +90,37 @@ def test_forward_matches_reference_vectors(fp, mode):
         assert np.abs(out["patch_tokens"][0].cpu().numpy() - g["patch_tokens_b0"]).max() <= 5e-5
 
 
+@pytest.mark.parametrize("fp", CASES, ids=[os.path.basename(c)[8:-4] for c in CASES])
+def test_throughput_mode_diagnostic_ledger(fp):
+    """gemm_mode="f16" (ONE f16 MFMA per product, fp32 statistics) is a diagnostic, not the product: this
+    records how far it lands from the reference's vectors on every fixture (max-abs logit error, pixel flips, arg-max
+    objectness, IoU of the thresholded last-layer masks to 3 d.p.) and asserts only that it is sane (finite, an f16-sized
+    error - well outside the 1e-4 gate - and mostly the same masks)."""
+    g = np.load(fp)
+    patch, B, Hh, Ww, wseed, xseed, _ = [int(v) for v in g["meta"]]
+    m = _model(patch, wseed, str(g["style"]), "f16")
+    x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww))).to(DEV)
+    out = m(x, return_logits=True)
+    logits = out["mask_logits"][:, -1].cpu().numpy()
+    assert np.isfinite(logits).all()
+    scale = float(g["logit_absmax"])
+    d32 = float(np.abs(logits - g["logits_last"]).max())
+    ref_bin = g["logits_last"] >= 0
+    got_bin = logits >= 0
+    flips = float((got_bin != ref_bin).mean())
+    inter = (got_bin & ref_bin).sum(axis=(-1, -2)).astype(np.float64)
+    union = (got_bin | ref_bin).sum(axis=(-1, -2)).astype(np.float64)
+    iou = float(np.where(union > 0, inter / np.maximum(union, 1), 1.0).mean())  # f16 masks vs the reference's masks
+    obj_ref, obj = g["objectness"][:, -1, :, 0], out["objectness"][:, -1, :, 0].cpu().numpy()
+    ledger.record("throughput_mode_f16", os.path.basename(fp)[8:-4], {
+        "logit_absmax": scale, "hip_minus_ref32": d32, "pixel_flips": flips, "mask_iou_vs_reference": round(iou, 4),
+        "mask_iou_is_1_to_3dp": round(iou, 3) == 1.0, "argmax_objectness_equal": bool((obj.argmax(1) == obj_ref.argmax(1)).all()),
+        "objectness_maxabs": float(np.abs(obj - obj_ref).max()), "rule": "diagnostic: recorded, not gated"})
+    print(f"\n[f16 throughput mode] {os.path.basename(fp)}: |logit|max={scale:.1f} hip-ref32={d32:.2e} flips={flips:.2e} iou={iou:.4f}")
+    assert 1e-4 < d32 <= 0.05 * max(scale, 16.0), d32   # an f16-sized error: not the fp32-grade path, not garbage
+    assert flips <= 2e-2 and iou >= 0.95
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_forward_vs_oracle_batch8_and_fp64_truth(mode):
     """Larger seeded batch through the oracle on this box's CPU (fp32 + fp64), strict 1e-4 on a calib checkpoint."""
