@@ -151,37 +151,88 @@ def cpu_baseline(P, S, budget_s=7.0, legs=("step", "forward", "one_thread", "bat
     return res
 
 
-def end_to_end(model, dev, P, S, B, streams, n_images=768):
+def end_to_end(model, dev, P, S, B, streams, n_images=768, world=1, rank=0):
     """The real Evaluator over a generated DUTS-layout tree of JPEG / PNG files (300-400 px): decode on the
-    host pool, resize + normalise + forward + metrics on the device."""
+    host worker processes, resize + normalise + forward + metrics on the device.  With several ranks the tree holds
+    n_images x world files, the Evaluator shards them (one RCCL all-gather of the result rows) and every rank decodes its
+    share on its own block of host cores."""
     import shutil
     import tempfile
     from selfmask_amd import datasets as DS
+    from selfmask_amd.decode_pool import default_workers
     from selfmask_amd.evaluator import Evaluator
-    root = tempfile.mkdtemp(prefix="sm_bench_ds_")
+    n_images *= world
+    box = [tempfile.mkdtemp(prefix="sm_bench_ds_") if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    root = box[0]
     try:
-        DS.write_synthetic_dataset(root, "duts", n_images, seed=7)
+        if rank == 0:
+            DS.write_synthetic_dataset(root, "duts", n_images, seed=7)
+        if world > 1:
+            dist.barrier()
         ev = Evaluator(network=model, dir_dataset=root)
         ev.device = dev
         ev("duts", dir_ckpt=os.path.join(root, "ckpt"), img_size=S, batch_size=B, device=dev, streams=streams)  # warm: page cache, graphs
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         res = ev("duts", dir_ckpt=os.path.join(root, "ckpt"), img_size=S, batch_size=B, device=dev, streams=streams)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # the host part alone: decode of the same files on the same pool, nothing else
+        # the host part alone: decode of this rank's files on the same pool, nothing else
+        from selfmask_amd.distributed import shard_indices
         from selfmask_amd.pipeline import PrefetchingLoader
         ds = DS.get_dataset(root, "duts", eval_img_size=S)
+        mine = shard_indices(len(ds), rank, world)
         t1 = time.perf_counter()
-        for _ in PrefetchingLoader(ds, range(len(ds)), B, depth=streams + 1):
+        for _ in PrefetchingLoader(ds, mine, B, depth=streams + 1):
             pass
         dt_dec = time.perf_counter() - t1
-        return {"end_to_end_images_per_sec": round(n_images / dt, 1), "images": n_images, "decode_workers": _cores(),
-                "host_decode_only_images_per_sec": round(n_images / dt_dec, 1), "iou": res["iou"],
-                "what": "Evaluator('duts', img_size=%d, batch_size=%d): JPEG/PNG decode on host threads, Pillow-exact resize + "
-                        "normalise + forward + metrics on the device" % (S, B)}
+        t1 = time.perf_counter()
+        for _ in PrefetchingLoader(ds, mine[:256], B, depth=streams + 1, decode="thread"):
+            pass
+        dt_thr = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt, dt_dec], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, dt_dec = t.tolist()
+        out = {"end_to_end_images_per_sec": round(n_images / dt, 1), "images": n_images, "ranks": world,
+               "decode_workers_per_rank": default_workers(), "decode": "worker processes + shared memory (decode_pool.py)",
+               "host_decode_only_images_per_sec": round(n_images / dt_dec, 1),
+               "host_decode_only_thread_pool_images_per_sec_per_rank": round(len(mine[:256]) / dt_thr, 1), "iou": res["iou"],
+               "what": "Evaluator('duts', img_size=%d, batch_size=%d): JPEG/PNG decode on host worker processes, Pillow-exact resize + "
+                       "normalise + forward + metrics on the device" % (S, B)}
+        if world > 1:
+            return out
+        # The reference's OWN operating point (evaluator.pyc@L373): native resolution.  Batch 1 as the reference runs it, and
+        # the same rows from token-grid buckets (images that pad to the same patch grid share a batch; bit-identical rows)
+        import numpy as np
+
+        def native(bs):
+            ev("duts", dir_ckpt=os.path.join(root, "ckpt_n"), batch_size=bs, device=dev, streams=streams)  # warm: graphs, page cache
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            ev("duts", dir_ckpt=os.path.join(root, "ckpt_n"), batch_size=bs, device=dev, streams=streams)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t, ev.last_rows.copy(), dict(ev.graph_stats)
+
+        t1, rows1, _ = native(1)
+        t16, rows16, g16 = native(16)
+        out["native_resolution"] = {
+            "images": n_images, "sizes": "300-400 px per side, uniformly random (49 token grids at patch %d)" % P,
+            "batch1_images_per_sec": round(n_images / t1, 1), "bucketed_batch16_images_per_sec": round(n_images / t16, 1),
+            "rows_bit_identical": bool(np.array_equal(rows1, rows16)), "hip_graph_bucketed": g16,
+            "what": "Evaluator('duts', img_size=None): batch_size=1 (the reference's mode: eager launches, one image per forward) vs "
+                    "batch_size=16 (token-grid buckets, zero-padded like make_input_divisible, graph replay per bucket shape); both "
+                    "include the host JPEG/PNG decode; the CPU oracle at batch 1 is cpu_baseline.forward_only_batch1_all_cores"}
+        return out
     finally:
-        shutil.rmtree(root, ignore_errors=True)
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
 
 
 def serving_latency(model, dev, n=200):
@@ -465,6 +516,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from selfmask_amd.distributed import pin_rank_cores
+        pin_rank_cores()  # this rank's block of the host's cores: its decode workers inherit the affinity
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
@@ -522,6 +575,9 @@ def main():
         sustained = {"steps": a.sustained_steps, "value": round(world * a.sustained_steps * B / ds_, 1), "unit": "images/sec",
                      "ms_per_step": round(ds_ / a.sustained_steps * 1e3, 3)}
 
+    # end to end (files -> metrics): every rank takes part (the Evaluator shards the files and gathers the rows over RCCL)
+    e2e = end_to_end(model, dev, P, S, B, len(ring.streams), world=world, rank=rank) if not a.quick else None
+
     if rank == 0:
         value = world * a.steps * B / dt
         flops_img = forward_flops_per_image(P, S)
@@ -570,8 +626,8 @@ def main():
             "roofline_other_kernels": {k: roofline_of(kern, model.gemm_mode, k) for k in list(kern)[1:]},
         }
         res["sustained"] = sustained
+        res["end_to_end"] = e2e
         if world == 1 and not a.quick:
-            res["end_to_end"] = end_to_end(model, dev, P, S, B, len(ring.streams))
             res["serving"] = serving_latency(model, dev)
             if model.gemm_mode == "w16" and not a.zero_data:
                 res["throughput_mode"] = throughput_mode_leg(dev, wl)

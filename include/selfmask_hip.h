@@ -247,6 +247,11 @@ int sm_preprocess_resize_u8(const uint8_t* in, const sm_pre_image* images, const
 /* native resolution (the reference's test mode): ToTensor + Normalize only; image b -> out + images[b].out_off as (3, H, W) */
 int sm_preprocess_normalize_u8(const uint8_t* in, const sm_pre_image* images, const float* lut, float* out, int32_t B,
                                int32_t max_pixels, void* stream);
+/* native resolution, images of ONE token grid batched: out (B, 3, Hp, Wp), image b in the top-left corner, zeros to the right and
+ * below - the tensor make_input_divisible (vision_transformer.py:260-267) builds from the normalised image, for every image of
+ * the batch at once (H <= Hp, W <= Wp; Hp, Wp = the sizes rounded up to the patch size) */
+int sm_preprocess_normalize_pad_u8(const uint8_t* in, const sm_pre_image* images, const float* lut, float* out, int32_t B,
+                                   int32_t Hp, int32_t Wp, void* stream);
 
 /* serving selection (SelfMaskInference.predict, app.py:266-284): best[b] = argmax_q objectness[b][q] (first maximum),
  * out[b] = clip(masks[b][best[b]], 0, 1); masks: image b, query q at + b*mask_stride_b + q*hw (the last decoder layer) */
@@ -273,7 +278,7 @@ typedef struct sm_eval_args {
     float* ious;                 /* out [B][nq] per-query IoU against the GT, or NULL                                 */
     void* workspace;             /* sm_evaluate_workspace_bytes(B, nq, mh, mw, max_pixels), 256-B aligned             */
     size_t workspace_bytes;
-    int32_t B, nq, mh, mw;       /* nq <= 32                                                                         */
+    int32_t B, nq, mh, mw;       /* nq <= SM_EVAL_MAX_QUERIES (960: passes of 32 queries), any mask width                 */
     int32_t max_pixels;          /* largest H*W among the batch's ground truths (<= 2048*2048): sizes the launch grid */
     float scale;                 /* > 0: reference mode F.interpolate(scale_factor=scale)[..., :H, :W]
                                     (evaluator.pyc@L209-211: 4 for ViT-S/8); 0: resize to (H, W) (batched mode)       */

@@ -57,6 +57,17 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_off) {
         : "memory");
 }
 
+// The same with a wave-uniform 64-bit base (SGPR pair) + a per-lane 32-bit byte offset: half the address registers of the
+// pointer form, and a K loop advances the scalar base instead of 64 per-lane pointers
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, unsigned voff, unsigned lds_off) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_off)
+        : "memory");
+}
+
 // Reductions across the 16-lane rows / the two halves of a wave by register swaps (gfx950 v_permlane16_swap / v_permlane32_swap)
 // instead of ds_bpermute round trips through the LDS: swapping a value with itself leaves rows {0,0,2,2} in one result and
 // {1,1,3,3} in the other (halves: {lo,lo} and {hi,hi}), so one max / add per step gives every lane the same reduced value,
@@ -82,6 +93,7 @@ __device__ __forceinline__ float rows4_sum(float x) {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The hi conversion goes through inline asm so that the value stored and the value subtracted are ONE conversion
 // result: left to itself hipcc emitted a packed round-toward-zero convert for a stored vector and a round-to-nearest
@@ -120,6 +132,26 @@ __device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo
     split4(b, h1, l1);
     hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
     lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// The same split from instructions the compiler models (v_cvt_pk_f16_f32 from the vector conversion, the lo half as
+// f16(fma(f32(hi), -2048, 2048 x)) - exact in f32, one rounding: the same bits as split2).  For results that feed an MFMA
+// straight from registers: hipcc neither schedules around nor pads the hazards of an `asm` statement's instructions (VALU
+// write -> MFMA operand read needs wait states, cdna_hip_programming.md 5.7 item 2), and with the attention step laid out
+// as one basic block the scheduler does place the P V MFMAs right behind the split (measured: 2^-11-sized errors).
+__device__ __forceinline__ void split2c(float x0, float x1, f16x2& hi, f16x2& lo) {
+    const f32x2 v = {x0, x1};
+    hi = __builtin_convertvector(v, f16x2);
+    f16x2 l;
+    l[0] = (_Float16)__builtin_fmaf((float)hi[0], -2048.0f, x0 * 2048.0f);
+    l[1] = (_Float16)__builtin_fmaf((float)hi[1], -2048.0f, x1 * 2048.0f);
+    lo = l;
+}
+__device__ __forceinline__ void split8c(const float (&x)[8], f16x8& hi, f16x8& lo) {
+    f16x2 h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2c(x[2 * i], x[2 * i + 1], h[i], l[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hi[2 * i] = h[i][0]; hi[2 * i + 1] = h[i][1]; lo[2 * i] = l[i][0]; lo[2 * i + 1] = l[i][1]; }
 }
 // byte offset of element k of an F16X2 row: hi half; the lo half lives 16 bytes further
 __device__ __forceinline__ int64_t f16x2_off(int64_t k) { return (k & ~(int64_t)7) * 4 + (k & 7) * 2; }
@@ -192,7 +224,6 @@ __device__ __forceinline__ float fast_erff(float x) {
 
 // The same erf on two values per instruction (v_pk_fma_f32 / v_pk_mul_f32: the fp32 vector rate doubles on packed
 // operands), same operations in the same order per element - bitwise the scalar function's results.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 fast_erff2(f32x2 x) {
     const f32x2 t = __builtin_elementwise_abs(x), s = x * x;
     f32x2 q = 7.882497448e-05f;

@@ -261,10 +261,15 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     const bool fused_qkv = c.W16 && fused_qkv_env != 0 && s.N <= sm_qkv_attention_max_tokens();
     LnOpt xs;
     xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
+#ifdef SM_TUNING  // timing-only ablation (tuning build): what the 24 encoder LayerNorm launches cost the pipeline (results are garbage)
+    static const int ablate_ln = getenv("SM_ABLATE_LN") ? atoi(getenv("SM_ABLATE_LN")) : 0;
+#else
+    constexpr int ablate_ln = 0;
+#endif
     if (fuse_fc2) TRY(ln(c, ws.X, w->enc[0].norm1_w, w->enc[0].norm1_b, nullptr, s.M, 1e-6f, xs));
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
-        if (!fuse_fc2) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        if (!fuse_fc2 && !(ablate_ln && i > 0)) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         if (fused_qkv) {
             sm_qkv_attn_args q = {};
             q.Xn = ws.Xn; q.Wqkv = e.qkv_w; q.bias = e.qkv_b; q.O = ws.AO; q.ldx = D; q.ldo = D;
@@ -286,7 +291,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
             TRY(linear_residual_ln(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, s.M, D, e.norm2_w, e.norm2_b, 1e-6f, ws.Xn));
         } else {
             TRY(linear(c, ws.AO, D, e.proj_w, e.proj_s, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
-            TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+            if (!ablate_ln) TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         }
         TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_s, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
         if (fuse_fc2 && i + 1 < SM_ENC_DEPTH) {

@@ -342,9 +342,6 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
 // (row >> 1) & 1 - conflict-free for all four lane groups and both halves (brute-forced over the 4^8 x 2^8 layouts of this
 // family).  The LDS-DMA destination is linear, so the permutation goes on the per-lane SOURCE address, as before.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-#ifndef SM_DMA_SPREAD
-#define SM_DMA_SPREAD 0
-#endif
 
 
 #ifdef SM_TUNING  // in-kernel stamps (tuning build only; a buffer nothing else reads): prologue / K loop / epilogue of a tile
@@ -373,13 +370,23 @@ __device__ int g_gemm_stamp_filter[3];  // (N, K, M) of the launches that stamp;
 // TERMS = 3: the fp32-grade product (wh*ah + wl*ah + whs*al').  TERMS = 1: "throughput mode"  - only wh*ah,
 // plain f16 operands with fp32 accumulation: a DIAGNOSTIC of what the kernel structure reaches without the x3, never the
 // metric (the results miss the 1e-4 gate by two orders of magnitude).  Same operand formats: the lo halves are staged and ignored.
+// Ring feed.  Source addresses are a wave-uniform base (advanced per K-tile by scalar adds) + one 32-bit per-lane offset per
+// piece.  SM_GEMM_LOADH=1 (experiment build, round 3): only the first half of the waves - the older wave(s) of every SIMD - issue
+// the LDS-DMA pieces (twice as many each) so that the younger ones start their MFMAs at once.  It took 11 % off the fused
+// QKV kernel's projection loop (qkv_attention.hip, shipped there) but nothing off these GEMMs: K loop of the 256 x 128 fc2 tile
+// 102.5k cycles against 97.4k, pipeline 21.75k vs 21.75k images/s (profiles/r03_loader_half_ab.log) - four waves per SIMD
+// already cover each other's issue time.  Default off.
+#ifndef SM_GEMM_LOADH
+#define SM_GEMM_LOADH 0
+#endif
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS, int TERMS = 3>
 __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gemm_args g) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 16, TN = WTN / 16;       // 16x16 tiles per wave
     constexpr int ROWB = 128;
-    constexpr int A_INST = BM / 8 / NW, W_INST = BN / 8 / NW;
-    static_assert(A_INST * 8 * NW == BM && W_INST * 8 * NW == BN && TM * 16 * NWM == BM && TN * 16 * NWN == BN && (TM % 2) == 0, "tile split");
+    constexpr int NL = (SM_GEMM_LOADH && NW >= 8) ? NW / 2 : NW;   // waves that feed the ring
+    constexpr int A_INST = BM / 8 / NL, W_INST = BN / 8 / NL;
+    static_assert(A_INST * 8 * NL == BM && W_INST * 8 * NL == BN && TM * 16 * NWM == BM && TN * 16 * NWN == BN && (TM % 2) == 0, "tile split");
     constexpr int NI = A_INST + W_INST;
     constexpr int A_STAGE = BM * ROWB, W_STAGE = BN * ROWB, W_RING = NST * A_STAGE, RING_BYTES = NST * (A_STAGE + W_STAGE);
     extern __shared__ __attribute__((aligned(16))) char smemm[];
@@ -402,45 +409,37 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
     const char* W = reinterpret_cast<const char*>(g.W + k_begin);
     // DMA: lane -> (row = lane >> 3 of its 8-row piece, slot p = lane & 7); the slot holds chunk (2 kg + x) with
     // kg = ((p >> 1) + 2 * ((row >> 3) & 1)) & 3 (the pair rotation is its own inverse), x = (p & 1) ^ ((row >> 1) & 1)
-    const char* a_src[A_INST];
-    const char* w_src[W_INST];
+    const bool loader = wave < NL;
+    const int lw = loader ? wave : 0;  // (the offsets of a non-loader are never used)
+    unsigned a_off[A_INST], w_off[W_INST];  // byte offsets from A / W (the host checks that M lda 4 and N ldw 4 fit in 32 bits)
     auto src_chunk = [&](int row) { return m16_chunk_of_slot(row, lane & 7); };
 #pragma unroll
     for (int i = 0; i < A_INST; ++i) {
-        const int row = (wave * A_INST + i) * 8 + (lane >> 3);
+        const int row = (lw * A_INST + i) * 8 + (lane >> 3);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        a_src[i] = A + ((int64_t)gm * g.lda) * 4 + src_chunk(row) * 16;
+        a_off[i] = (unsigned)gm * (unsigned)g.lda * 4u + src_chunk(row) * 16;
     }
 #pragma unroll
     for (int i = 0; i < W_INST; ++i) {
-        const int row = (wave * W_INST + i) * 8 + (lane >> 3);
+        const int row = (lw * W_INST + i) * 8 + (lane >> 3);
         int gn = n0 + row;
         gn = gn < N ? gn : N - 1;
-        w_src[i] = W + ((int64_t)gn * g.ldw) * 4 + src_chunk(row) * 16;
+        w_off[i] = (unsigned)gn * (unsigned)g.ldw * 4u + src_chunk(row) * 16;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smemm;
     auto issue_step = [&](int kt) {
+        if (!loader) return;  // wave-uniform; a non-loader has no piece in flight, its vmcnt waits pass at once
         const int t = kt + NST - 1;
         const int tt = t < nk ? t : nk - 1, slot = t % NST;
+        const char* wb = W + tt * ROWB;  // scalar: the K-tile's column block of both operands
+        const char* ab = A + tt * ROWB;
         const unsigned sw = __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + wave * W_INST * 1024);
 #pragma unroll
-        for (int i = 0; i < W_INST; ++i) lds_dma16(w_src[i] + tt * ROWB, sw + i * 1024);
+        for (int i = 0; i < W_INST; ++i) lds_dma16_s(wb, w_off[i], sw + i * 1024);
         const unsigned sa = __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + wave * A_INST * 1024);
 #pragma unroll
-        for (int i = 0; i < A_INST; ++i) lds_dma16(a_src[i] + tt * ROWB, sa + i * 1024);
-    };
-    // piece p (W pieces first, then A pieces) of the K-tile NST-1 ahead of kt.  In the K loop the pieces are issued BETWEEN the
-    // MFMA blocks instead of in front of them: every wave of the workgroup leaves the barrier at the same moment, and an LDS-DMA
-    // costs its wave 60-180 cycles of issue - with all waves of a SIMD issuing their pieces together the matrix pipe idled for
-    // that long at the top of every K-tile (fused kernel: 26 % of its projection loop, the 256-row GEMMs 10 %)
-    auto issue_piece = [&](int kt, int p) {
-        const int t = kt + NST - 1;
-        const int tt = t < nk ? t : nk - 1, slot = t % NST;
-        if (p < W_INST)
-            lds_dma16(w_src[p] + tt * ROWB, __builtin_amdgcn_readfirstlane(lds_base + W_RING + slot * W_STAGE + (wave * W_INST + p) * 1024));
-        else
-            lds_dma16(a_src[p - W_INST] + tt * ROWB, __builtin_amdgcn_readfirstlane(lds_base + slot * A_STAGE + (wave * A_INST + p - W_INST) * 1024));
+        for (int i = 0; i < A_INST; ++i) lds_dma16_s(ab, a_off[i], sa + i * 1024);
     };
     // fragment offsets: tile rows are multiples of 16, so the slot of (row = base + r16, kg) does not depend on the tile
     const int off_hi = r16 * ROWB + m16_slot(r16, kg, 0) * 16, off_lo = r16 * ROWB + m16_slot(r16, kg, 1) * 16;
@@ -464,9 +463,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) GEMM_STAMP(1);
-        constexpr int NBLK = (TM / (TM > 4 ? 4 : TM)) * TN;           // MFMA blocks per K-tile: (A-fragment block, weight tile)
-        constexpr int PPB = (NI + NBLK - 1) / NBLK;                   // pieces issued behind each block
-        if constexpr (!SM_DMA_SPREAD) issue_step(kt);
+        issue_step(kt);
         const char* sta = smemm + (kt % NST) * A_STAGE + a_base;
         const char* stw = smemm + W_RING + (kt % NST) * W_STAGE + w_base;
         // Register plan: the W fragments of the step stay live (TN x 12 registers), the A fragments come in blocks of at most
@@ -500,14 +497,6 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                         acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[j], ah[ii], acc[i0 + ii][j], 0, 0, 0);
                         acc[i0 + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(whs[j], al[ii], acc[i0 + ii][j], 0, 0, 0);
                     }
-                }
-                if constexpr (SM_DMA_SPREAD) {
-                    const int blk = (i0 / IB) * TN + j;
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int q = 0; q < PPB; ++q)
-                        if (blk * PPB + q < NI) issue_piece(kt, blk * PPB + q);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -981,6 +970,8 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
                    g->epilogue == SM_EPI_RESIDUAL || g->epilogue == SM_EPI_PATCH, "sm_gemm_w16: unsupported epilogue");
     int ex = 0;
     SM_REQUIRE(g->w_scale > 0.f && frexpf(g->w_scale, &ex) == 0.5f, "sm_gemm_w16: w_scale must be the weight tensor's 2^-s");
+    SM_REQUIRE((uint64_t)g->M * (uint64_t)g->lda * 4 < (1ull << 32) && (uint64_t)g->N * (uint64_t)g->ldw * 4 < (1ull << 32),
+               "sm_gemm_w16: operands beyond 4 GiB (the ring's source addresses are 32-bit offsets from A / W)");
     SM_REQUIRE(g->mfma_terms == 0 || g->mfma_terms == 3 || (g->mfma_terms == 1 && variant >= 40 && variant < 50),
                "sm_gemm_w16: mfma_terms must be 0/3 (fp32-grade) or 1 (throughput mode, 16x16x32 kernels only)");
     if (out_f16x2)

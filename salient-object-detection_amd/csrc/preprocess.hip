@@ -96,6 +96,32 @@ __global__ __launch_bounds__(256) void pp_normalize_kernel(const unsigned char* 
     }
 }
 
+// native resolution, batched by token grid: images whose sizes round up to the same (Hp, Wp) patch multiple share one batch
+// (B, 3, Hp, Wp).  Rows / columns beyond an image's own size hold 0 - exactly what make_input_divisible pads the NORMALISED
+// tensor with (vision_transformer.py:260-267: F.pad(x, ..., value=0) on the right and bottom), so image b of the batch is
+// bit for bit the tensor the reference's batch-1 forward builds for it.
+__global__ __launch_bounds__(256) void pp_normalize_pad_kernel(const unsigned char* __restrict__ in, const sm_pre_image* __restrict__ imgs,
+                                                              const float* __restrict__ lut, float* __restrict__ out, int Hp, int Wp) {
+    __shared__ float slut[768];
+    for (int i = threadIdx.x; i < 768; i += 256) slut[i] = lut[i];
+    __syncthreads();
+    const sm_pre_image im = imgs[blockIdx.y];
+    const int64_t plane = (int64_t)Hp * Wp;
+    const unsigned char* src = in + im.off;
+    float* o = out + (int64_t)blockIdx.y * 3 * plane;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < plane; p += (int64_t)gridDim.x * 256) {
+        const int y = (int)(p / Wp), x = (int)(p - (int64_t)y * Wp);
+        float r = 0.f, g = 0.f, b = 0.f;
+        if (y < im.H && x < im.W) {
+            const unsigned char* q = src + ((int64_t)y * im.W + x) * 3;
+            r = slut[q[0]]; g = slut[256 + q[1]]; b = slut[512 + q[2]];
+        }
+        o[p] = r;
+        o[plane + p] = g;
+        o[2 * plane + p] = b;
+    }
+}
+
 }  // namespace sm
 
 extern "C" int sm_preprocess_resize_u8(const uint8_t* in, const sm_pre_image* images, const int32_t* coef, const float* lut,
@@ -117,4 +143,13 @@ extern "C" int sm_preprocess_normalize_u8(const uint8_t* in, const sm_pre_image*
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(sm::pp_normalize_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, in, images, lut, out);
     return sm::check_launch("sm_preprocess_normalize_u8");
+}
+
+extern "C" int sm_preprocess_normalize_pad_u8(const uint8_t* in, const sm_pre_image* images, const float* lut, float* out, int32_t B,
+                                              int32_t Hp, int32_t Wp, void* stream) {
+    SM_REQUIRE(in && images && lut && out && B > 0 && Hp > 0 && Wp > 0, "sm_preprocess_normalize_pad_u8: bad arguments");
+    int64_t gx = ((int64_t)Hp * Wp + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(sm::pp_normalize_pad_kernel, dim3((int)gx, B), dim3(256), 0, (hipStream_t)stream, in, images, lut, out, Hp, Wp);
+    return sm::check_launch("sm_preprocess_normalize_pad_u8");
 }

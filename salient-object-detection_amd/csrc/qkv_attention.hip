@@ -581,9 +581,14 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         };
         f32x4q sc[2][2], sn[2][2];
         scores(0, sc);
-        for (int stp = 0; stp < nsteps; ++stp) {
-            if (stp + 1 < nsteps) scores(stp + 1, sn);
-            if (stp == nsteps - 1) {  // only the last step can hold keys >= N (K rows 197..223 repeat the last token)
+        // One step = softmax + P V of 32 keys.  Layout of the body (round 3): the running-maximum test of BOTH query tiles comes
+        // first and the (rare) rescale sits behind ONE wave-uniform branch, so that everything after it - the scores of the NEXT
+        // step (MFMA, independent of this step's softmax), the exponentials / hi-lo split (VALU) and P V (MFMA) - is a single
+        // basic block the scheduler can interleave.  Before, the scores were issued at the top of the body and two branches
+        // stood between them and the softmax: the wave ran 24 MFMAs, then ~170 VALU instructions, then 24 MFMAs, each alone.
+        auto step = [&](int stp, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            if constexpr (LAST) {  // only the last step can hold keys >= N (K rows 197..223 repeat the last token)
     #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
     #pragma unroll
@@ -592,26 +597,38 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                         for (int v = 0; v < 4; ++v)
                             if (stp * 32 + kt * 16 + 4 * kg + v >= N) sc[kt][t][v] = -INFINITY;
             }
-            f16x8 ph[2], pl[2];
+            const float lim = 8.0f / cs;  // lazy running maximum: p <= 2^8 between moves
+            float cmax[2];
+            bool move = false;
     #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                float cmax = -INFINITY;
+                float c = -INFINITY;
     #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
     #pragma unroll
-                    for (int v = 0; v < 4; ++v) cmax = fmaxf(cmax, sc[kt][t][v]);
-                cmax = rows4_max(cmax);
-                const float lim = 8.0f / cs;  // lazy running maximum: p <= 2^8 between moves
-                if (__builtin_amdgcn_ballot_w64(cmax > m_run[t] + lim) != 0) {
-                    const float m_new = fmaxf(m_run[t], cmax);
-                    const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * cs);
-                    m_run[t] = m_new;
-                    l_run[t] *= alpha;
+                    for (int v = 0; v < 4; ++v) c = fmaxf(c, sc[kt][t][v]);
+                cmax[t] = rows4_max(c);
+                move = move || cmax[t] > m_run[t] + lim;
+            }
+            if (__builtin_amdgcn_ballot_w64(move) != 0) {
     #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt)
+                for (int t = 0; t < NT; ++t) {
+                    if (__builtin_amdgcn_ballot_w64(cmax[t] > m_run[t] + lim) != 0) {
+                        const float m_new = fmaxf(m_run[t], cmax[t]);
+                        const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * cs);
+                        m_run[t] = m_new;
+                        l_run[t] *= alpha;
     #pragma unroll
-                        for (int v = 0; v < 4; ++v) { om[dt][t][v] *= alpha; oc[dt][t][v] *= alpha; }
+                        for (int dt = 0; dt < 4; ++dt)
+    #pragma unroll
+                            for (int v = 0; v < 4; ++v) { om[dt][t][v] *= alpha; oc[dt][t][v] *= alpha; }
+                    }
                 }
+            }
+            if constexpr (!LAST) scores(stp + 1, sn);
+            f16x8 ph[2], pl[2];
+    #pragma unroll
+            for (int t = 0; t < NT; ++t) {
                 const float moff = -m_run[t] * cs;
                 float psum = 0.f, pf[8];
                 const f32x4q e0 = sc[0][t] * cs + moff, e1 = sc[1][t] * cs + moff;  // packed fma
@@ -620,7 +637,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                     pf[j] = __builtin_amdgcn_exp2f(j < 4 ? e0[j & 3] : e1[j & 3]);
                     psum += pf[j];
                 }
-                split8(pf, ph[t], pl[t]);
+                split8c(pf, ph[t], pl[t]);  // compiler-visible: P feeds the MFMAs below straight from registers
                 l_run[t] += psum;
             }
     #pragma unroll
@@ -638,11 +655,15 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
                     }
                 }
             }
+            if constexpr (!LAST) {
     #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
     #pragma unroll
-                for (int t = 0; t < NT; ++t) sc[kt][t] = sn[kt][t];
-        }
+                    for (int t = 0; t < NT; ++t) sc[kt][t] = sn[kt][t];
+            }
+        };
+        for (int stp = 0; stp + 1 < nsteps; ++stp) step(stp, std::false_type{});
+        step(nsteps - 1, std::true_type{});
 
         QKV_STAMP(5);
     #pragma unroll
@@ -673,12 +694,12 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
 
 }  // namespace sm
 
-// kernel selection: tuning knob (same results up to summation order).  SM_QKV_RING = "m16x2" (default: the 16x16x32-MFMA
-// kernel, 32-k stages, ring of two) | "m16x3" | "32x2" | "32x3" | "16x2" | "16x6" (the 32x32x16-MFMA kernel, "<k per stage>x<stages>")
+// kernel selection: tuning knob (same results up to summation order).  SM_QKV_RING = "m16x2L4" (default: the 16x16x32-MFMA
+// kernel, 32-k stages, ring of two, waves 0-3 feed the ring) | "m16x2" (every wave feeds it: round 2) | "m16x3L4" | "m16x3" | "32x2" | "32x3" | "16x2" | "16x6" (the 32x32x16-MFMA kernel, "<k per stage>x<stages>")
 static int qkv_mode() {
     static const char* ring = getenv("SM_QKV_RING");
-    return !ring ? 4 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : !strcmp(ring, "32x2") ? 0 :
-           !strcmp(ring, "m16x3") ? 5 : !strcmp(ring, "m16x2L4") ? 6 : !strcmp(ring, "m16x3L4") ? 7 : 4;
+    return !ring ? 6 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : !strcmp(ring, "32x2") ? 0 :
+           !strcmp(ring, "m16x3") ? 5 : !strcmp(ring, "m16x2") ? 4 : !strcmp(ring, "m16x3L4") ? 7 : 6;
 }
 // name rocprofv3 reports for the selected kernel (labels the in-situ taps of forward.hip)
 const char* sm_qkv_attention_kernel_name() {

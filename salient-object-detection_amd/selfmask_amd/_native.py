@@ -148,6 +148,7 @@ SYMBOLS = {
     "sm_upsample_selected_f64": (C.c_int, [fp, C.c_int64, fp, C.c_int32, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_mask_u8_to_f32": (C.c_int, [fp, fp, C.c_int64, fp]),
     "sm_preprocess_normalize_u8": (C.c_int, [fp, fp, fp, fp, C.c_int32, C.c_int32, fp]),
+    "sm_preprocess_normalize_pad_u8": (C.c_int, [fp, fp, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_pick_mask_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_vote_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sm_vote_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),

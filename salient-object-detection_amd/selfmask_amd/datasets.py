@@ -40,6 +40,13 @@ class SaliencyTestDataset:
     def __len__(self) -> int:
         return len(self.p_imgs)
 
+    def image_size(self, ind: int) -> Tuple[int, int]:
+        """(H, W) from the file header only (PIL opens lazily): the native-resolution evaluator plans its token-grid buckets
+        from these before anything is decoded."""
+        with Image.open(self.p_imgs[ind]) as im:
+            w, h = im.size
+        return h, w
+
     def __getitem__(self, ind: int) -> dict:
         image = Image.open(self.p_imgs[ind]).convert("RGB")
         if self.img_size is not None:

@@ -1,0 +1,158 @@
+"""A pool of decode worker PROCESSES writing straight into shared memory (why processes: sm_decode_worker.py).
+
+``DecodePool(n)`` starts ``n`` children (``python sm_decode_worker.py``: numpy + Pillow only, no torch, no GPU - started with
+``subprocess``, never forked from this process, which may already hold a HIP context).  ``BatchSlots`` is a ring of shared
+segments (files under /dev/shm), one per batch in flight; sample i of a batch owns a fixed window of its slot, so a worker needs
+no coordination to write its pixels.  ``decode_batch(slot, paths)`` returns zero-copy numpy views of the decoded images and
+ground truths inside the slot - exactly what ``pipeline.pack_images`` / ``pack_gts`` take - valid until the slot is reused.
+
+A sample larger than its window (``max_side``) is decoded in-process instead (rare; same function, same bytes).
+"""
+import os
+import queue
+import subprocess
+import sys
+import threading
+import uuid
+from concurrent.futures import Future
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_WORKER = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sm_decode_worker.py"))
+
+
+def default_workers() -> int:
+    """Cores this rank may use for decoding: its CPU affinity divided among the ranks of the node (LOCAL_WORLD_SIZE), one
+    left for the main thread; at most 32."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 4
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    if os.environ.get("SM_RANK_CORES_PINNED") == "1":  # distributed.pin_rank_cores already narrowed the affinity to this rank
+        local_world = 1
+    return max(1, min(32, n // local_world - (1 if n // local_world > 2 else 0)))
+
+
+class BatchSlots:
+    """``n_slots`` shared segments of ``batch`` windows each: [rgb: max_side^2 * 3 bytes | gt: max_side^2 bytes] per sample."""
+
+    def __init__(self, n_slots: int, batch: int, max_side: int = 640):
+        self.batch, self.rgb_cap, self.gt_cap = batch, max_side * max_side * 3, max_side * max_side
+        self.stride = self.rgb_cap + self.gt_cap
+        self.files, self.maps = [], []
+        tag = uuid.uuid4().hex[:12]
+        import mmap
+        for k in range(n_slots):
+            path = f"/dev/shm/sm_decode_{os.getpid()}_{tag}_{k}"
+            with open(path, "w+b") as f:
+                f.truncate(self.stride * batch)  # sparse: pages materialise as the workers write them
+                self.maps.append(mmap.mmap(f.fileno(), 0))
+            self.files.append(path)
+
+    def close(self) -> None:
+        for p in self.files:
+            try:
+                os.unlink(p)  # the mappings of views still alive stay valid; the memory goes when they do
+            except OSError:
+                pass
+        self.files = []
+
+    def __del__(self):
+        self.close()
+
+
+class DecodePool:
+    def __init__(self, workers: Optional[int] = None):
+        self.n = workers or default_workers()
+        self._q: "queue.Queue" = queue.Queue()
+        self._procs, self._threads = [], []
+        self._closed = False
+        env = dict(os.environ)
+        env["OMP_NUM_THREADS"] = "1"
+        for _ in range(self.n):
+            p = subprocess.Popen([sys.executable, "-u", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                 bufsize=1, env=env, close_fds=True)
+            t = threading.Thread(target=self._feed, args=(p,), daemon=True)
+            t.start()
+            self._procs.append(p)
+            self._threads.append(t)
+
+    def _feed(self, p) -> None:
+        """One thread per worker: blocked on the queue or on the worker's pipe, i.e. outside the GIL almost always."""
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            lines, fut = item  # a chunk of samples: one write, then one reply line per sample
+            try:
+                p.stdin.write("".join(lines))
+                p.stdin.flush()
+                replies = []
+                for _ in lines:
+                    reply = p.stdout.readline()
+                    if not reply:
+                        raise RuntimeError("decode worker exited")
+                    replies.append(reply.rstrip("\n").split("\t"))
+                fut.set_result(replies)
+            except Exception as e:  # noqa: BLE001
+                fut.set_exception(e)
+
+    def decode_batch(self, slots: BatchSlots, slot: int, paths: Sequence[Tuple[str, Optional[str]]]):
+        """Decode ``paths`` = [(image path, GT path or None)] into windows 0.. of ``slots`` segment ``slot``.  Returns a Future-like
+        callable: call it to wait and get (list of rgb views (H, W, 3), list of GT views (H, W) or None)."""
+        assert len(paths) <= slots.batch and not self._closed
+        # chunks of consecutive samples, about two per worker and batch: the per-message cost (queue, pipe, thread wake-up) is
+        # paid per chunk, and the chunks still balance the workers
+        chunk = max(1, -(-len(paths) // (2 * self.n)))
+        futs: List[Future] = []
+        for c0 in range(0, len(paths), chunk):
+            lines = []
+            for i in range(c0, min(c0 + chunk, len(paths))):
+                pi, pg = paths[i]
+                ro = i * slots.stride
+                lines.append(f"{pi}\t{pg or '-'}\t{slots.files[slot]}\t{ro}\t{slots.rgb_cap}\t{ro + slots.rgb_cap}\t{slots.gt_cap}\n")
+            f: Future = Future()
+            self._q.put((lines, f))
+            futs.append(f)
+        mm = slots.maps[slot]
+
+        def result():
+            rgbs, gts = [], []
+            replies = [r for f in futs for r in f.result()]
+            for i, r in enumerate(replies):
+                if r[0] == "err":
+                    raise RuntimeError(f"decode worker: {r[1]} ({paths[i][0]})")
+                h, w, gh, gw = (int(v) for v in r[1:5])
+                if r[0] == "big":  # beyond the window: decode here (same function)
+                    from sm_decode_worker import decode_item
+                    rgb, m = decode_item(*paths[i])
+                else:
+                    ro = i * slots.stride
+                    rgb = np.frombuffer(mm, np.uint8, h * w * 3, ro).reshape(h, w, 3)
+                    m = np.frombuffer(mm, np.uint8, gh * gw, ro + slots.rgb_cap).reshape(gh, gw) if paths[i][1] else None
+                rgbs.append(rgb)
+                gts.append(m)
+            return rgbs, gts
+        return result
+
+    def close(self) -> None:
+        if self._closed:
+            return
+        self._closed = True
+        for _ in self._threads:
+            self._q.put(None)
+        for p in self._procs:
+            try:
+                p.stdin.close()
+            except OSError:
+                pass
+        for p in self._procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    def __del__(self):
+        self.close()

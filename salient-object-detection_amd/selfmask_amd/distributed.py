@@ -12,6 +12,32 @@ HEADER = ("iou,pixel_acc,f_score,f_max,f_mean,mae,s_measure,miou_ub,pixel_acc_ub
 KEYS = ("iou", "pixel_accuarcy", "f_score", "f_max", "f_mean", "mae", "s_measure")  # dict keys, evaluator.pyc@L294-308
 
 
+def rank_cores(local_rank: int, local_world: int, cores: Sequence[int]) -> List[int]:
+    """This rank's share of the node's cores: a contiguous block (neighbouring cores share caches / a NUMA node)."""
+    cores = sorted(cores)
+    per = max(1, len(cores) // max(1, local_world))
+    lo = min(local_rank * per, max(0, len(cores) - per))
+    return cores[lo:lo + per]
+
+
+def pin_rank_cores() -> List[int]:
+    """One process per GPU, eight of them on one host: give each rank its own block of the host's cores (its decode workers
+    inherit it) instead of 8 x N threads fighting over all of them.  Reads LOCAL_RANK / LOCAL_WORLD_SIZE (torch.distributed.run);
+    a no-op for a single rank.  Sets SM_RANK_CORES_PINNED so that decode_pool.default_workers does not divide again."""
+    import os
+    lw, lr = int(os.environ.get("LOCAL_WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        cur = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    if lw <= 1 or os.environ.get("SM_RANK_CORES_PINNED") == "1":
+        return cur
+    mine = rank_cores(lr, lw, cur)
+    os.sched_setaffinity(0, mine)
+    os.environ["SM_RANK_CORES_PINNED"] = "1"
+    return mine
+
+
 def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_items, world_size))
 

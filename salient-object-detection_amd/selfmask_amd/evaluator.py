@@ -57,8 +57,15 @@ class Evaluator(BaseStructure):
             mine = mine[:batch_size]
         patch = self.model.encoder.patch_size
         scale = 0.0 if img_size is not None else float(patch // scale_factor)
-        if img_size is None and batch_size != 1:
-            raise ValueError("native-resolution evaluation runs at batch_size=1 (images differ in size)")
+        # Native resolution (the reference's own operating point, evaluator.pyc@L373: batch 1).  batch_size > 1 here batches the
+        # images whose sizes pad to the SAME patch grid (pipeline.native_buckets): each image sits zero-padded in the top-left
+        # corner of a (B, 3, gh P, gw P) batch - exactly the tensor make_input_divisible builds for it alone - and the forward
+        # is batch-invariant bit for bit, so every result row equals the batch-1 row.
+        bucketed = img_size is None and batch_size > 1
+        plan = None
+        if bucketed:
+            from .pipeline import native_buckets
+            plan = native_buckets([dataset.image_size(i) for i in mine], patch, batch_size)  # positions into `mine`
         if refine not in (None, "bilateral"):
             raise ValueError(f"refine={refine!r}: None or 'bilateral'")
         if refine and (img_size is None or input_pipeline != "device"):
@@ -66,14 +73,33 @@ class Evaluator(BaseStructure):
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
         rows_refined = torch.empty((len(mine), 16), dtype=torch.float32, device=device) if refine else None
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
-        # recurring batch shapes replay one captured hipGraph per stream instead of 171 launches (graphs.py)
+        # recurring batch shapes replay one captured hipGraph per stream instead of ~150 launches (graphs.py)
         # native-resolution mode meets a new shape with almost every image: graphs would only thrash there
-        self._graphed = GraphedForward(self.model, enabled=hip_graph and img_size is not None and
-                                       isinstance(self.model, torch.nn.Module))
+        self._graphed = GraphedForward(self.model, enabled=hip_graph and (img_size is not None or bucketed) and
+                                       isinstance(self.model, torch.nn.Module), max_graphs=24 if bucketed else 8)
         assert input_pipeline in ("device", "host"), input_pipeline
 
+        def padded(shapes):
+            return (-(-max(h for h, _ in shapes) // patch) * patch, -(-max(w for _, w in shapes) // patch) * patch)
+
         def batches():
-            if input_pipeline == "host":
+            if bucketed and input_pipeline == "host":
+                for pos in plan:
+                    items = [dataset[mine[p]] for p in pos]
+                    Hp, Wp = padded([tuple(it["x"].shape[-2:]) for it in items])
+                    xs = [torch.nn.functional.pad(it["x"], (0, Wp - it["x"].shape[-1], 0, Hp - it["x"].shape[-2])) for it in items]
+                    yield pos, torch.stack(xs), [it["m"].squeeze() for it in items]
+            elif bucketed:
+                from .pipeline import PrefetchingLoader, preprocess_on_device
+                from .decode_pool import default_workers
+                avg = max(1, len(mine) // max(1, len(plan)))  # buckets are often smaller than batch_size
+                depth = max(len(ring.streams) + 1, -(-2 * (workers or default_workers()) // avg))
+                loader = PrefetchingLoader(dataset, mine, batch_size, workers=workers, depth=depth, pack=True,
+                                           pack_size=None, batches=[[mine[p] for p in pos] for pos in plan])
+                for pos, ((packed, shapes), gts, _) in zip(plan, loader):
+                    yield pos, (shapes, lambda sh, S, dev, packed=packed, pad=padded(shapes), **kw:
+                                preprocess_on_device(sh, None, dev, packed=packed, pad_to=pad, **kw)), gts
+            elif input_pipeline == "host":
                 for s in range(0, len(mine), batch_size):
                     items = [dataset[i] for i in mine[s:s + batch_size]]
                     yield s, torch.stack([it["x"] for it in items]), [it["m"].squeeze() for it in items]
@@ -81,8 +107,11 @@ class Evaluator(BaseStructure):
                 from .pipeline import PrefetchingLoader, preprocess_on_device
                 s = 0
                 # decode on the worker threads, packing into page-locked staging on one more thread, a batch ahead
+                # enough batches in flight to keep every decode worker busy (batch 1: one image per batch)
+                from .decode_pool import default_workers
+                depth = max(len(ring.streams) + 1, -(-2 * (workers or default_workers()) // batch_size))
                 for (packed, shapes), gts, _ in PrefetchingLoader(dataset, mine, batch_size, workers=workers,
-                                                                 depth=len(ring.streams) + 1, pack=True, pack_size=img_size):
+                                                                 depth=depth, pack=True, pack_size=img_size):
                     yield s, (shapes, lambda sh, S, dev, packed=packed, **kw: preprocess_on_device(sh, S, dev, packed=packed, **kw)), gts
                     s += len(shapes)
 
@@ -95,14 +124,17 @@ class Evaluator(BaseStructure):
                         x, u8 = pre(rgbs, img_size, device, pinned=True, return_u8=True)
                     else:
                         x = pre(rgbs, img_size, device, pinned=True)
-                        x = x if img_size is not None else x[0]
+                        x = x if (img_size is not None or bucketed) else x[0]
                 out = self._forward({"x": x}, device=device)
                 mask_pred, obj = out["mask_pred"], out.get("objectness")
                 if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
                     mask_pred, obj = mask_pred[:, -1], obj[:, -1]
                 gtb = ops.GtBatch.from_packed(gts, device) if isinstance(gts, tuple) else ops.GtBatch(gts, device)
                 rows = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gtb, scale=scale)
-                rows_local[s:s + gtb.B] = rows
+                if bucketed:  # s = this bucket's positions in the rank's image list
+                    rows_local[torch.as_tensor(s, device=device)] = rows
+                else:
+                    rows_local[s:s + gtb.B] = rows
                 if refine:
                     from .bilateral_solver import bilateral_solver_batch_device
                     target = ops.upsample_selected(mask_pred, rows, (img_size, img_size), "pick")
@@ -161,6 +193,8 @@ def main(argv=None):
     local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else args.gpu_id
     if world > 1:
         import torch.distributed as dist
+        from .distributed import pin_rank_cores
+        pin_rank_cores()  # this rank's block of host cores (decode workers inherit it)
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = torch.device("cuda", local)

@@ -207,10 +207,25 @@ def pack_gts(gts: Sequence[np.ndarray]):
     return flat, dt, [(int(g.shape[0]), int(g.shape[1])) for g in gts]
 
 
-def preprocess_on_device(images, S: Optional[int], device, pinned: bool = False, return_u8: bool = False, packed=None):
+def native_buckets(sizes: Sequence[Tuple[int, int]], patch: int, max_batch: int) -> List[List[int]]:
+    """Native-resolution evaluation in token-grid buckets: positions (into ``sizes``, a list of (H, W)) grouped by the patch
+    grid (ceil(H / P), ceil(W / P)) their image pads to, cut into batches of at most ``max_batch``, in order of first
+    appearance; inside a batch the dataset order is kept.  Every position appears exactly once."""
+    groups = {}
+    for i, (h, w) in enumerate(sizes):
+        groups.setdefault((-(-h // patch), -(-w // patch)), []).append(i)
+    out = []
+    for idx in groups.values():
+        out += [idx[s:s + max_batch] for s in range(0, len(idx), max_batch)]
+    return out
+
+
+def preprocess_on_device(images, S: Optional[int], device, pinned: bool = False, return_u8: bool = False, packed=None,
+                         pad_to: Optional[Tuple[int, int]] = None):
     """Decoded uint8 images -> normalised fp32 model input on ``device``.  S given: (B, 3, S, S) after the PIL-exact
     bilinear resize (``return_u8``: also the resized uint8 images (B, S, S, 3)); S None: a list of (1, 3, H, W) tensors at
-    native resolution (views of one buffer)."""
+    native resolution (views of one buffer), or - ``pad_to=(Hp, Wp)`` - ONE (B, 3, Hp, Wp) batch with every image in the
+    top-left corner and zeros elsewhere (what make_input_divisible builds per image, vision_transformer.py:260-267)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("the input pipeline's resize / normalise kernels run on a HIP device (no CPU fallback)")
@@ -233,6 +248,15 @@ def preprocess_on_device(images, S: Optional[int], device, pinned: bool = False,
                                             tmp.stride(0), out.data_ptr(), u8.data_ptr() if return_u8 else None, B, S, max_h, st),
                 "sm_preprocess_resize_u8")
         return (out, u8) if return_u8 else out
+    if pad_to is not None:
+        Hp, Wp = pad_to
+        for im in images:
+            h, w = (im.shape[:2] if hasattr(im, "shape") else im[:2])
+            assert h <= Hp and w <= Wp, "pad_to must cover every image of the batch"
+        out = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=device)
+        N.check(lib.sm_preprocess_normalize_pad_u8(pd.data_ptr(), dd.data_ptr(), _lut(device).data_ptr(), out.data_ptr(), B, Hp, Wp, st),
+                "sm_preprocess_normalize_pad_u8")
+        return out
     out = torch.empty(out_elems, dtype=torch.float32, device=device)
     N.check(lib.sm_preprocess_normalize_u8(pd.data_ptr(), dd.data_ptr(), _lut(device).data_ptr(), out.data_ptr(), B, max_px, st),
             "sm_preprocess_normalize_u8")
@@ -244,16 +268,7 @@ def preprocess_on_device(images, S: Optional[int], device, pinned: bool = False,
     return views
 
 
-def decode_item(p_img: str, p_gt: Optional[str]):
-    """Host part of one sample: RGB decode (+ GT decode and binarisation, base_dataset.py:248-255 / duts.py:123,144)."""
-    rgb = np.asarray(Image.open(p_img).convert("RGB"), np.uint8)
-    m = None
-    if p_gt is not None:
-        m = np.asarray(Image.open(p_gt).convert("L"))
-        if m.max() > 1:
-            m = m > 0
-        m = np.ascontiguousarray(m.astype(np.uint8))
-    return rgb, m
+from sm_decode_worker import decode_item  # noqa: E402  (numpy + Pillow only: also what the decode worker processes run)
 
 
 class PrefetchingLoader:
@@ -261,53 +276,80 @@ class PrefetchingLoader:
     Iterating yields (list of rgb uint8 arrays, list of GT uint8 arrays, list of dataset indices)."""
 
     def __init__(self, dataset, indices: Sequence[int], batch_size: int, workers: Optional[int] = None, depth: int = 3,
-                 pack: bool = False, pack_size: Optional[int] = None):
+                 pack: bool = False, pack_size: Optional[int] = None, batches: Optional[Sequence[Sequence[int]]] = None,
+                 decode: Optional[str] = None):
         """``pack``: one more host thread assembles every decoded batch into the page-locked staging buffers of the device
         pipeline (pack_images(..., pack_size, pinned=True) + pack_gts) while the consumer is still busy with the previous
         batch; iterating then yields ((packed images, image shapes), packed GTs, indices) for
         ``preprocess_on_device(shapes, S, device, packed=...)`` / ``ops.GtBatch.from_packed``."""
         self.ds, self.idx, self.bs, self.depth = dataset, list(indices), batch_size, max(1, depth)
         self.pack, self.pack_size = pack, pack_size
+        # ``batches``: explicit lists of dataset indices (native-resolution buckets) instead of consecutive slices of ``indices``
+        self.batches = [list(b) for b in batches] if batches is not None else None
+        # ``decode``: "process" (default) = worker processes writing into shared memory (decode_pool.py): Pillow holds the GIL for
+        # about half of a sample's host time, so threads stop scaling at 1 / that (595 images/s on one thread, 480 on eight);
+        # "thread" = the round-2 thread pool (SM_DECODE=thread selects it globally).  ``workers`` defaults to this rank's share
+        # of the node's cores (CPU affinity / LOCAL_WORLD_SIZE).
+        self.decode = decode or os.environ.get("SM_DECODE", "process")
+        assert self.decode in ("process", "thread"), self.decode
         if workers is None:
-            try:
-                workers = len(os.sched_getaffinity(0))
-            except AttributeError:
-                workers = os.cpu_count() or 4
-            workers = max(1, min(32, workers))
+            from .decode_pool import default_workers
+            workers = default_workers()
         self.workers = workers
 
     def __len__(self):
-        return -(-len(self.idx) // self.bs)
+        return len(self.batches) if self.batches is not None else -(-len(self.idx) // self.bs)
 
     def __iter__(self):
-        batches = [self.idx[s:s + self.bs] for s in range(0, len(self.idx), self.bs)]
+        batches = self.batches if self.batches is not None else [self.idx[s:s + self.bs] for s in range(0, len(self.idx), self.bs)]
+        if not batches:
+            return
+        if self.decode == "process":
+            from .decode_pool import BatchSlots, DecodePool
+            dpool, slots = DecodePool(self.workers), BatchSlots(self.depth + 1, max(len(b) for b in batches))
+            try:
+                def submit(k):  # -> callable returning (rgb views, GT views) inside shared slot k % (depth + 1)
+                    return dpool.decode_batch(slots, k % (self.depth + 1), [(self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]])
+                yield from self._run(batches, submit)
+            finally:
+                dpool.close()
+                slots.close()
+            return
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
             def submit(k):
-                return [pool.submit(decode_item, self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]]
-            if not self.pack:
-                inflight = [submit(k) for k in range(min(self.depth, len(batches)))]
-                for k in range(len(batches)):
-                    futs = inflight.pop(0)
-                    if k + self.depth < len(batches):
-                        inflight.append(submit(k + self.depth))
+                futs = [pool.submit(decode_item, self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]]
+
+                def result():
                     items = [f.result() for f in futs]
-                    yield [it[0] for it in items], [it[1] for it in items], batches[k]
-                return
+                    return [it[0] for it in items], [it[1] for it in items]
+                return result
+            yield from self._run(batches, submit)
 
-            def assemble(futs):  # runs on the packing thread: waits for the batch's decodes, copies into pinned staging
-                items = [f.result() for f in futs]
-                rgbs = [it[0] for it in items]
-                shapes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
-                gts = [it[1] for it in items]
-                return (pack_images(rgbs, self.pack_size, pinned=True), shapes), (pack_gts(gts) if gts[0] is not None else None)
+    def _run(self, batches, submit):
+        """``submit(k)`` starts the decode of batch k and returns a callable that waits for it: (rgb arrays, GT arrays).  The
+        arrays of batch k may be overwritten once batch k + depth + 1 is submitted (shared-memory slots)."""
+        if not self.pack:
+            inflight = [submit(k) for k in range(min(self.depth, len(batches)))]
+            for k in range(len(batches)):
+                wait = inflight.pop(0)
+                if k + self.depth < len(batches):
+                    inflight.append(submit(k + self.depth))
+                rgbs, gts = wait()
+                yield rgbs, gts, batches[k]
+            return
 
-            with ThreadPoolExecutor(max_workers=1) as packer:
-                def submit_packed(k):
-                    return packer.submit(assemble, submit(k))
-                inflight = [submit_packed(k) for k in range(min(self.depth, len(batches)))]
-                for k in range(len(batches)):
-                    fut = inflight.pop(0)
-                    if k + self.depth < len(batches):
-                        inflight.append(submit_packed(k + self.depth))
-                    imgs, gts = fut.result()
-                    yield imgs, gts, batches[k]
+        def assemble(wait):  # runs on the packing thread: waits for the batch's decodes, copies into pinned staging
+            rgbs, gts = wait()
+            shapes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
+            return (pack_images(rgbs, self.pack_size, pinned=True), shapes), (pack_gts(gts) if gts[0] is not None else None)
+
+        with ThreadPoolExecutor(max_workers=1) as packer:
+            def submit_packed(k):
+                return packer.submit(assemble, submit(k))
+            inflight = [submit_packed(k) for k in range(min(self.depth, len(batches)))]
+            for k in range(len(batches)):
+                fut = inflight.pop(0)
+                if k + self.depth < len(batches):
+                    inflight.append(submit_packed(k + self.depth))
+                imgs, gts = fut.result()
+                yield imgs, gts, batches[k]

@@ -1,0 +1,66 @@
+"""Host half of one evaluation sample and the worker process that runs it.
+
+``decode_item`` is the reference's per-sample host work (datasets/base_dataset.py:248-255, duts.py:123,144): RGB decode of the
+image, GT decode in mode "L" binarised with ``m > 0`` when its maximum exceeds 1.  This module imports only numpy and Pillow - it
+is also the entry point of the decode WORKER PROCESSES of ``selfmask_amd.decode_pool`` (``python sm_decode_worker.py``), which
+must start fast and must never touch the GPU.
+
+Why processes: Pillow releases the GIL only inside libjpeg / zlib; everything around it (the Python-level header parsing of
+``Image.open``, ``convert``, ``np.asarray``, ``max``, ``astype``) holds it - about half of the 1.7 ms a 350 x 350 sample costs.
+Threads therefore top out near 1 / (GIL-held time): measured 595 images/s on ONE thread, 414 on four and 482 on eight threads
+of the same 8-core host; 16 threads of a GPU box reach 1.6-2.0k images/s where 16 cores could decode 9k.
+
+Worker protocol (one request per line on stdin, one reply per line on stdout, tab separated):
+    request   <image path> <GT path or -> <shm file> <rgb offset> <rgb capacity> <gt offset> <gt capacity>
+    reply     ok <H> <W> <gtH> <gtW>      pixels written to the shared segment: (H, W, 3) uint8 at rgb offset, (gtH, gtW) uint8
+                                           {0, 1} at gt offset (gtH = gtW = 0 without a GT)
+              big <H> <W> <gtH> <gtW>     a capacity is too small: nothing written, the parent decodes this sample itself
+              err <message>
+"""
+import mmap
+import sys
+
+import numpy as np
+from PIL import Image
+
+
+def decode_item(p_img: str, p_gt=None):
+    """Host part of one sample: RGB decode (+ GT decode and binarisation, base_dataset.py:248-255 / duts.py:123,144)."""
+    rgb = np.asarray(Image.open(p_img).convert("RGB"), np.uint8)
+    m = None
+    if p_gt is not None:
+        m = np.asarray(Image.open(p_gt).convert("L"))
+        if m.max() > 1:
+            m = m > 0
+        m = np.ascontiguousarray(m.astype(np.uint8))
+    return rgb, m
+
+
+def _serve() -> None:
+    maps = {}
+    out = sys.stdout
+    for line in sys.stdin:
+        try:
+            p_img, p_gt, shm, ro, rc, go, gc = line.rstrip("\n").split("\t")
+            ro, rc, go, gc = int(ro), int(rc), int(go), int(gc)
+            rgb, m = decode_item(p_img, None if p_gt == "-" else p_gt)
+            h, w = rgb.shape[:2]
+            gh, gw = (m.shape if m is not None else (0, 0))
+            if rgb.size > rc or (m is not None and m.size > gc):
+                out.write(f"big\t{h}\t{w}\t{gh}\t{gw}\n")
+            else:
+                mm = maps.get(shm)
+                if mm is None:
+                    with open(shm, "r+b") as f:  # the segment's file under /dev/shm (no resource tracker involved)
+                        mm = maps[shm] = mmap.mmap(f.fileno(), 0)
+                np.frombuffer(mm, np.uint8, rgb.size, ro)[:] = rgb.reshape(-1)
+                if m is not None:
+                    np.frombuffer(mm, np.uint8, m.size, go)[:] = m.reshape(-1)
+                out.write(f"ok\t{h}\t{w}\t{gh}\t{gw}\n")
+        except Exception as e:  # noqa: BLE001 - reported to the parent, which raises
+            out.write("err\t" + repr(e).replace("\n", " ").replace("\t", " ") + "\n")
+        out.flush()
+
+
+if __name__ == "__main__":
+    _serve()

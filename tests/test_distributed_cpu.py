@@ -87,3 +87,12 @@ def test_dataset_reader_semantics(tmp_path):
     assert DS.get_dataset(str(tmp_path), "dut_omron", eval_img_size=32)[0]["x"].shape == (3, 32, 32)
     with pytest.raises(ValueError):
         DS.get_dataset(str(tmp_path), "cub")
+
+
+def test_rank_cores_partition_the_host():
+    from selfmask_amd.distributed import rank_cores
+    cores = list(range(3, 131))  # 128 cores, not starting at 0
+    blocks = [rank_cores(r, 8, cores) for r in range(8)]
+    assert all(len(b) == 16 for b in blocks) and sorted(sum(blocks, [])) == cores   # disjoint, complete, contiguous
+    assert all(b == list(range(b[0], b[0] + 16)) for b in blocks)
+    assert rank_cores(0, 1, cores) == cores and len(rank_cores(5, 8, list(range(6)))) == 1   # fewer cores than ranks: one each

@@ -68,3 +68,53 @@ def test_prefetching_loader_order(tmp_path):
             assert np.array_equal(gt, item["m"].numpy()) and rgb.shape[:2] == gt.shape and set(np.unique(gt)) <= {0, 1}
         seen += idx
     assert seen == list(range(7))
+
+
+def test_native_buckets_partition_by_token_grid():
+    from selfmask_amd.pipeline import native_buckets
+    rng = np.random.Generator(np.random.PCG64(3))
+    sizes = [(int(h), int(w)) for h, w in rng.integers(90, 200, size=(200, 2))]
+    for patch, mb in ((16, 8), (8, 5), (16, 1)):
+        plan = native_buckets(sizes, patch, mb)
+        flat = [i for b in plan for i in b]
+        assert sorted(flat) == list(range(len(sizes)))            # every image exactly once
+        for b in plan:
+            assert 1 <= len(b) <= mb and b == sorted(b)          # dataset order kept inside a batch
+            grids = {(-(-sizes[i][0] // patch), -(-sizes[i][1] // patch)) for i in b}
+            assert len(grids) == 1                               # one token grid per batch
+    assert native_buckets([], 16, 4) == []
+
+
+def test_decode_pool_processes_write_the_same_bytes_as_decode_item(tmp_path):
+    """Worker processes + shared-memory slots (decode_pool.py) against the in-process decode_item: same pixels, same GT bytes;
+    a sample beyond its window falls back to the in-process decode; a missing file surfaces as an error; no /dev/shm leftovers."""
+    import glob
+    from selfmask_amd import datasets as DS
+    from selfmask_amd.decode_pool import BatchSlots, DecodePool
+    from selfmask_amd.pipeline import PrefetchingLoader, decode_item
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 21, seed=3, size_range=(40, 90))
+    ds = DS.get_dataset(str(tmp_path), "ecssd")
+    before = set(glob.glob("/dev/shm/sm_decode_*"))
+    seen = []
+    for mode in ("process", "thread"):
+        for rgbs, gts, idx in PrefetchingLoader(ds, range(len(ds)), 8, workers=3, depth=2, decode=mode):
+            for r, g, i in zip(rgbs, gts, idx):
+                rr, gg = decode_item(ds.p_imgs[i], ds.p_gts[i])
+                assert np.array_equal(r, rr) and np.array_equal(g, gg) and g.dtype == np.uint8 and set(np.unique(g)) <= {0, 1}
+                seen.append(i)
+    assert sorted(seen) == sorted(list(range(len(ds))) * 2)
+    pool, slots = DecodePool(2), BatchSlots(1, 4, max_side=64)   # 64 x 64 windows: the larger images come back "big"
+    try:
+        paths = [(ds.p_imgs[i], ds.p_gts[i]) for i in range(4)]
+        rgbs, gts = pool.decode_batch(slots, 0, paths)()
+        for (pi, pg), r, g in zip(paths, rgbs, gts):
+            rr, gg = decode_item(pi, pg)
+            assert np.array_equal(r, rr) and np.array_equal(g, gg)
+        with pytest.raises(RuntimeError, match="decode worker"):
+            pool.decode_batch(slots, 0, [(str(tmp_path / "missing.jpg"), None)])()
+        rgbs, gts = pool.decode_batch(slots, 0, [(ds.p_imgs[0], None)])()   # the pool survives an error; GT-less samples
+        assert gts == [None] and np.array_equal(rgbs[0], decode_item(ds.p_imgs[0], None)[0])
+    finally:
+        pool.close()
+        slots.close()
+    assert set(glob.glob("/dev/shm/sm_decode_*")) == before
