@@ -401,6 +401,10 @@ typedef struct sm_forward_io {
     float* queries;     /* (B,L,nq,384) decoder outputs after decoder.norm, or NULL (debug/parity tap)           */
     float* patch_tokens;/* (B,gh*gw,384) final-LN'd encoder tokens, or NULL (debug/parity tap; encoder_only)     */
     int32_t encoder_only;
+    int32_t attn_path;       /* encoder attention in gemm_mode 2/3 on token grids <= 208: 0 = by batch size (the fused QKV + attention
+                                kernel from B >= 16 up, the qkv GEMM + attention pair below: the faster one each), 1 = fused whenever
+                                the grid allows, 2 = always the pair.  The two paths differ in the last bits (other summation
+                                order): a caller that needs bit-identical results across batch sizes pins one (the Evaluator does) */
     int32_t last_layer_only; /* 1: return_intermediate=False (maskformer.py:219-220) - only the last decoder layer reaches the mask
                                 einsum; mask_logits / mask_pred are then (B,1,nq,2gh,2gw).  features / queries keep all L layers */
 } sm_forward_io;

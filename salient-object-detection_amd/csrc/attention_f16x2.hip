@@ -27,10 +27,13 @@ constexpr int HAT_CH = 64;                  // keys per ring slot
 constexpr int HAT_TENSOR = HAT_CH * 256;    // bytes of K (or V) per slot
 constexpr int HAT_SLOT = 2 * HAT_TENSOR;
 
+// ds_read_b64_tr_b16 through the compiler's builtin (round 3): hipcc then counts the read in lgkmcnt and may keep several in
+// flight under the MFMAs of the previous group - the inline-asm form needed an s_waitcnt lgkmcnt(0) + sched_barrier before every
+// group of MFMAs, i.e. one exposed LDS round trip per 6 MFMAs
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 __device__ __forceinline__ f16x4 tr_read4(unsigned addr) {
-    f16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
+    const fp16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(reinterpret_cast<__attribute__((address_space(3))) fp16x4_t*>((uintptr_t)addr));
+    return __builtin_bit_cast(f16x4, v);
 }
 // slot permutation of row r: bits (r0, r1, r2, r3) -> XOR mask bits (0, 3, 1, 2)
 __device__ __forceinline__ int hat_swz(int r) { return (r & 1) | ((r & 2) << 2) | ((r & 4) >> 1) | ((r & 8) >> 1); }
@@ -212,8 +215,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
                         const int pc = 8 * db + vpiece;
                         const f16x4 h1 = tr_read4(rowA + ((pc ^ vswA) * 16)), h2 = tr_read4(rowA + 8 * 256 + ((pc ^ vswB) * 16));
                         const f16x4 l1 = tr_read4(rowA + (((pc + 1) ^ vswA) * 16)), l2 = tr_read4(rowA + 8 * 256 + (((pc + 1) ^ vswB) * 16));
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_sched_barrier(0);
                         f16x8 vh, vl;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { vh[e] = h1[e]; vh[4 + e] = h2[e]; vl[e] = l1[e]; vl[4 + e] = l2[e]; }

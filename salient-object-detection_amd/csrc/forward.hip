@@ -251,14 +251,22 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // ---- 12 pre-norm blocks (vision_transformer.py:164-170) -----------------------------------------------------
     // Optional (split mode): the two pre-norms of a block ride on the GEMM that produces their input (proj -> norm2,
     // fc2 -> the next block's norm1); only the first norm1 is then a launch of its own.
-    // SM_FUSED_LN (tuning knob, default 0): 1 = proj and fc2, 2 = proj only.  Measured with three batches in flight:
+    // SM_FUSED_LN (tuning build only, default 0): 1 = proj and fc2, 2 = proj only.  Measured with three batches in flight:
     // 17.3k images/s against 18.0k unfused - the full-row tile needs 112 KiB of LDS (one workgroup per CU, 197 of them).
+#ifdef SM_TUNING
     static const int fused_ln_env = getenv("SM_FUSED_LN") ? atoi(getenv("SM_FUSED_LN")) : 0;
+    static const int fused_qkv_env = getenv("SM_FUSED_QKV") ? atoi(getenv("SM_FUSED_QKV")) : 1;
+#else
+    constexpr int fused_ln_env = 0, fused_qkv_env = 1;
+#endif
     const bool fuse_proj = S && !c.W16 && fused_ln_env >= 1, fuse_fc2 = S && !c.W16 && fused_ln_env == 1;
     // W16 mode, token grids of <= 208 (ViT-S/16 at 224^2): the qkv projection and the attention are ONE launch
-    // (qkv_attention.hip); SM_FUSED_QKV=0 keeps the two-launch path (tuning knob, same results to rounding)
-    static const int fused_qkv_env = getenv("SM_FUSED_QKV") ? atoi(getenv("SM_FUSED_QKV")) : 1;
-    const bool fused_qkv = c.W16 && fused_qkv_env != 0 && s.N <= sm_qkv_attention_max_tokens();
+    // (qkv_attention.hip); SM_FUSED_QKV=0 (tuning build only) keeps the two-launch path (same results to rounding)
+    // ... and at least 96 (image, head) workgroups: the fused kernel is one workgroup per pair with a ~30 us life, so a small batch
+    // leaves most CUs idle for that long - below B = 16 the two-launch path is faster (B = 1: 1.25 vs 1.38 ms per forward, B = 4:
+    // 1.40 vs 1.96, B = 8: 1.53 vs 2.10, B = 16: 1.94 vs 1.93; profiles/r03_fused_vs_unfused_by_batch.log)
+    const bool fused_qkv = c.W16 && fused_qkv_env != 0 && s.N <= sm_qkv_attention_max_tokens() && io->attn_path != 2 &&
+                           (io->attn_path == 1 || s.B * SM_HEADS >= 96);
     LnOpt xs;
     xs.ys = S ? ws.Xn : nullptr;  // LN output only feeds a GEMM: F16X2 in split mode
 #ifdef SM_TUNING  // timing-only ablation (tuning build): what the 24 encoder LayerNorm launches cost the pipeline (results are garbage)
@@ -517,6 +525,7 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
                    "sm_maskformer_forward: null output");
     else
         SM_REQUIRE(io->patch_tokens, "sm_maskformer_forward: encoder_only needs patch_tokens");
+    SM_REQUIRE(io->attn_path >= 0 && io->attn_path <= 2, "sm_maskformer_forward: attn_path=%d (0 auto, 1 fused, 2 two launches)", io->attn_path);
     SM_REQUIRE(!(io->last_layer_only && w->mask_head_ffn), "sm_maskformer_forward: last_layer_only is the 3-D path (no ffn mask head)");
     return SM_OK;
 }

@@ -465,11 +465,16 @@ extern "C" int sm_gemm_f16x2_tile(const sm_gemm_args* g, int out_f16x2, int bm, 
     // epilogue of one workgroup only overlap with those of OTHER workgroups on the CU, so the default shapes are the
     // ones that fit three workgroups per CU - 48 KiB of LDS and, via __launch_bounds__(256, 3), <= 168 registers
     // (left alone hipcc spends 109 VGPR + 64 AGPR on the 128x64 tile = two per CU, and the kernel is 25 % slower).
-    // tuning knobs: SM_F16X2_NST = ring depth (2..5 where instantiated), SM_F16X2_VARIANT = "a3" (128x128, four waves,
+    // tuning knobs (tuning build only): SM_F16X2_NST = ring depth (2..5 where instantiated), SM_F16X2_VARIANT = "a3" (128x128, four waves,
     // the A ring one tile deeper), "w4" (128x128 as four waves of 64x64), "w16" (256x128 as sixteen waves of 64x32)
+#ifdef SM_TUNING
     const char* env = getenv("SM_F16X2_NST");
     const int nst = env ? atoi(env) : 0;
     const char* var = getenv("SM_F16X2_VARIANT");
+#else
+    constexpr int nst = 0;
+    const char* var = nullptr;
+#endif
     const bool var_a3 = var && !strcmp(var, "a3"), var_w4 = var && !strcmp(var, "w4");
     if (bm == 64 && bn == 384) return sm::launch_gemm_h<64, 384, 2, 2, 4, 1, 0>(a, st);  // full-row tile (LayerNorm epilogue)
     if (bm == 256 && bn == 128 && var && !strcmp(var, "w16")) return sm::launch_gemm_h<256, 128, 2, 4, 4, 1, 0>(a, st);  // 16 waves of 64x32
@@ -499,8 +504,13 @@ extern "C" int sm_gemm_f16x2_pick_tile(const sm_gemm_args* g, int* bm, int* bn, 
     else if (wg128 >= 512) { *bm = 128; *bn = 64; *nst = 2; }
     else { *bm = 64; *bn = 64; *nst = 3; }
     // tuning knobs: "BMxBN" for the GEMMs with >= 512 workgroups, by output width (N >= 768 / narrower)
+#ifdef SM_TUNING
     static const char* force_w = getenv("SM_F16X2_TILE_WIDE");
     static const char* force_n = getenv("SM_F16X2_TILE_NARROW");
+#else
+    const char* force_w = nullptr;
+    const char* force_n = nullptr;
+#endif
     const char* force = g->N >= 768 ? force_w : force_n;
     if (force && wg128 >= 512) {
         int fbm = 0, fbn = 0;

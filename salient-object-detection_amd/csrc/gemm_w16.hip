@@ -41,6 +41,8 @@ __device__ __forceinline__ int stage_swz(int row) {
     else return (row >> 2) & 3;
 }
 
+#ifdef SM_TUNING  // the v_mfma_f32_32x32x16_f16 family of round 2 (software-pipelined, deep-ring forms): measured and rejected
+// (the 16x16x32 kernels are 10-15 % faster alone, +4.4 % in the pipeline); kept in the tuning build as the comparison
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (N > 0) {
@@ -329,6 +331,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16_kernel(sm_gemm_a
         default: out_split ? run(std::integral_constant<int, SM_EPI_BIAS>{}, T{}) : run(std::integral_constant<int, SM_EPI_BIAS>{}, Fa{}); break;
     }
 }
+
+#endif  // SM_TUNING
 
 // ---- 16x16x32 MFMA variant -------------------------------------------------------------------------------------------------
 // The same GEMM on v_mfma_f32_16x16x32_f16.  Why: with three batches in flight the chip sits at its power limit, and in
@@ -656,6 +660,7 @@ static int launch_gemm_m16(const sm_gemm_args& g, hipStream_t st) {
     return launch_gemm_m16_terms<BM, BN, NST, NWM, NWN, WPS, 3>(g, st);
 }
 
+#ifdef SM_TUNING  // measured and rejected (fc1 -7 % alone, others +-1 %, nothing in the pipeline): tuning build only
 // ---- persistent variant ----------------------------------------------------------------------------------------------------
 // What the one-tile-per-workgroup kernel above cannot hide: every workgroup of a launch starts
 // together, so all of them wait for their first K-tiles together, run their MFMA loops together and write their C tiles
@@ -892,6 +897,8 @@ static int launch_gemm_w_persist(const sm_gemm_args& g, int stagger, hipStream_t
     return check_launch("sm_gemm_w16 (persistent)");
 }
 
+#endif  // SM_TUNING
+
 // fp32 weights (rows, K) -> W16: per group of 8 k, 16 B of wh = f16(w * scale) then 16 B of wl = f16(w * scale - wh)
 __global__ __launch_bounds__(256) void split_w16_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst,
                                                         int64_t ldd, int K, int64_t total_groups, float scale) {
@@ -919,6 +926,7 @@ __global__ __launch_bounds__(256) void split_w16_kernel(const float* __restrict_
     }
 }
 
+#ifdef SM_TUNING
 template <int BM, int BN, int KT, int NST, int NWM, int NWN, int MINB, int PIPE = 0>
 static int launch_gemm_w(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : 1);
@@ -934,6 +942,8 @@ static int launch_gemm_w(const sm_gemm_args& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_w16_kernel<BM, BN, KT, NST, NWM, NWN, MINB, PIPE>), grid, dim3(NWM * NWN * 64), lds, st, g);
     return check_launch("sm_gemm_w16");
 }
+
+#endif  // SM_TUNING
 
 }  // namespace sm
 
@@ -972,6 +982,8 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
     SM_REQUIRE(g->w_scale > 0.f && frexpf(g->w_scale, &ex) == 0.5f, "sm_gemm_w16: w_scale must be the weight tensor's 2^-s");
     SM_REQUIRE((uint64_t)g->M * (uint64_t)g->lda * 4 < (1ull << 32) && (uint64_t)g->N * (uint64_t)g->ldw * 4 < (1ull << 32),
                "sm_gemm_w16: operands beyond 4 GiB (the ring's source addresses are 32-bit offsets from A / W)");
+    SM_REQUIRE(sm_gemm_w16_variant_name(variant) != nullptr, "sm_gemm_w16_tile: variant %d is not in this build (shipped: 40, 42, 44, 45, 47; "
+               "the rejected shapes are in the tuning build)", variant);
     SM_REQUIRE(g->mfma_terms == 0 || g->mfma_terms == 3 || (g->mfma_terms == 1 && variant >= 40 && variant < 50),
                "sm_gemm_w16: mfma_terms must be 0/3 (fp32-grade) or 1 (throughput mode, 16x16x32 kernels only)");
     if (out_f16x2)
@@ -987,6 +999,17 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
     if (out_f16x2) a.patch_n = -1;
     hipStream_t st = (hipStream_t)stream;
     switch (variant) {
+        // the shipped v_mfma_f32_16x16x32_f16 kernels
+        case 40: return sm::launch_gemm_m16<256, 256, 2, 2, 8, 4>(a, st);   // 16 waves of 128x32 (fc1, all-layer K/V)
+        case 42: return sm::launch_gemm_m16<128, 128, 2, 2, 4, 4>(a, st);   // 8 waves of 64x32
+        case 44: return sm::launch_gemm_m16<64, 64, 3, 2, 2, 3>(a, st);     // 4 waves of 32x32 (decoder, batch 1)
+        case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // 4 waves of 64x32
+        case 47: return sm::launch_gemm_m16<256, 128, 3, 4, 4, 4>(a, st);   // 16 waves of 64x32, ring of three (proj, fc2, qkv, patch)
+#ifdef SM_TUNING  // measured-and-rejected shapes, kept as comparisons (scripts/gemm_w16_sweep.py, scripts/gemm_stamps.py)
+        case 41: return sm::launch_gemm_m16<256, 128, 3, 4, 2, 2>(a, st);   // 8 waves of 64x64, ring of three
+        case 46: return sm::launch_gemm_m16<128, 384, 2, 2, 4, 2>(a, st);   // full 384-wide rows: 8 waves of 64x96 (N = 384 GEMMs on 99 CUs)
+        case 48: return sm::launch_gemm_m16<256, 128, 2, 4, 4, 4>(a, st);   // as 47 with a ring of two (96 KiB)
+        // the v_mfma_f32_32x32x16_f16 family
         case 0: return sm::launch_gemm_w<256, 128, 16, 3, 4, 2, 4>(a, st);
         case 1: return sm::launch_gemm_w<256, 128, 32, 2, 4, 4, 4>(a, st);
         case 2: return sm::launch_gemm_w<128, 128, 32, 2, 2, 4, 4>(a, st);
@@ -995,38 +1018,26 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 6: return sm::launch_gemm_w<256, 128, 32, 2, 4, 2, 2>(a, st);
         case 7: return sm::launch_gemm_w<128, 64, 32, 2, 2, 2, 3>(a, st);
         case 8: return sm::launch_gemm_w<128, 128, 16, 3, 2, 4, 6>(a, st);
-        // software-pipelined K loop (PIPE = 1)
-        case 10: return sm::launch_gemm_w<128, 128, 16, 3, 2, 2, 3, 1>(a, st);  // 4 waves of 64x64, 48 KiB: three per CU
-        case 11: return sm::launch_gemm_w<128, 128, 16, 4, 2, 2, 2, 1>(a, st);  // ... ring of 4, 64 KiB: two per CU
-        case 12: return sm::launch_gemm_w<128, 128, 16, 4, 2, 4, 4, 1>(a, st);  // 8 waves of 64x32, 64 KiB: two per CU
-        case 13: return sm::launch_gemm_w<256, 128, 16, 4, 4, 2, 2, 1>(a, st);  // 8 waves of 64x64, 96 KiB: one per CU
-        case 14: return sm::launch_gemm_w<128, 64, 16, 4, 2, 2, 4, 1>(a, st);   // 4 waves of 64x32, 48 KiB: three per CU
-        case 15: return sm::launch_gemm_w<128, 128, 32, 3, 2, 2, 2, 1>(a, st);  // 4 waves of 64x64, 32-k stages x 3, 96 KiB: one per CU
-        // deep rings, one workgroup per CU: what bounds the shallow variants is bytes in flight (Little's law on the LDS-DMA
-        // feed: ~2.6k cycles issue -> landed under load x the bytes per cycle the MFMAs consume), DESIGN.md section 5
-        case 30: return sm::launch_gemm_w<256, 128, 32, 3, 4, 4, 4>(a, st);   // 16 waves of 64x32, 144 KiB
-        case 31: return sm::launch_gemm_w<256, 128, 32, 3, 4, 2, 2>(a, st);   // 8 waves of 64x64, 144 KiB
-        case 32: return sm::launch_gemm_w<256, 256, 32, 2, 2, 8, 4>(a, st);   // 16 waves of 128x32, 128 KiB
-        case 33: return sm::launch_gemm_w<128, 128, 32, 4, 2, 4, 4>(a, st);   // 8 waves of 64x32, 128 KiB
-        case 34: return sm::launch_gemm_w<128, 128, 32, 5, 2, 4, 4>(a, st);   // ... 160 KiB
-        case 35: return sm::launch_gemm_w<256, 128, 16, 6, 4, 2, 2>(a, st);   // 8 waves of 64x64, 16-k stages x 6, 144 KiB
-        case 36: return sm::launch_gemm_w<512, 128, 32, 2, 8, 2, 4>(a, st);   // 16 waves of 64x64, 160 KiB: fewest bytes per MFMA at N = 384
-        // v_mfma_f32_16x16x32_f16 forms of the shipped shapes
-        case 40: return sm::launch_gemm_m16<256, 256, 2, 2, 8, 4>(a, st);   // as 32: 16 waves of 128x32
-        case 41: return sm::launch_gemm_m16<256, 128, 3, 4, 2, 2>(a, st);   // as 31: 8 waves of 64x64, ring of three
-        case 42: return sm::launch_gemm_m16<128, 128, 2, 2, 4, 4>(a, st);   // as 2
-        case 44: return sm::launch_gemm_m16<64, 64, 3, 2, 2, 3>(a, st);     // as 4
-        case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // as 7
-        case 46: return sm::launch_gemm_m16<128, 384, 2, 2, 4, 2>(a, st);   // full 384-wide rows: 8 waves of 64x96 (N = 384 GEMMs on 99 CUs)
-        case 47: return sm::launch_gemm_m16<256, 128, 3, 4, 4, 4>(a, st);   // as 41 with 16 waves of 64x32 (four per SIMD hide the stage waits)
-        case 48: return sm::launch_gemm_m16<256, 128, 2, 4, 4, 4>(a, st);   // ... and a ring of two (96 KiB)
-        // persistent 128x128 (two resident workgroups per CU walk the tile list; next tile prefetched under the epilogue)
-        case 20: case 21: case 22: case 23: case 24: {
+        case 10: return sm::launch_gemm_w<128, 128, 16, 3, 2, 2, 3, 1>(a, st);  // software-pipelined K loop (PIPE = 1)
+        case 11: return sm::launch_gemm_w<128, 128, 16, 4, 2, 2, 2, 1>(a, st);
+        case 12: return sm::launch_gemm_w<128, 128, 16, 4, 2, 4, 4, 1>(a, st);
+        case 13: return sm::launch_gemm_w<256, 128, 16, 4, 4, 2, 2, 1>(a, st);
+        case 14: return sm::launch_gemm_w<128, 64, 16, 4, 2, 2, 4, 1>(a, st);
+        case 15: return sm::launch_gemm_w<128, 128, 32, 3, 2, 2, 2, 1>(a, st);
+        case 30: return sm::launch_gemm_w<256, 128, 32, 3, 4, 4, 4>(a, st);   // deep rings, one workgroup per CU
+        case 31: return sm::launch_gemm_w<256, 128, 32, 3, 4, 2, 2>(a, st);
+        case 32: return sm::launch_gemm_w<256, 256, 32, 2, 2, 8, 4>(a, st);
+        case 33: return sm::launch_gemm_w<128, 128, 32, 4, 2, 4, 4>(a, st);
+        case 34: return sm::launch_gemm_w<128, 128, 32, 5, 2, 4, 4>(a, st);
+        case 35: return sm::launch_gemm_w<256, 128, 16, 6, 4, 2, 2>(a, st);
+        case 36: return sm::launch_gemm_w<512, 128, 32, 2, 8, 2, 4>(a, st);
+        case 20: case 21: case 22: case 23: case 24: {  // persistent 128x128
             SM_REQUIRE((g->K / 32) % 2 == 0 && !(g->split_k > 1), "sm_gemm_w16: the persistent variant needs an even number of 32-k tiles, no split-K");
             static const int stag_env = getenv("SM_W16_STAGGER") ? atoi(getenv("SM_W16_STAGGER")) : -1;
             const int stag[5] = {0, 8, 16, 32, 64};  // x ~512 clocks of s_sleep: 0, 4k, 8k, 16k, 33k cycles
             return sm::launch_gemm_w_persist(a, stag_env >= 0 ? stag_env : stag[variant - 20], st);
         }
+#endif
     }
     sm::set_error("sm_gemm_w16_tile: unknown variant %d", variant);
     return SM_EINVAL;
@@ -1034,6 +1045,15 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
 
 extern "C" const char* sm_gemm_w16_variant_name(int variant) {
     switch (variant) {
+        case 40: return "gemm_w16m16_kernel<256, 256, 2, 2, 8, 4>";
+        case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4>";
+        case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3>";
+        case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3>";
+        case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4>";
+#ifdef SM_TUNING
+        case 41: return "gemm_w16m16_kernel<256, 128, 3, 4, 2, 2>";
+        case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2>";
+        case 48: return "gemm_w16m16_kernel<256, 128, 2, 4, 4, 4>";
         case 0: return "gemm_w16_kernel<256, 128, 16, 3, 4, 2, 4, 0>";
         case 1: return "gemm_w16_kernel<256, 128, 32, 2, 4, 4, 4, 0>";
         case 2: return "gemm_w16_kernel<128, 128, 32, 2, 2, 4, 4, 0>";
@@ -1056,16 +1076,9 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 34: return "gemm_w16_kernel<128, 128, 32, 5, 2, 4, 4, 0>";
         case 35: return "gemm_w16_kernel<256, 128, 16, 6, 4, 2, 2, 0>";
         case 36: return "gemm_w16_kernel<512, 128, 32, 2, 8, 2, 4, 0>";
-        case 40: return "gemm_w16m16_kernel<256, 256, 2, 2, 8, 4>";
-        case 41: return "gemm_w16m16_kernel<256, 128, 3, 4, 2, 2>";
-        case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4>";
-        case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3>";
-        case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3>";
-        case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2>";
-        case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4>";
-        case 48: return "gemm_w16m16_kernel<256, 128, 2, 4, 4, 4>";
+#endif
     }
-    return nullptr;
+    return nullptr;  // not compiled into this build (the rejected shapes live in the tuning build, build.py --tuning)
 }
 
 // Tile choice.  Alone on the GPU every shape from 128 x 64 to 256 x 256 lands within a few per cent of the others
@@ -1077,16 +1090,19 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
 // launch is no faster.  Small problems (decoder, batch 1) keep 128 x 128 / 128 x 64 / 64 x 64 by workgroup count.
 extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     if (!g) return -1;
-    static const int forced_w = getenv("SM_W16_VARIANT_WIDE") ? atoi(getenv("SM_W16_VARIANT_WIDE")) : -1;    // tuning knobs
-    static const int forced_n = getenv("SM_W16_VARIANT_NARROW") ? atoi(getenv("SM_W16_VARIANT_NARROW")) : -1;  // (same results)
+#ifdef SM_TUNING  // tuning knobs (same results): force a variant for the wide (N > 384) / narrow GEMMs, or the 32x32x16 family
+    static const int forced_w = getenv("SM_W16_VARIANT_WIDE") ? atoi(getenv("SM_W16_VARIANT_WIDE")) : -1;
+    static const int forced_n = getenv("SM_W16_VARIANT_NARROW") ? atoi(getenv("SM_W16_VARIANT_NARROW")) : -1;
+    static const bool m32 = getenv("SM_W16_MFMA") && atoi(getenv("SM_W16_MFMA")) == 32;
+#else
+    constexpr int forced_w = -1, forced_n = -1;
+    constexpr bool m32 = false;
+#endif
     const long nb = g->split_k > 1 ? g->split_k : 1;
     const long wg128x64 = (long)((g->M + 127) / 128) * ((g->N + 63) / 64) * nb;
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
     const long wg256x128 = (long)((g->M + 255) / 256) * ((g->N + 127) / 128) * nb;
     const long wg256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256) * nb;
-    // SM_W16_MFMA=32 selects the v_mfma_f32_32x32x16_f16 kernels of the same shapes (tuning knob; the 16x16x32 forms are
-    // +4.7 % images/s in the pipeline and 10-15 % faster alone: less energy per FLOP at the chip's power limit)
-    static const bool m32 = getenv("SM_W16_MFMA") && atoi(getenv("SM_W16_MFMA")) == 32;
     if (wg128x64 < 512) return m32 ? 4 : 44;
     const bool narrow = g->N <= 384;
     if (narrow && forced_n >= 0) return forced_n;

@@ -1,30 +1,29 @@
 // Fused QKV projection + softmax attention of one encoder block (vision_transformer.py:110-131: qkv Linear -> split heads
 // -> softmax(q k^T / 8) v), the kernel BASELINE.json's north star names.  One workgroup per (image, head), seven waves,
-// wave w owns tokens 32w .. 32w+31 - as projection rows first, as queries afterwards.  The (B*N, 1152) QKV tensor of
-// the unfused path (58 MB written and read back per layer at B = 64) never exists: K and V of the head live in LDS, Q in
-// registers.
+// wave w owns tokens 32w .. 32w+31 as two 16-token tiles - as projection rows first, as queries afterwards.  The (B*N, 1152)
+// QKV tensor of the unfused path (58 MB written and read back per layer at B = 64) never exists: K and V of the head live in
+// LDS, Q in registers.  What ships is qkv_attention_m16_kernel<2, TERMS, 4> (v_mfma_f32_16x16x32_f16):
 //
 // Phase 1 - projection.  Xn (the LayerNorm output, F16X2) and the head's 192 rows of the W16 qkv weight stream through a
-// two-slot LDS-DMA ring in 16-k stages (same source-side XOR swizzle as gemm_w16.hip).  Per stage a wave issues 18
-// MFMAs into six single-accumulator 32x32 blocks (gemm_w16.hip's arithmetic: wh*ah + wl*ah + (wh*2^-11)*al'):
-//     Q^T, K^T = W X^T   (weights = MFMA A operand): the token sits on the lane, 16 head-dims in the registers;
-//     V       = X W^T    (weights = MFMA B operand): the head-dim sits on the lane, 16 tokens in the registers.
-// Those are exactly the layouts phase 2 wants (cdna_hip_programming.md section 3, "an accumulator tile as the next
-// MFMA's operand"): registers 8s..8s+7 of a block are the 8 k-elements a lane supplies to step s of the next product,
-// in the permuted order k = 16s + 8(j>>2) + 4h + (j&3) - and because BOTH operands of each later product come from
-// such accumulators (Q and K for S^T, P and V for O^T) the permutation is the same on both sides and nothing has to be
-// transposed: Q stays in registers as the B operand of S^T = K Q^T; every lane writes its key's K fragments and its
-// head-dim's V fragments to LDS as whole 16-B hi / lo pieces in the order the consumer lane (same r, same h) reads them
-// back with ds_read_b128.  No ds_read_b64_tr_b16, no shuffles.
+// two-slot LDS-DMA ring in 32-k stages (128-B rows, the m16_slot image of gemm_w16.hip applied on the DMA source address);
+// waves 0-3 - one per SIMD - issue all 52 pieces of a stage, waves 4-6 only compute.  Per stage a wave issues 72 MFMAs into 24
+// single-accumulator 16x16 tiles (gemm_w16.hip's arithmetic: wh*ah + wl*ah + (wh*2^-11)*al'):
+//     Q^T, K^T = W X^T   (weights = MFMA A operand): the token sits on the lane, four head-dims in the registers;
+//     V       = X W^T    (weights = MFMA B operand): the head-dim sits on the lane, four tokens in the registers.
+// Two accumulator tiles along the contraction axis are exactly the eight k-elements lane group kg supplies to one 32-k step of
+// the next product, in the same permuted order k = 16 (j >> 2) + 4 kg + (j & 3) on both operands, so nothing is transposed:
+// Q stays in registers (B operand of S^T = K Q^T), every lane writes its key's K fragments and its head-dim's V^T fragments to
+// LDS as the 16-B pieces the consumer lane reads back with ds_read_b128.
 //
-// Phase 2 - attention, as attention_f16x2.hip: S^T = K Q^T (3 MFMAs per 16 dims), softmax on the lane (keys on the
-// accumulator rows: one cross-half shuffle), lazy running maximum, P split in registers = B operand of O^T = V^T P^T.
+// Phase 2 - attention: S^T = K Q^T (3 MFMAs per 32 dims), 32 keys per step, softmax on the lane (maxima / sums across the four
+// k-groups by v_permlane16_swap + v_permlane32_swap), lazy running maximum behind ONE wave-uniform branch, P split in
+// registers by compiler-visible instructions (it feeds the P V MFMAs directly) = B operand of O^T = V^T P^T.
 //
-// LDS: one workgroup per CU owns all of it.  During phase 1 the whole 160 KiB is the LDS-DMA ring - six 26-KiB stages, five
-// in flight: the feed is latency-bound (issue -> landed ~2.6k cycles under load), so what it sustains is bytes in flight
-// divided by that latency, and a two-slot ring starved the MFMAs (75 us per launch instead of 5x us).  After the last stage
-// (one barrier) the same memory becomes K (208 x 256 B) + V^T (64 x 848 B, 16 B of padding per row: conflict-free b128
-// reads) = 105 KiB.  N <= 208 tokens: the ViT-S/16 224^2 headline shape (197); other shapes take the unfused path.
+// LDS: one workgroup per CU owns all 160 KiB.  During phase 1 it is the ring (2 x 52 KiB); after the last stage (one barrier)
+// the same memory becomes K (224 x 256 B) + V^T (64 x 896 B).  N <= 208 tokens: the ViT-S/16 224^2 headline shape (197);
+// larger grids take the unfused path (K and V of one head no longer fit: 785 tokens x 256 B x 2 = 392 KiB).
+// The 32x32x16 form of round 2 (qkv_attention_kernel<KT, NST>), the all-waves-load form and the three-slot ring live in the
+// tuning build only (measured: DESIGN.md section 5).
 #include "common.h"
 #include <type_traits>
 #include <math.h>
@@ -43,6 +42,7 @@ constexpr int QA_V_BYTES = 64 * QA_VLD;      // 54272
 constexpr int QA_LDS = 160 * 1024;           // the whole LDS of a CU (one workgroup per CU)
 static_assert(QA_K_BYTES + QA_V_BYTES <= QA_LDS, "K and V^T overlay the ring");
 
+#ifdef SM_TUNING  // the v_mfma_f32_32x32x16_f16 form (round 2, first half): 77-78 us against 65 us for what ships
 // KT = k per ring stage: 32 -> a stage row is one full 128-B line (8 rows per 1-KiB LDS-DMA piece), 16 -> 64-B half lines
 // (16 rows per piece).  NST = ring stages.  Stage = [224 Xn rows | 192 weight rows] x KT * 4 bytes.
 template <int KT, int NST>
@@ -337,8 +337,9 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_kernel(sm_qkv_
             }
     }
 }
+#endif  // SM_TUNING
 
-// ---- the same kernel on v_mfma_f32_16x16x32_f16 ---------------------------------------------------------------------------
+// ---- the kernel on v_mfma_f32_16x16x32_f16 ----------------------------------------------------------------------------------
 // Less energy per FLOP at the chip's power limit (gemm_w16.hip, 16x16x32 variant) and 16-row granularity.  The operand
 // reuse carries over tile for tile: a 16x16 accumulator holds, per lane (c = lane & 15, kg = lane >> 4), column c and rows
 // 4 kg + reg; two such tiles along the contraction axis are the 8 k-elements lane-group kg supplies to one 32-k step of the
@@ -694,12 +695,17 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
 
 }  // namespace sm
 
-// kernel selection: tuning knob (same results up to summation order).  SM_QKV_RING = "m16x2L4" (default: the 16x16x32-MFMA
-// kernel, 32-k stages, ring of two, waves 0-3 feed the ring) | "m16x2" (every wave feeds it: round 2) | "m16x3L4" | "m16x3" | "32x2" | "32x3" | "16x2" | "16x6" (the 32x32x16-MFMA kernel, "<k per stage>x<stages>")
+// kernel selection.  Product: qkv_attention_m16_kernel<2, 3, 4> (or <2, 1, 4>: the throughput-mode diagnostic).  Tuning build:
+// SM_QKV_RING = "m16x2L4" (default) | "m16x2" (every wave feeds the ring: round 2) | "m16x3L4" | "m16x3" | "32x2" | "32x3" |
+// "16x2" | "16x6" (the 32x32x16-MFMA kernel, "<k per stage>x<stages>") - same results up to summation order.
 static int qkv_mode() {
+#ifdef SM_TUNING
     static const char* ring = getenv("SM_QKV_RING");
     return !ring ? 6 : !strcmp(ring, "32x3") ? 1 : !strcmp(ring, "16x2") ? 2 : !strcmp(ring, "16x6") ? 3 : !strcmp(ring, "32x2") ? 0 :
            !strcmp(ring, "m16x3") ? 5 : !strcmp(ring, "m16x2") ? 4 : !strcmp(ring, "m16x3L4") ? 7 : 6;
+#else
+    return 6;
+#endif
 }
 // name rocprofv3 reports for the selected kernel (labels the in-situ taps of forward.hip)
 const char* sm_qkv_attention_kernel_name() {
@@ -724,30 +730,31 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
                "sm_qkv_attention_w16: row strides must be multiples of 8 elements, pointers 32-B aligned");
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        const void* ks[] = {reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 3>),
-                            reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 6>)};
+        const void* ks[] = {reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2, 3, 4>), reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2, 1, 4>),
+#ifdef SM_TUNING
+                            reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 3>),
+                            reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 6>),
+                            reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2>), reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3>),
+                            reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3, 3, 4>),
+#endif
+        };
         for (const void* k : ks) (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, sm::QA_LDS);
         (void)hipGetLastError();
     });
-    // stage shape of the projection phase: tuning knob (same results), "<k per stage>x<ring stages>"; measured on MI355X with
-    // scripts/qkv_attn_bench.py: full 128-B line pieces (32-k stages) move at twice the bytes per address-unit cycle of 64-B pieces
     const int mode = qkv_mode();
     const dim3 grid(a->B * SM_HEADS), block(sm::QA_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (a->mfma_terms == 1) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 1>), grid, block, sm::QA_LDS, st, *a);
+    if (a->mfma_terms == 1) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 1, 4>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 6) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 3, 4>), grid, block, sm::QA_LDS, st, *a);
+#ifdef SM_TUNING
     else if (mode == 4) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 5) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3>), grid, block, sm::QA_LDS, st, *a);
-    else if (mode == 6) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 3, 4>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 7) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3, 3, 4>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 1) hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 3>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 2) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 2>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 3) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 6>), grid, block, sm::QA_LDS, st, *a);
     else hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 2>), grid, block, sm::QA_LDS, st, *a);
+#endif
     return sm::check_launch("sm_qkv_attention_w16");
 }
 

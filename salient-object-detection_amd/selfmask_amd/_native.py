@@ -81,7 +81,8 @@ class Weights(C.Structure):
 class ForwardIO(C.Structure):
     _fields_ = [("x", fp), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("mask_logits", fp), ("mask_pred", fp), ("objectness", fp), ("features", fp), ("queries", fp),
-                ("patch_tokens", fp), ("encoder_only", C.c_int32), ("last_layer_only", C.c_int32)]
+                ("patch_tokens", fp), ("encoder_only", C.c_int32), ("attn_path", C.c_int32),
+                ("last_layer_only", C.c_int32)]
 
 
 class KernelTime(C.Structure):

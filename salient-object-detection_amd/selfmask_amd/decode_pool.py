@@ -22,13 +22,36 @@ import numpy as np
 _WORKER = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sm_decode_worker.py"))
 
 
+def _cgroup_cpus() -> Optional[float]:
+    """CPU quota of this container (cgroup v2 cpu.max / v1 cfs_quota): a box may show 64 cores in its affinity mask and still
+    be allowed 16 cores' worth of time - more busy workers than that only add context switches."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        if q > 0:
+            return q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def default_workers() -> int:
-    """Cores this rank may use for decoding: its CPU affinity divided among the ranks of the node (LOCAL_WORLD_SIZE), one
-    left for the main thread; at most 32."""
+    """Cores this rank may use for decoding: min(CPU affinity, the container's CPU quota) divided among the ranks of the node
+    (LOCAL_WORLD_SIZE), one left for the main thread; at most 32.  SM_DECODE_WORKERS overrides."""
+    if os.environ.get("SM_DECODE_WORKERS"):
+        return max(1, int(os.environ["SM_DECODE_WORKERS"]))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 4
+    q = _cgroup_cpus()
+    if q is not None:
+        n = max(1, min(n, int(q)))
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
     if os.environ.get("SM_RANK_CORES_PINNED") == "1":  # distributed.pin_rank_cores already narrowed the affinity to this rank
         local_world = 1

@@ -70,6 +70,11 @@ class Evaluator(BaseStructure):
             raise ValueError(f"refine={refine!r}: None or 'bilateral'")
         if refine and (img_size is None or input_pipeline != "device"):
             raise ValueError("refine='bilateral' runs in the batched mode (img_size given) on the device input pipeline")
+        # One encoder attention path for the whole run (maskformer.attention_path): ragged last batches, token-grid buckets of
+        # any size and shards of any world size then give the same bits per image as every other way of batching them
+        prev_path = getattr(self.model, "attention_path", None)
+        if prev_path == "auto":
+            self.model.attention_path = "fused" if (img_size is not None and batch_size >= 16) else "unfused"
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
         rows_refined = torch.empty((len(mine), 16), dtype=torch.float32, device=device) if refine else None
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
@@ -115,33 +120,37 @@ class Evaluator(BaseStructure):
                     yield s, (shapes, lambda sh, S, dev, packed=packed, **kw: preprocess_on_device(sh, S, dev, packed=packed, **kw)), gts
                     s += len(shapes)
 
-        for s, x, gts in batches():
-            with ring.next():
-                u8 = None
-                if isinstance(x, tuple):  # decoded uint8 images: resize / normalise on this batch's stream
-                    rgbs, pre = x
-                    if refine:
-                        x, u8 = pre(rgbs, img_size, device, pinned=True, return_u8=True)
+        try:
+            for s, x, gts in batches():
+                with ring.next():
+                    u8 = None
+                    if isinstance(x, tuple):  # decoded uint8 images: resize / normalise on this batch's stream
+                        rgbs, pre = x
+                        if refine:
+                            x, u8 = pre(rgbs, img_size, device, pinned=True, return_u8=True)
+                        else:
+                            x = pre(rgbs, img_size, device, pinned=True)
+                            x = x if (img_size is not None or bucketed) else x[0]
+                    out = self._forward({"x": x}, device=device)
+                    mask_pred, obj = out["mask_pred"], out.get("objectness")
+                    if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
+                        mask_pred, obj = mask_pred[:, -1], obj[:, -1]
+                    gtb = ops.GtBatch.from_packed(gts, device) if isinstance(gts, tuple) else ops.GtBatch(gts, device)
+                    rows = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gtb, scale=scale)
+                    if bucketed:  # s = this bucket's positions in the rank's image list
+                        rows_local[torch.as_tensor(s, device=device)] = rows
                     else:
-                        x = pre(rgbs, img_size, device, pinned=True)
-                        x = x if (img_size is not None or bucketed) else x[0]
-                out = self._forward({"x": x}, device=device)
-                mask_pred, obj = out["mask_pred"], out.get("objectness")
-                if mask_pred.dim() == 5:  # evaluator.pyc@L199-205: last decoder layer
-                    mask_pred, obj = mask_pred[:, -1], obj[:, -1]
-                gtb = ops.GtBatch.from_packed(gts, device) if isinstance(gts, tuple) else ops.GtBatch(gts, device)
-                rows = ops.evaluate_masks(mask_pred, obj.squeeze(-1), gtb, scale=scale)
-                if bucketed:  # s = this bucket's positions in the rank's image list
-                    rows_local[torch.as_tensor(s, device=device)] = rows
-                else:
-                    rows_local[s:s + gtb.B] = rows
-                if refine:
-                    from .bilateral_solver import bilateral_solver_batch_device
-                    target = ops.upsample_selected(mask_pred, rows, (img_size, img_size), "pick")
-                    _, binary = bilateral_solver_batch_device(u8, target)
-                    refined = ops.mask_u8_to_f32(binary).unsqueeze(1)  # one "query" per image; its objectness is moot
-                    rows_refined[s:s + gtb.B] = ops.evaluate_masks(refined, rows[:, 0:1], gtb, scale=0.0)
-        ring.join()
+                        rows_local[s:s + gtb.B] = rows
+                    if refine:
+                        from .bilateral_solver import bilateral_solver_batch_device
+                        target = ops.upsample_selected(mask_pred, rows, (img_size, img_size), "pick")
+                        _, binary = bilateral_solver_batch_device(u8, target)
+                        refined = ops.mask_u8_to_f32(binary).unsqueeze(1)  # one "query" per image; its objectness is moot
+                        rows_refined[s:s + gtb.B] = ops.evaluate_masks(refined, rows[:, 0:1], gtb, scale=0.0)
+            ring.join()
+        finally:
+            if prev_path == "auto":
+                self.model.attention_path = prev_path
         self.graph_stats = {"captures": self._graphed.captures, "replays": self._graphed.replays,
                             "failed": self._graphed.failed}
         self._graphed = None

@@ -97,7 +97,8 @@ class GraphedForward:
         if gen != self._generation:  # packed weights were rebuilt: every captured pointer is stale
             self.policy.clear()
             self._generation = gen
-        key = (x.device, tuple(x.shape), x.dtype, torch.cuda.current_stream(x.device).cuda_stream)
+        key = (x.device, tuple(x.shape), x.dtype, torch.cuda.current_stream(x.device).cuda_stream,
+               getattr(self.model, "attention_path", "auto"))  # a graph bakes in the kernels of one attention path
         what = self.policy.decide(key)
         if what == "eager":
             return self.model(x)

@@ -52,6 +52,7 @@ class SelfMaskInference:
         # The replayed graph owns ONE static input and ONE set of outputs per (shape, stream); Flask's server is threaded
         # (app.py:3927), so requests are serialised from the copy into the static input to the last D2H copy
         self._lock = threading.Lock()
+        self._out = None  # (shape key, device result buffer, pinned host copy)
 
     # ---- host: whatever arrives -> (H, W, 3) uint8 ------------------------------------------------------------------------
     @staticmethod
@@ -86,13 +87,22 @@ class SelfMaskInference:
             raise RuntimeError("the serving path selects by objectness (app.py:268-276): use_binary_classifier=True")
         last, last_obj = mask_pred[:, -1], obj[:, -1, :, 0]
         nq, h, w = last.shape[1:]
-        best_mask = torch.empty((1, h, w), dtype=torch.float32, device=self.device)
-        best = torch.empty(1, dtype=torch.int32, device=self.device)
+        # one device buffer [best index | nq scores | h*w mask] and ONE copy into page-locked memory: the request ends with a
+        # single stream synchronisation instead of three blocking device->host copies
+        key = (nq, h, w)
+        if self._out is None or self._out[0] != key:
+            dev_buf = torch.empty(1 + nq + h * w, dtype=torch.float32, device=self.device)
+            self._out = (key, dev_buf, torch.empty(1 + nq + h * w, dtype=torch.float32).pin_memory())
+        _, dev_buf, host_buf = self._out
         N.check(N.load().sm_pick_mask_f32(last.data_ptr(), last.stride(0), last_obj.data_ptr(), last_obj.stride(0),
-                                          best_mask.data_ptr(), best.data_ptr(), 1, nq, h * w,
+                                          dev_buf[1 + nq:].data_ptr(), dev_buf[:1].data_ptr(), 1, nq, h * w,
                                           torch.cuda.current_stream(self.device).cuda_stream), "sm_pick_mask_f32")
-        scores = last_obj[0].cpu().numpy()  # (these D2H copies synchronise the stream: the request is done)
-        return {"best_idx": int(best.cpu()[0]), "objectness_scores": scores, "mask": best_mask[0].cpu().numpy()}
+        dev_buf[1:1 + nq].copy_(last_obj[0])
+        host_buf.copy_(dev_buf, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()  # the request is done
+        out_h = host_buf.numpy()
+        return {"best_idx": int(out_h[:1].view(np.int32)[0]), "objectness_scores": out_h[1:1 + nq].copy(),
+                "mask": out_h[1 + nq:].reshape(h, w).copy()}
 
     # ---- host: the reference's response ---------------------------------------------------------------------------------------
     def predict(self, image) -> dict:

@@ -160,6 +160,10 @@ class MaskFormer(nn.Module):
         self.gemm_mode = gemm_mode or os.environ.get("SM_GEMM_MODE", "w16")
         if self.gemm_mode not in ("w16", "f16x2", "fp32", "f16"):
             raise ValueError(f"gemm_mode={self.gemm_mode!r}: 'w16', 'f16x2', 'fp32' (or the 'f16' throughput-mode diagnostic)")
+        # encoder attention path (sm_forward_io.attn_path): "auto" = the faster of the fused QKV + attention kernel (batch >= 16)
+        # and the GEMM + attention pair (smaller batches); "fused" / "unfused" pin one - the two differ in the last bits, so a
+        # caller that compares results across batch sizes bit for bit (the Evaluator) pins it for the whole run
+        self.attention_path = "auto"
         self._table = None       # (Weights struct, key) cache
         self._packed = None      # tensors derived from the state_dict (kept alive here, rebuilt when weights change)
         self.weights_generation = 0  # bumped whenever the packed weights are dropped: captured hipGraphs hold raw
@@ -327,6 +331,7 @@ class MaskFormer(nn.Module):
         ws = workspace if workspace is not None else self._get_workspace(w, x)
         io = N.ForwardIO()
         io.x, io.B, io.H, io.W = x.data_ptr(), B, H, W
+        io.attn_path = {"auto": 0, "fused": 1, "unfused": 2}[self.attention_path]
         if encoder_only:
             # the reference's encoder_only branch raises on a non-contiguous view (maskformer.py:188); return the
             # evident intent: (B, gh, gw, 384) patch tokens

@@ -3,6 +3,7 @@
 usage: one_gemm_w16.py M N K variant [epilogue: bias|gelu|residual] [out_f16x2: 0|1]"""
 import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("SM_HIP_LIB", os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so"))  # the variant knobs live in the tuning build
 sys.path[:0] = [os.path.join(REPO, "salient-object-detection_amd"), REPO]
 import torch
 from selfmask_amd import ops, _native as N

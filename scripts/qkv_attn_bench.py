@@ -3,6 +3,7 @@
 median of interleaved rounds.  Run once per SM_QKV_RING value (2, 3, 6): the ring depth is read once per process."""
 import os, sys, statistics
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("SM_HIP_LIB", os.path.join(REPO, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so"))  # the variant knobs live in the tuning build
 sys.path[:0] = [os.path.join(REPO, "salient-object-detection_amd"), REPO]
 import torch
 from selfmask_amd import ops, _native as N

@@ -11,7 +11,12 @@ pytestmark = pytest.mark.gpu
 from selfmask_amd import ops, _native as N  # noqa: E402
 
 DEV = "cuda:0"
-VARIANTS = [0, 1, 2, 3, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 20, 22, 30, 31, 32, 33, 34, 35, 36, 40, 41, 42, 44, 45, 46, 47, 48]  # 20+: persistent; 30+: deep rings
+# The shipped instantiations.  The measured-and-rejected shapes (32x32x16 family, persistent, deep rings, 41 / 46 / 48) exist in
+# the tuning build only (build.py --tuning): point SM_HIP_LIB at libselfmask_hip_tuning.so to run this sweep over all of them.
+import os
+SHIPPED = [40, 42, 44, 45, 47]
+ALL = [0, 1, 2, 3, 4, 6, 7, 8, 10, 11, 12, 13, 14, 15, 20, 22, 30, 31, 32, 33, 34, 35, 36, 40, 41, 42, 44, 45, 46, 47, 48]
+VARIANTS = ALL if "tuning" in os.environ.get("SM_HIP_LIB", "") else SHIPPED
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -64,7 +69,7 @@ def test_variants_epilogues_formats(variant, M, Nn, K, epi, osplit):
     assert err <= 4e-6 * max(1.0, ref.abs().max().item()), err  # fp32-grade (a torch fp32 GEMM is at 2-7e-6 here)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 4])
+@pytest.mark.parametrize("variant", [40, 42, 44] + ([0, 2, 4] if VARIANTS is ALL else []))
 def test_split_k_second_operand_and_patch_rows(variant):
     # split-K: raw partial sums per slice, no bias
     a, w = _rand(140, 1536, seed=6), _rand(384, 1536, seed=7, scale=0.03)
