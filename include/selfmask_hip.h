@@ -219,6 +219,12 @@ int sm_upsample2x_tokens_f16x2(const float* tok, int64_t strideb, float* up, int
  * both maps are linear, so the forward evaluates up(einsum(Q, tokens)) - same taps and weights, a quarter of the FLOPs. */
 int sm_upsample2x_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh, int32_t gw,
                                      void* stream);
+/* the same three with the model's scale_factor (maskformer.py:23,161: F.interpolate(scale_factor=s, mode="bilinear")); s = 2 is
+ * what the functions above do, s = 1 the identity (+ sigmoid): outputs are (s gh) x (s gw) */
+int sm_upsample_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, int32_t scale, void* stream);
+int sm_upsample_tokens_f16x2(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, int32_t scale, void* stream);
+int sm_upsample_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh, int32_t gw,
+                                   int32_t scale, void* stream);
 
 /* objectness = sigmoid(h . w3 + b3) for each row of h (rows,384): last layer of MLP + sigmoid (maskformer.py:231-239) */
 int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows, void* stream);
@@ -311,6 +317,22 @@ int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int3
                      int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* ---- candidate masks of the pseudo-mask generator, DINO branch (mask_generator.pyc@L136-200) --------------------
+ * features = F.interpolate(tokens, scale_factor=2, mode="bilinear", align_corners=True): tok (B, gh*gw, 384) with batch stride
+ * strideb (elements) -> up (B, (s gh)*(s gw), 384) */
+int sm_upsample_tokens_aligned_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, int32_t scale,
+                                   void* stream);
+/* clusterer(features, k): Lloyd's k-means (farthest-point initial centres, `iters` iterations, every sum in a fixed order) on
+ * B sets of n points of 384 floats; labels (B, n) int32, centers (B, k, 384) or NULL, workspace >= B * n floats.  The reference's
+ * `clusterings` module is absent from its repository in every form: this is a stated stand-in (its cluster_type="kmeans" option),
+ * parity UNPINNED (oracle/cluster_oracle.py restates it; scikit-learn from the same initial centres is the third-party check). */
+int sm_kmeans_f32(const float* feat, int32_t B, int32_t n, int32_t k, int32_t iters, int32_t* labels, float* centers, float* workspace,
+                  void* stream);
+/* to_one_hot (utils/misc.py:10-35) + F.interpolate(scale_factor=scale, mode="nearest")[..., :H, :W]: labels (lh, lw) int32 ->
+ * masks (k, H, W) uint8 {0, 1} */
+int sm_labels_to_masks_u8(const int32_t* labels, int32_t lh, int32_t lw, int32_t scale, int32_t k, int32_t H, int32_t W, uint8_t* masks,
+                          void* stream);
+
 /* ---- bilateral-solver refinement ---------------------------------------------------- */
 typedef struct sm_bilateral_args {
     const uint8_t* img;    /* (H, W, 3) interleaved RGB = np.array(PIL image)   (bilateral_solver.py:159)            */
@@ -387,6 +409,8 @@ typedef struct sm_weights {
     int32_t normalize_before; /* 1: TransformerDecoderLayer.forward_pre in every decoder layer (transformer_decoder.py:299-327):
                                  each sub-block normalises its input, the residual stream is only normalised by the shared
                                  decoder.norm; 0 (the shipped config): forward_post (:260-297) */
+    int32_t scale_factor;     /* the pixel decoder's up-sampling factor (maskformer.py:23,161; YAML key scale_factor): 0 or 2 = the
+                                 shipped x2, any 1..16 accepted; masks are (scale gh) x (scale gw) */
     int32_t no_objectness;    /* 1: use_binary_classifier=False without the mask head (the 3-D path, maskformer.py:219-220): the
                                  objectness tail is skipped and io->objectness may be NULL; ffn2_w is not read */
 } sm_weights;

@@ -225,6 +225,48 @@ def gen_forward_prenorm():
           f"f32-f64={err:.2e} -> {os.path.getsize(fp) / 1e6:.2f} MB")
 
 
+def gen_forward_scale_factor():
+    """scale_factor in {1, 4} (maskformer.py:23,161; YAML key, utils/misc.py:179): the pixel decoder's F.interpolate factor -
+    the real reference in fp32 and fp64, last decoder layer's pre-sigmoid logits + objectness + features, on a 14 x 12 token
+    grid (168 tokens: the einsum commutes with the up-sampling) and a 14 x 13 one (182 tokens, not a multiple of 4: the
+    literal order; scale_factor 1 is not run there - the product needs token count or mask size to be a multiple of 4)."""
+    vits, mf = _import_reference()
+    torch.set_num_threads(N_THREADS)
+    patch, B, wseed, style, xseed = 16, 1, 13, "calib", 1777
+    sd = synthetic_state_dict(wseed, style, patch_size=patch)
+    save = {"meta": np.array([patch, B, wseed, xseed, N_THREADS]), "style": np.array(style)}
+    cases = []
+    for (Hh, Ww), sfs in (((224, 192), (1, 4)), ((224, 208), (4,))):
+        x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+        for sf in sfs:
+            outs = {}
+            for dtype in (torch.float32, torch.float64):
+                model = mf.MaskFormer(n_queries=20, arch="vit_small", patch_size=patch, n_decoder_layers=6, return_intermediate=True,
+                                      scale_factor=sf, use_binary_classifier=True).eval()
+                model.load_state_dict(sd, strict=True)
+                model = model.to(dtype)
+                with torch.no_grad():
+                    o = model(x.to(dtype))
+                    last = model.forward_encoder(x.to(dtype))[:, -1, ...]
+                    q = model.forward_transformer_decoder(last)
+                    up = model.forward_pixel_decoder(patch_tokens=last, input_size=(Hh // patch, Ww // patch))
+                    logits = torch.einsum("bdqn,bnhw->bdqhw", q, up)
+                    assert torch.equal(torch.sigmoid(logits), o["mask_pred"])
+                outs[dtype] = {"logits_last": logits[:, -1], "objectness": o["objectness"], "features": o["features"]}
+            o32, o64 = outs[torch.float32], outs[torch.float64]
+            err = (o32["logits_last"].double() - o64["logits_last"]).abs().max().item()
+            tag = f"{Hh}x{Ww}_sf{sf}"
+            cases.append(tag)
+            save.update({f"logits_last_{tag}": o32["logits_last"].numpy(), f"logits_last_f64_{tag}": o64["logits_last"].numpy(),
+                         f"objectness_{tag}": o32["objectness"].numpy(), f"features_{tag}": o32["features"].numpy(),
+                         f"f32_vs_f64_maxabs_{tag}": np.array(err), f"logit_absmax_{tag}": np.array(o32["logits_last"].abs().max().item())})
+            print(f"{tag}: logits {tuple(o32['logits_last'].shape)} max|logit|={o32['logits_last'].abs().max().item():.2f} f32-f64={err:.2e}")
+    save["cases"] = np.array(cases)
+    fp = os.path.join(GOLD, "scalefactor_p16_calib.npz")
+    np.savez_compressed(fp, **save)
+    print(f"-> {os.path.getsize(fp) / 1e6:.2f} MB")
+
+
 def _voting_cases():
     """Candidate sets shaped like the generator's (k-way one-hot cluster maps at image resolution): 9 masks per case, with
     full-height / full-width strips, an empty mask, a tiny and a near-full one, on non-multiple-of-64 sizes."""
@@ -387,6 +429,8 @@ if __name__ == "__main__":
         gen_forward_ffnhead()
     if a.only in (None, "forward_prenorm"):
         gen_forward_prenorm()
+    if a.only in (None, "forward_scale_factor"):
+        gen_forward_scale_factor()
     if a.only in (None, "voting"):
         gen_voting()
     if a.only in (None, "metrics"):

@@ -43,7 +43,7 @@ struct TapScope {
 };
 
 struct Shape {
-    int B, H, W, P, gh, gw, n, N, L, nq;
+    int B, H, W, P, gh, gw, n, N, L, nq, sf;  // sf: the pixel decoder's scale_factor (2 as shipped)
     int64_t M, Mp, Md, Mo;  // tokens, patch tokens, decoder rows, objectness rows
 };
 
@@ -52,6 +52,7 @@ static Shape make_shape(const sm_weights* w, int B, int H, int W) {
     s.B = B; s.H = H; s.W = W; s.P = w->patch;
     s.gh = (H + s.P - 1) / s.P; s.gw = (W + s.P - 1) / s.P;
     s.n = s.gh * s.gw; s.N = s.n + 1; s.L = w->n_dec_layers; s.nq = w->n_queries;
+    s.sf = w->scale_factor > 0 ? w->scale_factor : 2;
     s.M = (int64_t)B * s.N; s.Mp = (int64_t)B * s.n; s.Md = (int64_t)B * s.nq; s.Mo = s.Md * s.L;
     return s;
 }
@@ -83,7 +84,7 @@ static Ws carve(const Shape& s, float* base) {
     w.TOK = take(s.Mp * D);
     w.TOKs = take(s.Mp * D);            // F16X2 copy of TOK (A operand of the all-layer K/V GEMM)
     w.KV = take(s.Mp * 2 * D * s.L);    // cross-attention K|V of ALL decoder layers: (B*n, L*768)
-    w.UP = take(s.Mp * 4 * D);          // (S)
+    w.UP = take(s.Mp * s.sf * s.sf * D);  // (S)
     w.TGT = take(s.Md * D);
     w.TGTs = take(s.Md * D);            // F16X2 copy of TGT
     w.TGTQ = take(s.Md * D);            // (S) tgt + query_pos
@@ -95,7 +96,7 @@ static Ws carve(const Shape& s, float* base) {
     w.PART = take(s.Md * D * 4);        // split-K partials of linear2
     w.QD = take(s.Mo * D);
     w.QDs = take(s.Mo * D);             // F16X2 copy of QD
-    w.LOG = take(s.Mo * 4 * s.n);
+    w.LOG = take(s.Mo * s.sf * s.sf * s.n);
     w.O1 = take(s.Mo * D);              // (S)
     w.O2 = take(s.Mo * D);
     w.total = off * sizeof(float);
@@ -131,7 +132,9 @@ static std::string gemm_name(const Ctx& c, const sm_gemm_args& g) {
     int bm = 0, bn = 0, nst = 0;
     if (use_w16(c, g)) {
         const char* nm = sm_gemm_w16_variant_name(sm_gemm_w16_pick(&g));
-        return nm ? nm : "gemm_w16_kernel<?>";
+        std::string s = nm ? nm : "gemm_w16_kernel<?>";
+        if (c.terms == 1 && s.size() > 3 && s.compare(s.size() - 3, 3, " 3>") == 0) s.replace(s.size() - 2, 1, "1");  // the TERMS template argument
+        return s;
     }
     if (c.S) {
         sm_gemm_f16x2_pick_tile(&g, &bm, &bn, &nst);
@@ -476,15 +479,16 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)s.n * D; g.strideC = (int64_t)Lm * s.nq * s.n;
         g.batch = s.B; g.epilogue = SM_EPI_BIAS;
         TRY(gemm(c, g));
-        TRY(sm_upsample2x_logits_sigmoid_f32(ws.LOG, io->mask_logits, io->mask_pred, (int64_t)s.B * Lm * s.nq, s.gh, s.gw, st));
+        TRY(sm_upsample_logits_sigmoid_f32(ws.LOG, io->mask_logits, io->mask_pred, (int64_t)s.B * Lm * s.nq, s.gh, s.gw, s.sf, st));
     } else {  // token counts that are not a multiple of 4 (float4 rows of the GEMM output): the literal order
-        TRY(S ? sm_upsample2x_tokens_f16x2(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st)
-              : sm_upsample2x_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, st));
+        TRY(S ? sm_upsample_tokens_f16x2(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, s.sf, st)
+              : sm_upsample_tokens_f32(tok, (int64_t)s.n * D, ws.UP, s.B, s.gh, s.gw, s.sf, st));
         // mask_pred[b] = sigmoid(Q[b] (L*nq x 384) . up[b]^T (384 x 4n))   (maskformer.py:223)
         sm_gemm_args g = {};
         g.A = qm_a; g.W = ws.UP; g.C = io->mask_logits ? io->mask_logits : ws.LOG; g.C2 = io->mask_pred;
-        g.M = Lm * s.nq; g.N = 4 * s.n; g.K = D; g.lda = D; g.ldw = D; g.ldc = 4 * s.n;
-        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)4 * s.n * D; g.strideC = (int64_t)Lm * s.nq * 4 * s.n;
+        const int up_n = s.sf * s.sf * s.n;
+        g.M = Lm * s.nq; g.N = up_n; g.K = D; g.lda = D; g.ldw = D; g.ldc = up_n;
+        g.strideA = (int64_t)s.L * s.nq * D; g.strideW = (int64_t)up_n * D; g.strideC = (int64_t)Lm * s.nq * up_n;
         g.batch = s.B; g.epilogue = SM_EPI_SIGMOID2;
         TRY(gemm(c, g));
     }
@@ -502,11 +506,14 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
     SM_REQUIRE(w->n_dec_layers >= 1 && w->n_dec_layers <= SM_MAX_DEC_LAYERS, "sm_maskformer_forward: n_dec_layers=%d",
                w->n_dec_layers);
     SM_REQUIRE(w->n_queries >= 1 && w->pos_grid >= 1, "sm_maskformer_forward: bad n_queries/pos_grid");
+    SM_REQUIRE(w->scale_factor >= 0 && w->scale_factor <= 16, "sm_maskformer_forward: scale_factor=%d (1..16; 0 = the shipped 2)", w->scale_factor);
     SM_REQUIRE(w->dec_kv_w && w->dec_kv_b, "sm_maskformer_forward: dec_kv_w/dec_kv_b (packed cross-attention K/V) missing");
     SM_REQUIRE(io->x && io->B > 0 && io->H > 0 && io->W > 0, "sm_maskformer_forward: bad input shape");
     if (w->gemm_mode >= 1) {
         const int gh = (io->H + w->patch - 1) / w->patch, gw = (io->W + w->patch - 1) / w->patch;
-        SM_REQUIRE((4 * gh * gw) % 4 == 0, "sm_maskformer_forward: mask width must be a multiple of 4");
+        const int sf = w->scale_factor > 0 ? w->scale_factor : 2;
+        SM_REQUIRE((gh * gw) % 4 == 0 || (sf * sf * gh * gw) % 4 == 0,
+                   "sm_maskformer_forward: the token count or the mask size must be a multiple of 4 (scale_factor %d on a %d x %d grid)", sf, gh, gw);
     }
     if (w->gemm_mode >= 2) {
         // W16 weights carry their 2^-s in the *_s fields; a zero (a caller that filled the pointers but not the scales) would

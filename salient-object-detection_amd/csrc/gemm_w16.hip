@@ -1045,15 +1045,15 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
 
 extern "C" const char* sm_gemm_w16_variant_name(int variant) {
     switch (variant) {
-        case 40: return "gemm_w16m16_kernel<256, 256, 2, 2, 8, 4>";
-        case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4>";
-        case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3>";
-        case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3>";
-        case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4>";
+        case 40: return "gemm_w16m16_kernel<256, 256, 2, 2, 8, 4, 3>";
+        case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4, 3>";
+        case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3, 3>";
+        case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3, 3>";
+        case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4, 3>";
 #ifdef SM_TUNING
-        case 41: return "gemm_w16m16_kernel<256, 128, 3, 4, 2, 2>";
-        case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2>";
-        case 48: return "gemm_w16m16_kernel<256, 128, 2, 4, 4, 4>";
+        case 41: return "gemm_w16m16_kernel<256, 128, 3, 4, 2, 2, 3>";
+        case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2, 3>";
+        case 48: return "gemm_w16m16_kernel<256, 128, 2, 4, 4, 4, 3>";
         case 0: return "gemm_w16_kernel<256, 128, 16, 3, 4, 2, 4, 0>";
         case 1: return "gemm_w16_kernel<256, 128, 32, 2, 4, 4, 4, 0>";
         case 2: return "gemm_w16_kernel<128, 128, 32, 2, 2, 4, 4, 0>";

@@ -92,16 +92,18 @@ __global__ __launch_bounds__(128) void pos_bicubic_kernel(const float* __restric
     }
 }
 
-// ---- bilinear x2, align_corners=False, channels-last: up[b][(oy,ox)][c] ------------------------------------------
+// ---- bilinear x sf (the model's scale_factor: 2 as shipped), align_corners=False, channels-last: up[b][(oy,ox)][c] -------
+// source index as F.interpolate(scale_factor=sf) computes it (ATen area_pixel_compute_source_index with the scale 1 / sf
+// rounded to fp32): max(inv * (o + 0.5) - 0.5, 0); sf = 2 gives the constants of round 1 bit for bit, sf = 1 the identity
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ tok, int64_t strideb,
-                                                         float* __restrict__ up, int gh, int gw, int64_t total4) {
-    const int oh = 2 * gh, ow = 2 * gw, C4 = SM_EMBED / 4;
+                                                         float* __restrict__ up, int gh, int gw, int64_t total4, int sf, float inv) {
+    const int oh = sf * gh, ow = sf * gw, C4 = SM_EMBED / 4;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
         const int c = (int)(t % C4) * 4;
         const int64_t px = t / C4;
         const int ox = (int)(px % ow), oy = (int)((px / ow) % oh), b = (int)(px / ((int64_t)ow * oh));
-        float syf = 0.5f * (oy + 0.5f) - 0.5f, sxf = 0.5f * (ox + 0.5f) - 0.5f;
+        float syf = inv * (oy + 0.5f) - 0.5f, sxf = inv * (ox + 0.5f) - 0.5f;
         syf = syf < 0.f ? 0.f : syf;
         sxf = sxf < 0.f ? 0.f : sxf;
         const int y0 = (int)syf, x0 = (int)sxf;
@@ -131,12 +133,12 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 // einsum(Q, up(tok)) = up(einsum(Q, tok)): the GEMM runs on the gh x gw grid (4x fewer FLOPs, no 4n x 384 feature
 // map in HBM) and this kernel up-samples its (B, R, gh, gw) output with the same taps and weights as upsample2x_kernel.
 __global__ __launch_bounds__(256) void upsample2x_logits_kernel(const float* __restrict__ low, float* __restrict__ logits,
-                                                                float* __restrict__ prob, int gh, int gw, int64_t total) {
-    const int oh = 2 * gh, ow = 2 * gw;
+                                                                float* __restrict__ prob, int gh, int gw, int64_t total, int sf, float inv) {
+    const int oh = sf * gh, ow = sf * gw;
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
         const int ox = (int)(t % ow), oy = (int)((t / ow) % oh);
         const int64_t plane = t / ((int64_t)ow * oh);  // (b, r)
-        float syf = 0.5f * (oy + 0.5f) - 0.5f, sxf = 0.5f * (ox + 0.5f) - 0.5f;
+        float syf = inv * (oy + 0.5f) - 0.5f, sxf = inv * (ox + 0.5f) - 0.5f;
         syf = syf < 0.f ? 0.f : syf;
         sxf = sxf < 0.f ? 0.f : sxf;
         const int y0 = (int)syf, x0 = (int)sxf;
@@ -233,16 +235,33 @@ extern "C" int sm_pos_embed_bicubic_f32(const float* pos_in, int32_t g0, float* 
 }
 
 static int upsample_impl(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, void* stream,
-                         bool split) {
-    SM_REQUIRE(tok && up && B > 0 && gh > 0 && gw > 0 && strideb % 4 == 0, "sm_upsample2x_tokens_f32: bad arguments");
-    const int64_t total4 = (int64_t)B * 4 * gh * gw * (SM_EMBED / 4);
+                         bool split, int sf = 2) {
+    SM_REQUIRE(tok && up && B > 0 && gh > 0 && gw > 0 && strideb % 4 == 0 && sf >= 1 && sf <= 16, "sm_upsample_tokens: bad arguments");
+    const int64_t total4 = (int64_t)B * sf * sf * gh * gw * (SM_EMBED / 4);
+    const float inv = (float)(1.0 / sf);
     if (split)
         hipLaunchKernelGGL(sm::upsample2x_kernel<true>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, tok,
-                           strideb, up, gh, gw, total4);
+                           strideb, up, gh, gw, total4, sf, inv);
     else
         hipLaunchKernelGGL(sm::upsample2x_kernel<false>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, tok,
-                           strideb, up, gh, gw, total4);
-    return sm::check_launch("sm_upsample2x_tokens_f32");
+                           strideb, up, gh, gw, total4, sf, inv);
+    return sm::check_launch("sm_upsample_tokens");
+}
+extern "C" int sm_upsample_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, int32_t scale,
+                                      void* stream) {
+    return upsample_impl(tok, strideb, up, B, gh, gw, stream, false, scale);
+}
+extern "C" int sm_upsample_tokens_f16x2(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw, int32_t scale,
+                                        void* stream) {
+    return upsample_impl(tok, strideb, up, B, gh, gw, stream, true, scale);
+}
+extern "C" int sm_upsample_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh, int32_t gw,
+                                              int32_t scale, void* stream) {
+    SM_REQUIRE(low && prob && planes > 0 && gh > 0 && gw > 0 && scale >= 1 && scale <= 16, "sm_upsample_logits_sigmoid_f32: bad arguments");
+    const int64_t total = planes * scale * scale * gh * gw;
+    hipLaunchKernelGGL(sm::upsample2x_logits_kernel, dim3(sm::grid_for(total)), dim3(256), 0, (hipStream_t)stream, low, logits,
+                       prob, gh, gw, total, scale, (float)(1.0 / scale));
+    return sm::check_launch("sm_upsample_logits_sigmoid_f32");
 }
 extern "C" int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
                                         void* stream) {
@@ -255,11 +274,7 @@ extern "C" int sm_upsample2x_tokens_f16x2(const float* tok, int64_t strideb, flo
 
 extern "C" int sm_upsample2x_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh,
                                                 int32_t gw, void* stream) {
-    SM_REQUIRE(low && prob && planes > 0 && gh > 0 && gw > 0, "sm_upsample2x_logits_sigmoid_f32: bad arguments");
-    const int64_t total = planes * 4 * gh * gw;
-    hipLaunchKernelGGL(sm::upsample2x_logits_kernel, dim3(sm::grid_for(total)), dim3(256), 0, (hipStream_t)stream, low, logits,
-                       prob, gh, gw, total);
-    return sm::check_launch("sm_upsample2x_logits_sigmoid_f32");
+    return sm_upsample_logits_sigmoid_f32(low, logits, prob, planes, gh, gw, 2, stream);
 }
 
 extern "C" int sm_rowdot_sigmoid_f32(const float* h, const float* w, const float* b, float* out, int32_t rows,

@@ -75,7 +75,7 @@ class Weights(C.Structure):
                 ("dec_kv_w", fp), ("dec_kv_b", fp), ("gemm_mode", C.c_int32), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
                 ("n_dec_layers", C.c_int32), ("patch_s", C.c_float), ("ffn0_s", C.c_float), ("ffn1_s", C.c_float),
                 ("dec_kv_s", C.c_float), ("ffn2_s", C.c_float), ("mask_head_ffn", C.c_int32), ("normalize_before", C.c_int32),
-                ("no_objectness", C.c_int32)]
+                ("scale_factor", C.c_int32), ("no_objectness", C.c_int32)]
 
 
 class ForwardIO(C.Structure):
@@ -143,6 +143,9 @@ SYMBOLS = {
     "sm_pos_embed_bicubic_f32": (C.c_int, [fp, C.c_int32, fp, C.c_int32, C.c_int32, fp]),
     "sm_upsample2x_tokens_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_upsample2x_logits_sigmoid_f32": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, fp]),
+    "sm_upsample_tokens_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_upsample_tokens_f16x2": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_upsample_logits_sigmoid_f32": (C.c_int, [fp, fp, fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_rowdot_sigmoid_f32": (C.c_int, [fp, fp, fp, fp, C.c_int32, fp]),
     "sm_query_mean_f32": (C.c_int, [fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_preprocess_resize_u8": (C.c_int, [fp, fp, fp, fp, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
@@ -153,6 +156,9 @@ SYMBOLS = {
     "sm_pick_mask_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_vote_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sm_vote_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "sm_upsample_tokens_aligned_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
+    "sm_kmeans_f32": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp]),
+    "sm_labels_to_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp]),
     "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),

@@ -179,3 +179,22 @@ class DecodePool:
 
     def __del__(self):
         self.close()
+
+
+_SHARED = {}
+_SHARED_LOCK = threading.Lock()
+
+
+def shared_pool(workers: Optional[int] = None) -> DecodePool:
+    """A process-wide pool per worker count, started on first use and closed at interpreter exit: an evaluation of a few hundred
+    images must not pay the start of 15 Python processes (~0.15 s) every call.  ``decode_batch`` is thread-safe."""
+    import atexit
+    n = workers or default_workers()
+    with _SHARED_LOCK:
+        pool = _SHARED.get(n)
+        if pool is None or pool._closed or any(p.poll() is not None for p in pool._procs):
+            if pool is not None:
+                pool.close()
+            pool = _SHARED[n] = DecodePool(n)
+            atexit.register(pool.close)
+        return pool

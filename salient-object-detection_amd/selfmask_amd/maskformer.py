@@ -130,8 +130,8 @@ class MaskFormer(nn.Module):
                                       f"(resnet50 backbones are out of scope, SURVEY.md section 2 #11)")
         if patch_size not in (8, 16):
             raise ValueError(f"patch_size={patch_size}: ViT-S/8 and ViT-S/16 are supported")
-        if scale_factor != 2:
-            raise NotImplementedError("scale_factor != 2 is not used by the shipped config and not implemented")
+        if int(scale_factor) != scale_factor or not 1 <= scale_factor <= 16:
+            raise ValueError(f"scale_factor={scale_factor}: an integer 1..16 (maskformer.py:161 passes it to F.interpolate)")
         # learnable_pixel_decoder is stored and never read by the reference's forward (maskformer.py:71,144-162): accepted,
         # no effect.  lateral_connection=True is accepted here as there and fails in forward as there (see forward()).
         if not 1 <= n_decoder_layers <= N.MAX_DEC_LAYERS:
@@ -151,7 +151,7 @@ class MaskFormer(nn.Module):
         self.use_binary_classifier = use_binary_classifier
         self.lateral_connection = lateral_connection
         self.learnable_pixel_decoder = learnable_pixel_decoder
-        self.scale_factor = scale_factor
+        self.scale_factor = int(scale_factor)
         self.normalize_before = bool(normalize_before)  # TransformerDecoderLayer.forward_pre (transformer_decoder.py:299-327)
         self.return_intermediate = return_intermediate
         self.n_queries = n_queries
@@ -262,6 +262,7 @@ class MaskFormer(nn.Module):
         (w.dec_kv_w, w.dec_kv_s), w.dec_kv_b = gws("dec_kv", packed["dec_kv_w"]), packed["dec_kv_b"].data_ptr()
         w.gemm_mode = 3 if self.gemm_mode == "f16" else 2 if w16 else (1 if split else 0)
         w.normalize_before = 1 if self.normalize_before else 0
+        w.scale_factor = self.scale_factor
         self._packed = packed
         w.patch = e.patch_size
         w.pos_grid = int(round((e.pos_embed.shape[1] - 1) ** 0.5))
@@ -304,8 +305,8 @@ class MaskFormer(nn.Module):
     def forward(self, x: torch.Tensor, encoder_only: bool = False, skip_decoder: bool = False,
                 return_logits: bool = False, workspace: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """x: (B,3,H,W) normalised image on a HIP device.  Output dict as maskformer.py:240-251:
-        5-D path -> {"objectness" (B,L,nq,1), "mask_pred" (B,L,nq,2gh,2gw) in [0,1], "features" (B,384)};
-        3-D path (return_intermediate=False, use_binary_classifier=False) -> {"mask_pred" logits (B,nq,2gh,2gw),
+        5-D path -> {"objectness" (B,L,nq,1), "mask_pred" (B,L,nq,s gh,s gw) in [0,1] (s = scale_factor), "features" (B,384)};
+        3-D path (return_intermediate=False, use_binary_classifier=False) -> {"mask_pred" logits (B,nq,s gh,s gw),
         "features"}.  ``return_logits`` additionally returns the pre-sigmoid einsum as "mask_logits" and the decoder
         queries / encoder patch tokens (parity taps)."""
         if not x.is_cuda:
@@ -342,7 +343,8 @@ class MaskFormer(nn.Module):
             return {"patch_tokens": tokens.view(B, gh, gw, N.EMBED)}
         Lm = L if self.return_intermediate else 1  # the 3-D path only builds the last layer's masks (maskformer.py:219-220)
         io.last_layer_only = 0 if self.return_intermediate else 1
-        mask_pred = torch.empty((B, Lm, nq, 2 * gh, 2 * gw), device=dev, dtype=torch.float32)
+        sf = self.scale_factor
+        mask_pred = torch.empty((B, Lm, nq, sf * gh, sf * gw), device=dev, dtype=torch.float32)
         objectness = torch.empty((B, L, nq, 1), device=dev, dtype=torch.float32)
         features = torch.empty((B, N.EMBED), device=dev, dtype=torch.float32)
         io.mask_pred, io.objectness, io.features = mask_pred.data_ptr(), objectness.data_ptr(), features.data_ptr()

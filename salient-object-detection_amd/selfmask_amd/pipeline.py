@@ -305,15 +305,14 @@ class PrefetchingLoader:
         if not batches:
             return
         if self.decode == "process":
-            from .decode_pool import BatchSlots, DecodePool
-            dpool, slots = DecodePool(self.workers), BatchSlots(self.depth + 1, max(len(b) for b in batches))
+            from .decode_pool import BatchSlots, shared_pool
+            dpool, slots = shared_pool(self.workers), BatchSlots(self.depth + 1, max(len(b) for b in batches))
             try:
                 def submit(k):  # -> callable returning (rgb views, GT views) inside shared slot k % (depth + 1)
                     return dpool.decode_batch(slots, k % (self.depth + 1), [(self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]])
                 yield from self._run(batches, submit)
             finally:
-                dpool.close()
-                slots.close()
+                slots.close()  # (the worker processes stay: shared_pool keeps them for the next loader)
             return
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
             def submit(k):

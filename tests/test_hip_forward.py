@@ -313,6 +313,34 @@ def test_3d_path_values_match_reference_vectors(mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
+def test_scale_factor_1_and_4_match_reference_vectors(mode):
+    """scale_factor (maskformer.py:23,161; YAML key): F.interpolate(scale_factor=s) in the pixel decoder - s = 1 and 4 against the
+    REAL reference's outputs (tests/golden/scalefactor_p16_calib.npz): a grid whose einsum commutes with the up-sampling
+    (14 x 12 tokens) and one that takes the literal order (14 x 13)."""
+    g = np.load(os.path.join(GOLD, "scalefactor_p16_calib.npz"))
+    patch, B, wseed, xseed, _ = [int(v) for v in g["meta"]]
+    for tag in [str(t) for t in g["cases"]]:
+        hw, sf = tag.split("_sf")
+        Hh, Ww = (int(v) for v in hw.split("x"))
+        m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True,
+                       scale_factor=int(sf), gemm_mode=mode)
+        m.load_state_dict(synthetic_state_dict(wseed, str(g["style"]), patch_size=patch), strict=True)
+        x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww))).to(DEV)
+        out = m.to(DEV)(x, return_logits=True)
+        assert out["mask_pred"].shape == (B, 6, 20, int(sf) * Hh // patch, int(sf) * Ww // patch)
+        d32 = np.abs(out["mask_logits"][:, -1].cpu().numpy() - g[f"logits_last_{tag}"]).max()
+        d64 = np.abs(out["mask_logits"][:, -1].cpu().numpy() - g[f"logits_last_f64_{tag}"]).max()
+        ref64 = float(g[f"f32_vs_f64_maxabs_{tag}"])
+        ledger.record("forward_scale_factor", f"{tag}|{mode}", {"hip_minus_ref32": float(d32), "hip_minus_ref64": float(d64),
+                                                                 "ref32_minus_ref64": ref64, "rule": "hip-ref32 <= 1e-4"})
+        assert ref64 <= STRICT_BELOW and d32 <= ABS_TOL and d64 <= max(ref64, 0.5 * ABS_TOL), (tag, d32, d64)
+        assert np.abs(out["objectness"].cpu().numpy() - g[f"objectness_{tag}"]).max() <= 2e-5
+        assert np.abs(out["features"].cpu().numpy() - g[f"features_{tag}"]).max() <= 5e-5
+    with pytest.raises(ValueError):
+        MaskFormer(n_queries=20, patch_size=16, scale_factor=0)
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_forward_ffn_mask_head_matches_reference(mode):
     """return_intermediate=True with use_binary_classifier=False (maskformer.py:59-66,225): the mask einsum takes
     ffn(queries), the dict has no objectness - against the REAL reference's output (tests/golden/ffnhead_*.npz)."""

@@ -106,3 +106,21 @@ def test_oracle_prenorm_decoder_matches_reference_vectors():
     o64 = O.forward(x.double(), O.cast_state(sd, torch.float64), patch, normalize_before=True)
     assert np.abs(o64["mask_logits"].numpy() - g["mask_logits_f64"]).max() <= 1e-10
 
+
+
+def test_oracle_scale_factor_matches_reference_vectors():
+    """scale_factor 1 and 4 (maskformer.py:23,161) against the real reference's outputs (tests/golden/scalefactor_*.npz)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "scalefactor_p16_calib.npz"))
+    patch, B, wseed, xseed, nthreads = [int(v) for v in g["meta"]]
+    torch.set_num_threads(min(nthreads, os.cpu_count() or 1))
+    sd = synthetic_state_dict(wseed, str(g["style"]), patch_size=patch)
+    for tag in [str(t) for t in g["cases"]]:
+        hw, sf = tag.split("_sf")
+        Hh, Ww = (int(v) for v in hw.split("x"))
+        x = torch.from_numpy(synthetic_images(xseed, (B, 3, Hh, Ww)))
+        out = O.forward(x, sd, patch, scale_factor=int(sf))
+        assert out["mask_logits"].shape[-2:] == (int(sf) * Hh // patch, int(sf) * Ww // patch)
+        assert np.abs(out["mask_logits"][:, -1].numpy() - g[f"logits_last_{tag}"]).max() <= 2e-6 * float(g[f"logit_absmax_{tag}"]) + 1e-6
+        assert np.abs(out["objectness"].numpy() - g[f"objectness_{tag}"]).max() <= 2e-6
+        o64 = O.forward(x.double(), O.cast_state(sd, torch.float64), patch, scale_factor=int(sf))
+        assert np.abs(o64["mask_logits"][:, -1].numpy() - g[f"logits_last_f64_{tag}"]).max() <= 1e-10

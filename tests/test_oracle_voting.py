@@ -48,3 +48,23 @@ def test_vote_known_answers(name):
     assert best == want_best and new_to_prev == want_map
     assert np.array_equal(best_mask.numpy(), masks[want_map[want_best]])
     assert np.array_equal(table.numpy(), np.asarray(want_table, np.float32))
+
+
+def test_cluster_oracle_against_sklearn_and_one_hot_semantics():
+    """oracle/cluster_oracle.py (the checker of csrc/cluster.hip; the reference's own clusterer is absent: parity unpinned):
+    Lloyd from farthest-point centres lands on scikit-learn's partition from the same centres; the one-hot / nearest step
+    reproduces to_one_hot (utils/misc.py:10-35) + F.interpolate(mode="nearest")."""
+    from sklearn.cluster import KMeans
+    from oracle import cluster_oracle as CO
+    rng = np.random.Generator(np.random.PCG64(1))
+    for k in (2, 3, 4):
+        c = rng.standard_normal((k, 384)).astype(np.float32) * 2
+        lab = rng.integers(0, k, 500)
+        x = (c[lab] + rng.standard_normal((500, 384)).astype(np.float32) * 0.35).astype(np.float32)
+        got, _ = CO.kmeans(x, k, 20)
+        sk = KMeans(n_clusters=k, init=x[CO.farthest_point_init(x, k)], n_init=1, algorithm="lloyd", max_iter=20, tol=0.0).fit(x)
+        assert (sk.labels_ == got).mean() >= 0.999
+    labels = torch.tensor([[0, 2], [1, 2]], dtype=torch.int32)
+    m = CO.to_one_hot_masks(labels, 3, 2, 3, 4)
+    assert m.shape == (3, 3, 4) and m.sum(0).eq(1).all()
+    assert m[2].tolist() == [[0, 0, 1, 1], [0, 0, 1, 1], [0, 0, 1, 1]] and m[1].tolist() == [[0, 0, 0, 0], [0, 0, 0, 0], [1, 1, 0, 0]]
