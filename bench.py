@@ -200,9 +200,7 @@ def end_to_end(model, dev, P, S, B, streams, n_images=768, world=1, rank=0):
             pass
         dt_thr = time.perf_counter() - t1
         if world > 1:
-            t = torch.tensor([dt, dt_dec], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, dt_dec = t.tolist()
+            dt, dt_dec = max_over_ranks([dt, dt_dec], dev)
         out = {"end_to_end_images_per_sec": round(n_images / dt, 1), "images": n_images, "distinct_files": distinct * world, "ranks": world,
                "decode_workers_per_rank": default_workers(), "decode": "worker processes + shared memory (decode_pool.py)",
                "host_decode_only_images_per_sec": round(n_images / dt_dec, 1),
@@ -415,6 +413,25 @@ def throughput_mode_leg(dev, ref, steps=30, warmup=6):
     return res
 
 
+def _gloo() -> bool:
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def all_gather_rows(rows: torch.Tensor, world: int) -> torch.Tensor:
+    """the path's one exchange: all-gather of the per-image result rows - RCCL on device tensors; on host copies
+    under the gloo rehearsal (SM_BENCH_REHEARSAL=1)"""
+    src = rows.cpu() if _gloo() else rows
+    out = torch.empty((world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src)
+    return out
+
+
+def max_over_ranks(values, dev) -> list:
+    t = torch.tensor(list(values), dtype=torch.float64, device="cpu" if _gloo() else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.tolist()
+
+
 def spawn_ranks(n: int, argv) -> int:
     """Start `n` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and
     wait for them.  The parent never touches the GPU: ranks are fresh processes, nothing is exec'ed after HIP init."""
@@ -499,6 +516,7 @@ def main():
                          "activity in the matrix cores; how far the result rises above the metric is how power-limited it is")
     ap.add_argument("--gemm-mode", default=None, choices=["w16", "f16x2", "fp32", "f16"],
                     help="GEMM back end (default w16; f16 = the one-MFMA-per-product diagnostic, not the metric)")
+    ap.add_argument("--e2e-ranks", action="store_true", help="with --gpus N > 1: also run the end-to-end leg (files -> metrics) on all N ranks")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the ViT-S/8 224^2 and ViT-S/16 384^2 legs")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, no GPU): same spawn, barrier, gather and "
@@ -523,8 +541,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         from selfmask_amd.distributed import pin_rank_cores
         pin_rank_cores()  # this rank's block of the host's cores: its decode workers inherit the affinity
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
+        if os.environ.get("SM_BENCH_REHEARSAL") == "1":
+            # logic rehearsal where only ONE GPU exists: every rank on cuda:0, gloo instead of RCCL (collectives on host copies)
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))  # nccl == RCCL on ROCm
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     else:
         torch.cuda.set_device(0)
@@ -552,14 +576,11 @@ def main():
     run_steps(a.steps, rows)
     t_enqueued = time.perf_counter() - t0  # host time to issue the K steps (launch-bound if close to dt)
     if world > 1:  # the path's one exchange: all-gather of the per-image rows
-        gathered = torch.empty((world * rows.shape[0], 16), device=dev)
-        dist.all_gather_into_tensor(gathered, rows)
+        gathered = all_gather_rows(rows, world)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt = max_over_ranks([dt], dev)[0]
 
     # per-kernel taps right behind the timed steps (same clocks / cache state as the K steps; agreement with rocprofv3's
     # kernel-trace averages of the same command is checked in profiles/)
@@ -574,14 +595,16 @@ def main():
         sync()
         ds_ = time.perf_counter() - t1
         if world > 1:
-            t = torch.tensor([ds_], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ds_ = t.item()
+            ds_ = max_over_ranks([ds_], dev)[0]
         sustained = {"steps": a.sustained_steps, "value": round(world * a.sustained_steps * B / ds_, 1), "unit": "images/sec",
                      "ms_per_step": round(ds_ / a.sustained_steps * 1e3, 3)}
 
-    # end to end (files -> metrics): every rank takes part (the Evaluator shards the files and gathers the rows over RCCL)
-    e2e = end_to_end(model, dev, P, S, B, len(ring.streams), world=world, rank=rank) if not a.quick else None
+    # end to end (files -> metrics).  With several ranks every rank takes part (the Evaluator shards the files and gathers the rows
+    # over RCCL) - opt-in there (--e2e-ranks): the driver's scaling runs measure the contract's K steps, and a leg that walks a
+    # file tree on N ranks has no place inside them
+    e2e = None
+    if not a.quick and (world == 1 or a.e2e_ranks):
+        e2e = end_to_end(model, dev, P, S, B, len(ring.streams), world=world, rank=rank)
 
     if rank == 0:
         value = world * a.steps * B / dt

@@ -383,6 +383,9 @@ __device__ int g_gemm_stamp_filter[3];  // (N, K, M) of the launches that stamp;
 #ifndef SM_GEMM_LOADH
 #define SM_GEMM_LOADH 0
 #endif
+#ifndef SM_GEMM_LATE_HALF
+#define SM_GEMM_LATE_HALF 0
+#endif
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS, int TERMS = 3>
 __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gemm_args g) {
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
@@ -467,7 +470,12 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt == 0) GEMM_STAMP(1);
-        issue_step(kt);
+        // Rings of three have a whole K-tile of slack (the pieces issued now feed tile kt + 2), so with SM_GEMM_LATE_HALF the second
+        // half of the waves issues its pieces AFTER its MFMAs: every wave leaves the barrier together, and with all of them in the
+        // issue queue of the CU's one address unit first, the matrix pipe idled ~500 cycles at the top of every K-tile
+        constexpr bool LATE = SM_GEMM_LATE_HALF && NST >= 3 && NW >= 8;
+        const bool late = LATE && wave >= NW / 2;
+        if (!late) issue_step(kt);
         const char* sta = smemm + (kt % NST) * A_STAGE + a_base;
         const char* stw = smemm + W_RING + (kt % NST) * W_STAGE + w_base;
         // Register plan: the W fragments of the step stay live (TN x 12 registers), the A fragments come in blocks of at most
@@ -505,6 +513,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (late) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_step(kt);
+        }
     }
     wait_vmcnt_w<0>();
     GEMM_STAMP(2);

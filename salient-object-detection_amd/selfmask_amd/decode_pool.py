@@ -41,21 +41,22 @@ def _cgroup_cpus() -> Optional[float]:
 
 
 def default_workers() -> int:
-    """Cores this rank may use for decoding: min(CPU affinity, the container's CPU quota) divided among the ranks of the node
-    (LOCAL_WORLD_SIZE), one left for the main thread; at most 32.  SM_DECODE_WORKERS overrides."""
+    """Cores this rank may use for decoding, one left for the main thread, at most 32: its share of the CPU affinity (already
+    narrowed to the rank by distributed.pin_rank_cores, or divided by LOCAL_WORLD_SIZE here) and of the container's CPU
+    quota (always divided: the quota is the node's).  SM_DECODE_WORKERS overrides."""
     if os.environ.get("SM_DECODE_WORKERS"):
         return max(1, int(os.environ["SM_DECODE_WORKERS"]))
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 4
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    if os.environ.get("SM_RANK_CORES_PINNED") != "1":
+        n = max(1, n // local_world)
     q = _cgroup_cpus()
     if q is not None:
-        n = max(1, min(n, int(q)))
-    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    if os.environ.get("SM_RANK_CORES_PINNED") == "1":  # distributed.pin_rank_cores already narrowed the affinity to this rank
-        local_world = 1
-    return max(1, min(32, n // local_world - (1 if n // local_world > 2 else 0)))
+        n = max(1, min(n, int(q) // local_world))
+    return max(1, min(32, n - (1 if n > 2 else 0)))
 
 
 class BatchSlots:

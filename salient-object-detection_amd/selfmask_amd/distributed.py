@@ -52,9 +52,12 @@ class TorchDistComm:
 
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         # concatenated along dim 0 (the layout both the nccl/RCCL and the gloo backends accept), viewed as stacked
-        out = torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-        return out.view((self.world_size,) + tuple(t.shape))
+        src = t.contiguous()
+        if src.is_cuda and self.dist.get_backend(self.group) == "gloo":  # gloo gathers host tensors (CPU tests, one-GPU rehearsals)
+            src = src.cpu()
+        out = torch.empty((self.world_size * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        self.dist.all_gather_into_tensor(out, src, group=self.group)
+        return out.view((self.world_size,) + tuple(t.shape)).to(t.device)
 
 
 class SingleComm:
