@@ -76,6 +76,16 @@ typedef struct sm_gemm_args {
     float ln_eps;
     float w_scale;         /* sm_gemm_w16 only: 2^-s of the W16 weight tensor (sm_split_w16 scale = 2^s); the accumulator
                               is multiplied by it before the bias                                                       */
+    /* sm_gemm_w16 only - LayerNorm folded into the neighbouring GEMMs (vision_transformer.py:164-170: x + proj(...) -> norm2 -> fc1,
+     * x + fc2(...) -> next norm1 -> qkv) instead of a launch of its own:
+     *   producer (SM_EPI_RESIDUAL, N = 384): C2 = the F16X2 copy of the new residual stream (row stride ldc), ln_stats_out =
+     *     (rows, 12, 2) floats: (mean, M2) of every 32-column segment of every row, written in a fixed order;
+     *   consumer (BIAS / GELU / RELU, K = 384): A = that raw F16X2 stream, W = the weight times the norm's gain (W16), bias =
+     *     b + W beta, ln_c = row sums of W' (N floats), ln_stats = the producer's statistics, ln_eps: the epilogue evaluates
+     *     LN(x) W^T + b = r (x W'^T - mu c) + b'. */
+    const float* ln_stats;
+    const float* ln_c;
+    float* ln_stats_out;
     int32_t mfma_terms;    /* sm_gemm_w16 only: 0 or 3 = the fp32-grade product (three f16 MFMAs per 32-k step); 1 = "throughput
                               mode" (SURVEY.md 7.2 (b)): hi x hi only, plain f16 operands, fp32 accumulate - a diagnostic of the
                               kernel structure without the x3, two orders of magnitude outside the 1e-4 gate, never the metric */
@@ -188,6 +198,9 @@ typedef struct sm_qkv_attn_args {
     float scale;        /* softmax scale: head_dim ** -0.5 = 0.125 (vision_transformer.py:104) */
     int32_t out_f16x2;
     int32_t mfma_terms; /* 0 or 3: fp32-grade products; 1: throughput-mode diagnostic (hi x hi only), see sm_gemm_args */
+    const float* ln_stats; /* non-NULL: LayerNorm (norm1) folded into the projection, as sm_gemm_args.ln_stats: Xn is the RAW F16X2   */
+    const float* ln_c;     /*   residual stream, Wqkv carries the gain, bias = b + W beta, ln_c = the 1152 row sums of W'             */
+    float ln_eps;
 } sm_qkv_attn_args;
 int sm_qkv_attention_w16(const sm_qkv_attn_args* args, void* stream);
 int sm_qkv_attention_max_tokens(void);
@@ -362,7 +375,12 @@ int sm_bilateral_solver_batch_f64(const sm_bilateral_args* args, int32_t n_image
 typedef struct sm_enc_layer {
     const float *norm1_w, *norm1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *norm2_w, *norm2_b, *fc1_w, *fc1_b, *fc2_w,
         *fc2_b;
+    /* sm_weights.ln_fold (gemm_mode 2 / 3): the pre-norms folded into the GEMMs they feed (sm_gemm_args.ln_stats): W16 copies of
+     * qkv.weight * norm1.weight and fc1.weight * norm2.weight (gain along the input dimension), the folded biases b + W beta, and
+     * the row sums c of the gain-scaled weights AS ROUNDED to W16 (so that x W'^T - mu c cancels what the MFMAs summed) */
+    const float *qkv_fw, *qkv_fb, *qkv_c, *fc1_fw, *fc1_fb, *fc1_c;
     float qkv_s, proj_s, fc1_s, fc2_s; /* gemm_mode 2: 2^-s of the W16 copies (sm_split_w16); unused otherwise */
+    float qkv_fs, fc1_fs;              /* 2^-s of qkv_fw / fc1_fw */
 } sm_enc_layer;
 
 typedef struct sm_dec_layer {
@@ -409,6 +427,11 @@ typedef struct sm_weights {
     int32_t normalize_before; /* 1: TransformerDecoderLayer.forward_pre in every decoder layer (transformer_decoder.py:299-327):
                                  each sub-block normalises its input, the residual stream is only normalised by the shared
                                  decoder.norm; 0 (the shipped config): forward_post (:260-297) */
+    int32_t ln_fold;          /* gemm_mode 2 / 3: 1 = the *_fw / *_fb / *_c fields of every encoder layer are filled, and forwards on the
+                                 small-batch path (sm_forward_io.attn_path) let the encoder's pre-norms ride on the GEMMs around them:
+                                 23 of the 25 encoder LayerNorm launches disappear (norm2 of every block into proj -> fc1, norm1 of
+                                 blocks 1..11 into fc2 -> qkv; block 0's norm1 and the final norm stay launches).  Same results to
+                                 rounding (other summation order of the statistics) */
     int32_t scale_factor;     /* the pixel decoder's up-sampling factor (maskformer.py:23,161; YAML key scale_factor): 0 or 2 = the
                                  shipped x2, any 1..16 accepted; masks are (scale gh) x (scale gw) */
     int32_t no_objectness;    /* 1: use_binary_classifier=False without the mask head (the 3-D path, maskformer.py:219-220): the
@@ -425,10 +448,12 @@ typedef struct sm_forward_io {
     float* queries;     /* (B,L,nq,384) decoder outputs after decoder.norm, or NULL (debug/parity tap)           */
     float* patch_tokens;/* (B,gh*gw,384) final-LN'd encoder tokens, or NULL (debug/parity tap; encoder_only)     */
     int32_t encoder_only;
-    int32_t attn_path;       /* encoder attention in gemm_mode 2/3 on token grids <= 208: 0 = by batch size (the fused QKV + attention
-                                kernel from B >= 16 up, the qkv GEMM + attention pair below: the faster one each), 1 = fused whenever
-                                the grid allows, 2 = always the pair.  The two paths differ in the last bits (other summation
-                                order): a caller that needs bit-identical results across batch sizes pins one (the Evaluator does) */
+    int32_t attn_path;       /* which encoder kernels run (gemm_mode 2/3): 0 = by batch size - from B >= 16 up the LARGE-batch set
+                                (fused QKV + attention kernel on token grids <= 208, LayerNorm as launches), below it the SMALL-batch
+                                set (qkv GEMM + attention pair, pre-norms folded into the GEMMs around them when sm_weights.ln_fold):
+                                the faster one each; 1 = always the large-batch set, 2 = always the small-batch set.  The two sets
+                                differ in the last bits (other summation orders): a caller that needs bit-identical results across
+                                batch sizes pins one (the Evaluator does) */
     int32_t last_layer_only; /* 1: return_intermediate=False (maskformer.py:219-220) - only the last decoder layer reaches the mask
                                 einsum; mask_logits / mask_pred are then (B,1,nq,2gh,2gw).  features / queries keep all L layers */
 } sm_forward_io;

@@ -60,7 +60,7 @@ static Shape make_shape(const sm_weights* w, int B, int H, int W) {
 // workspace carve-up (floats, every region 256-B aligned)
 struct Ws {
     float *pos, *X, *Xn, *QKV, *AO, *HID, *TOK, *TOKs, *KV, *UP, *TGT, *TGTs, *TGTQ, *T2, *QK, *Qc, *AOd, *HIDd, *PART, *QD,
-        *QDs, *LOG, *O1, *O2;
+        *QDs, *LOG, *O1, *O2, *ST;
     size_t total;
 };
 
@@ -99,6 +99,7 @@ static Ws carve(const Shape& s, float* base) {
     w.LOG = take(s.Mo * s.sf * s.sf * s.n);
     w.O1 = take(s.Mo * D);              // (S)
     w.O2 = take(s.Mo * D);
+    w.ST = take(s.M * 24);              // folded LayerNorm: (mean, M2) of the twelve 32-column segments of every token row
     w.total = off * sizeof(float);
     return w;
 }
@@ -113,12 +114,20 @@ struct Ctx {
 // `ws` = the weight tensor's 2^-s (W16 mode; 0 = W is not a W16 weight: an activation operand, or another mode)
 static int gemm(const Ctx& c, const sm_gemm_args& g, bool out_s = false);
 // C = epilogue(A W^T + b); in split mode A and W are F16X2 / W16 and `out_s` asks for an F16X2 C
+struct Fold {  // LayerNorm folded into the GEMMs around it (sm_gemm_args.ln_stats / ln_stats_out)
+    const float* stats = nullptr;  // consumer: the producer's row statistics ...
+    const float* cvec = nullptr;   // ... and the row sums of the gain-scaled weight
+    float eps = 0.f;
+    float* xs = nullptr;           // producer (RESIDUAL): F16X2 copy of the new residual stream ...
+    float* stats_out = nullptr;    // ... and its row statistics
+};
 static int linear(const Ctx& c, const float* A, int lda, const float* W, float ws, const float* b, float* C, int ldc, int64_t M,
-                  int N, int K, int epi, const float* R, int ldr, bool out_s = false) {
+                  int N, int K, int epi, const float* R, int ldr, bool out_s = false, const Fold& f = Fold()) {
     sm_gemm_args g = {};
     g.A = A; g.W = W; g.bias = b; g.C = C; g.R = R;
     g.M = (int)M; g.N = N; g.K = K; g.lda = lda; g.ldw = K; g.ldc = ldc; g.ldr = ldr;
     g.batch = 1; g.epilogue = epi; g.w_scale = ws;
+    g.ln_stats = f.stats; g.ln_c = f.cvec; g.ln_eps = f.eps; g.C2 = f.xs; g.ln_stats_out = f.stats_out;
     return gemm(c, g, out_s);
 }
 static bool use_w16(const Ctx& c, const sm_gemm_args& g) { return c.W16 && g.w_scale > 0.f; }
@@ -277,20 +286,35 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
 #else
     constexpr int ablate_ln = 0;
 #endif
+    // sm_weights.ln_fold: norm2 rides on proj -> fc1 and the next block's norm1 on fc2 -> qkv: the residual epilogues also write the
+    // raw stream as F16X2 (into Xn) with its row statistics, the consuming GEMM carries the gain in its weights and applies
+    // r (x W'^T - mu c) + b' in its epilogue.  Block 0's norm1 (its input comes from the patch embedding) stays a launch.
+    // Measured (profiles/r03_ln_fold_ab.log): the fold wins where the forward is latency-bound (B = 1: 1.24 -> 1.20 ms, B = 8: 1.45 -> 1.34)
+    // and loses where it is throughput-bound (B = 64, three streams: 21.55k -> 21.3k images/s: the extra F16X2 stream of the residual
+    // epilogues and the statistics cost more than 23 co-resident LayerNorm launches) - so it follows the same batch rule and the same
+    // pin as the attention path (sm_forward_io.attn_path: 2 = the small-batch kernels, 1 = the large-batch ones).
+    const bool lnf = c.W16 && w->ln_fold != 0 && io->attn_path != 1 && (io->attn_path == 2 || s.B * SM_HEADS < 96);
     if (fuse_fc2) TRY(ln(c, ws.X, w->enc[0].norm1_w, w->enc[0].norm1_b, nullptr, s.M, 1e-6f, xs));
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
-        if (!fuse_fc2 && !(ablate_ln && i > 0)) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        const bool f1 = lnf && i > 0;  // this block's norm1 is folded into its qkv projection
+        if (!fuse_fc2 && !f1 && !(ablate_ln && i > 0)) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        Fold fq;
+        if (f1) { fq.stats = ws.ST; fq.cvec = e.qkv_c; fq.eps = 1e-6f; }
+        const float* qkv_w = f1 ? e.qkv_fw : e.qkv_w;
+        const float* qkv_b = f1 ? e.qkv_fb : e.qkv_b;
+        const float qkv_s = f1 ? e.qkv_fs : e.qkv_s;
         if (fused_qkv) {
             sm_qkv_attn_args q = {};
-            q.Xn = ws.Xn; q.Wqkv = e.qkv_w; q.bias = e.qkv_b; q.O = ws.AO; q.ldx = D; q.ldo = D;
-            q.B = s.B; q.N = s.N; q.w_scale = e.qkv_s; q.scale = 0.125f; q.out_f16x2 = 1; q.mfma_terms = c.terms;
+            q.Xn = ws.Xn; q.Wqkv = qkv_w; q.bias = qkv_b; q.O = ws.AO; q.ldx = D; q.ldo = D;
+            q.B = s.B; q.N = s.N; q.w_scale = qkv_s; q.scale = 0.125f; q.out_f16x2 = 1; q.mfma_terms = c.terms;
+            q.ln_stats = fq.stats; q.ln_c = fq.cvec; q.ln_eps = fq.eps;
             // algorithmic work of SURVEY.md 8d: 2 N 384 1152 + 4 N^2 384 FLOPs, x in + o out bytes per image
             TapScope tap(c.st, sm_qkv_attention_kernel_name(), (double)s.B * (2.0 * s.N * D * 3 * D + 4.0 * s.N * s.N * D),
                          2.0 * s.M * D * 4);
             TRY(sm_qkv_attention_w16(&q, c.st));
         } else {
-            TRY(linear(c, ws.Xn, D, e.qkv_w, e.qkv_s, e.qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S));
+            TRY(linear(c, ws.Xn, D, qkv_w, qkv_s, qkv_b, ws.QKV, 3 * D, s.M, 3 * D, D, SM_EPI_BIAS, nullptr, 0, S, fq));
             sm_attn_args a = {};
             a.Q = ws.QKV; a.K = ws.QKV + D; a.V = ws.QKV + 2 * D; a.O = ws.AO;
             a.sQb = a.sKb = a.sVb = (int64_t)s.N * 3 * D; a.sQr = a.sKr = a.sVr = 3 * D;
@@ -301,15 +325,22 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         if (fuse_proj) {
             TRY(linear_residual_ln(c, ws.AO, D, e.proj_w, e.proj_b, ws.X, s.M, D, e.norm2_w, e.norm2_b, 1e-6f, ws.Xn));
         } else {
-            TRY(linear(c, ws.AO, D, e.proj_w, e.proj_s, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D));
-            if (!ablate_ln) TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+            Fold fp;
+            if (lnf) { fp.xs = ws.Xn; fp.stats_out = ws.ST; }
+            TRY(linear(c, ws.AO, D, e.proj_w, e.proj_s, e.proj_b, ws.X, D, s.M, D, D, SM_EPI_RESIDUAL, ws.X, D, false, fp));
+            if (!lnf && !ablate_ln) TRY(ln(c, ws.X, e.norm2_w, e.norm2_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         }
-        TRY(linear(c, ws.Xn, D, e.fc1_w, e.fc1_s, e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D, SM_EPI_GELU, nullptr, 0, S));
+        Fold f2;
+        if (lnf) { f2.stats = ws.ST; f2.cvec = e.fc1_c; f2.eps = 1e-6f; }
+        TRY(linear(c, ws.Xn, D, lnf ? e.fc1_fw : e.fc1_w, lnf ? e.fc1_fs : e.fc1_s, lnf ? e.fc1_fb : e.fc1_b, ws.HID, SM_MLP, s.M, SM_MLP, D,
+                   SM_EPI_GELU, nullptr, 0, S, f2));
         if (fuse_fc2 && i + 1 < SM_ENC_DEPTH) {
             const sm_enc_layer& nx = w->enc[i + 1];
             TRY(linear_residual_ln(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, s.M, SM_MLP, nx.norm1_w, nx.norm1_b, 1e-6f, ws.Xn));
         } else {
-            TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_s, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D));
+            Fold fo;
+            if (lnf && i + 1 < SM_ENC_DEPTH) { fo.xs = ws.Xn; fo.stats_out = ws.ST; }
+            TRY(linear(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_s, e.fc2_b, ws.X, D, s.M, D, SM_MLP, SM_EPI_RESIDUAL, ws.X, D, false, fo));
         }
     }
     // final norm on the last layer only (the other 11 per-layer norms of :299 are dead work when
@@ -526,6 +557,13 @@ static int validate(const sm_weights* w, const sm_forward_io* io) {
             ok = pow2(d.sa_in_s) && pow2(d.sa_out_s) && pow2(d.ca_in_s) && pow2(d.ca_out_s) && pow2(d.lin1_s) && pow2(d.lin2_s);
         }
         SM_REQUIRE(ok, "sm_maskformer_forward: gemm_mode 2/3 needs every weight's 2^-s (*_s fields) to be a positive power of two");
+        if (w->ln_fold) {
+            for (int i = 0; i < SM_ENC_DEPTH && ok; ++i) {
+                const sm_enc_layer& e = w->enc[i];
+                ok = e.fc1_fw && e.fc1_fb && e.fc1_c && pow2(e.fc1_fs) && (i == 0 || (e.qkv_fw && e.qkv_fb && e.qkv_c && pow2(e.qkv_fs)));
+            }
+            SM_REQUIRE(ok, "sm_maskformer_forward: ln_fold needs the gain-scaled weights, folded biases and row sums (*_fw, *_fb, *_c, *_fs) of every encoder layer");
+        }
     }
     if (!io->encoder_only)
         SM_REQUIRE(io->mask_pred && (io->objectness || w->mask_head_ffn || w->no_objectness) && io->features,

@@ -463,6 +463,30 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
     GEMM_STAMP(0);
 #pragma unroll
     for (int v = -(NST - 1); v < 0; ++v) issue_step(v);
+    // LayerNorm folded into this GEMM (g.ln_stats): A holds the RAW residual stream x (F16X2), W the weight times the norm's gain,
+    // and LN(x) W^T + b = r (x W'^T - mu c) + b' with c = row sums of W', b' = b + W beta - applied in the epilogue.  Here, under
+    // the latency of the first K-tile: (mu r, r) of this tile's rows from the twelve 32-column partials (mean, M2) the producing
+    // residual GEMM left per row, merged in segment order, into LDS behind the ring.
+    float2* lnrow = reinterpret_cast<float2*>(smemm + RING_BYTES);
+    if (g.ln_stats && tid < BM) {
+        int m = m0 + tid;
+        m = m < M ? m : M - 1;
+        const float4* sp = reinterpret_cast<const float4*>(g.ln_stats + (int64_t)m * 24);
+        float mean_s[12], m2 = 0.f, msum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float4 v = sp[q];
+            mean_s[2 * q] = v.x; mean_s[2 * q + 1] = v.z;
+            m2 += v.y; m2 += v.w;
+            msum += v.x; msum += v.z;
+        }
+        const float mu = msum * (1.0f / 12.0f);
+        float dev = 0.f;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) dev += (mean_s[q] - mu) * (mean_s[q] - mu);
+        const float rstd = 1.0f / sqrtf((m2 + 32.0f * dev) * (1.0f / 384.0f) + g.ln_eps);
+        lnrow[tid] = make_float2(mu * rstd, rstd);
+    }
     const f16x8 down = {(_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f,
                         (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f, (_Float16)0.00048828125f};
     for (int kt = 0; kt < nk; ++kt) {
@@ -573,18 +597,40 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                 brow[j][0] = bv.x; brow[j][1] = bv.y; brow[j][2] = bv.z; brow[j][3] = bv.w;
             }
         }
+        // folded LayerNorm (consumer side): c[n] = sum_k W'[n][k] of this lane's columns (N % 4 == 0, c 16-B aligned: host-checked)
+        constexpr bool CANFOLD = !HASR;
+        const bool fold = CANFOLD && g.ln_stats != nullptr;
+        float crow[CANFOLD ? TN : 1][4];
+        if constexpr (CANFOLD) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 16 + 4 * kg;
+                float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (fold && n + 3 < N) cv = *reinterpret_cast<const float4*>(g.ln_c + n);
+                crow[j][0] = cv.x; crow[j][1] = cv.y; crow[j][2] = cv.z; crow[j][3] = cv.w;
+            }
+        }
 #pragma unroll
         for (int ib = 0; ib < TM / 2; ++ib) {  // 32 staged rows = two 16-row tiles
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
                 const int i = 2 * ib + ii, row = ii * 16 + r16;
+                float rs = ws, mur = 0.f;  // fold: t = acc (2^-s r) + (b' - mu r c)
+                if constexpr (CANFOLD) {
+                    if (fold) {
+                        const float2 lr = lnrow[wm * WTM + i * 16 + r16];
+                        rs = ws * lr.y;
+                        mur = lr.x;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int nl = j * 16 + 4 * kg, n = n0 + wn * WTN + nl;  // this lane: columns nl .. nl+3 of its row
                     float t[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        t[e] = acc[i][j][e] * ws + brow[j][e];
+                        if constexpr (CANFOLD) t[e] = acc[i][j][e] * rs + (brow[j][e] - mur * crow[j][e]);
+                        else t[e] = acc[i][j][e] * ws + brow[j][e];
                         if constexpr (EPI == SM_EPI_RELU) t[e] = fmaxf(t[e], 0.f);
                     }
                     if constexpr (EPI == SM_EPI_GELU) gelu4(t);
@@ -610,6 +656,27 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                         m = img * (g.patch_n + 1) + 1 + p;
                     }
                     *reinterpret_cast<float4*>(C + (int64_t)m * g.ldc + n) = val;
+                    if constexpr (EPI == SM_EPI_RESIDUAL) {
+                        if (g.C2) {  // the F16X2 copy of the new residual stream: A operand of the GEMM the next LayerNorm is folded into
+                            const float vv[4] = {val.x, val.y, val.z, val.w};
+                            store_f16x2_4(g.C2 + (int64_t)m * g.ldc, n, vv);
+                        }
+                    }
+                }
+                if constexpr (EPI == SM_EPI_RESIDUAL && WTN == 32) {
+                    // ... and that norm's row statistics over this wave's 32 columns: (mean, M2) by two 8-lane butterflies (the
+                    // eight lanes pc = 0..7 of a row are consecutive), two-pass, written to slot (row, column segment): fixed
+                    // order everywhere, no atomics.  Rows past M join the shuffles (their staging rows hold finite values).
+                    if (g.ln_stats_out) {
+                        float sm_ = (val.x + val.y) + (val.z + val.w);
+                        sm_ += __shfl_xor(sm_, 1, 64); sm_ += __shfl_xor(sm_, 2, 64); sm_ += __shfl_xor(sm_, 4, 64);
+                        const float mean = sm_ * (1.0f / 32.0f);
+                        const float dx = val.x - mean, dy = val.y - mean, dz = val.z - mean, dw = val.w - mean;
+                        float q2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+                        q2 += __shfl_xor(q2, 1, 64); q2 += __shfl_xor(q2, 2, 64); q2 += __shfl_xor(q2, 4, 64);
+                        if (pc == 0 && m < M && n < N)
+                            *reinterpret_cast<float2*>(g.ln_stats_out + ((int64_t)m * 12 + (n0 + wn * WTN) / 32) * 2) = make_float2(mean, q2);
+                    }
                 }
             };
             auto staged = [&](int it) {
@@ -654,7 +721,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
 template <int BM, int BN, int NST, int NWM, int NWN, int WPS, int TERMS = 3>
 static int launch_gemm_m16_terms(const sm_gemm_args& g, hipStream_t st) {
     dim3 grid(((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM), 1, g.split_k > 1 ? g.split_k : 1);
-    constexpr size_t lds = (size_t)NST * (BM + BN) * 128;
+    constexpr size_t lds = (size_t)NST * (BM + BN) * 128 + (size_t)BM * 8;  // ring + (mu r, r) of the tile's rows (folded LayerNorm)
     if (lds > 64 * 1024) {
         static std::once_flag attr_once;
         std::call_once(attr_once, [] {
@@ -994,6 +1061,17 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
     SM_REQUIRE(g->w_scale > 0.f && frexpf(g->w_scale, &ex) == 0.5f, "sm_gemm_w16: w_scale must be the weight tensor's 2^-s");
     SM_REQUIRE((uint64_t)g->M * (uint64_t)g->lda * 4 < (1ull << 32) && (uint64_t)g->N * (uint64_t)g->ldw * 4 < (1ull << 32),
                "sm_gemm_w16: operands beyond 4 GiB (the ring's source addresses are 32-bit offsets from A / W)");
+    if (g->ln_stats || g->ln_stats_out || g->C2) {
+        SM_REQUIRE(variant >= 40 && variant < 50 && variant != 46, "sm_gemm_w16: the LayerNorm fold needs the 16x16x32 kernels with 32-column wave tiles");
+        if (g->ln_stats)
+            SM_REQUIRE(g->K == SM_EMBED && g->ln_c && ((uintptr_t)g->ln_c % 16) == 0 && ((uintptr_t)g->ln_stats % 16) == 0 && g->ln_eps > 0.f &&
+                           g->epilogue != SM_EPI_RESIDUAL && g->epilogue != SM_EPI_PATCH && !(g->split_k > 1) && g->alt_from_n == 0,
+                       "sm_gemm_w16: folded LayerNorm needs K = 384, ln_c (16-B aligned), ln_eps and a BIAS / GELU / RELU epilogue");
+        if (g->ln_stats_out || g->C2)
+            SM_REQUIRE(g->epilogue == SM_EPI_RESIDUAL && g->N == SM_EMBED && g->ldc % 8 == 0 && !(g->split_k > 1) &&
+                           (!g->C2 || ((uintptr_t)g->C2 % 32) == 0) && (!g->ln_stats_out || ((uintptr_t)g->ln_stats_out % 8) == 0),
+                       "sm_gemm_w16: the F16X2 copy / row statistics come from a RESIDUAL epilogue with N = 384");
+    }
     SM_REQUIRE(sm_gemm_w16_variant_name(variant) != nullptr, "sm_gemm_w16_tile: variant %d is not in this build (shipped: 40, 42, 44, 45, 47; "
                "the rejected shapes are in the tuning build)", variant);
     SM_REQUIRE(g->mfma_terms == 0 || g->mfma_terms == 3 || (g->mfma_terms == 1 && variant >= 40 && variant < 50),

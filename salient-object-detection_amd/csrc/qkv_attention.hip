@@ -437,6 +437,29 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     QKV_STAMP(0);
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t) issue(t, t);
+    // LayerNorm folded into the projection (a.ln_stats; see gemm_w16.hip): Xn then holds the RAW residual stream, the weights carry
+    // the norm's gain, and (mu r, r) per token come from the producer's twelve partials - computed here under the first stage's
+    // latency, kept at the top of the LDS (above the ring and above the K / V^T overlay)
+    float2* lnrow = reinterpret_cast<float2*>(smm + QA_LDS - QA_TOK * 8);
+    static_assert(DUMP + (PPW * LOADERS - NP) * 1024 <= QA_LDS - QA_TOK * 8 && QM_K_BYTES + QM_V_BYTES <= QA_LDS - QA_TOK * 8, "row statistics above everything");
+    if (a.ln_stats && tid < QA_TOK) {
+        const int tok = tid < N ? tid : N - 1;
+        const float4* sp = reinterpret_cast<const float4*>(a.ln_stats + ((int64_t)b * N + tok) * 24);
+        float mean_s[12], m2 = 0.f, msum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float4 v = sp[q];
+            mean_s[2 * q] = v.x; mean_s[2 * q + 1] = v.z;
+            m2 += v.y; m2 += v.w;
+            msum += v.x; msum += v.z;
+        }
+        const float mu = msum * (1.0f / 12.0f);
+        float dev = 0.f;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) dev += (mean_s[q] - mu) * (mean_s[q] - mu);
+        const float rstd = 1.0f / sqrtf((m2 + 32.0f * dev) * (1.0f / 384.0f) + a.ln_eps);
+        lnrow[tid] = make_float2(mu * rstd, rstd);
+    }
     // A wave whose second 16-token tile lies wholly beyond N (wave 6 at N = 197: rows 208..223) skips that tile's MFMAs in
     // both phases: its accumulators stay zero, so its K rows / V^T columns hold the bias (finite; those keys are masked).
     const bool two_tiles = wave * 32 + 16 < N;
@@ -498,10 +521,20 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     const float* bq = a.bias + head * SM_HEAD_DIM;
     const float* bk = bq + SM_EMBED;
     const float* bv = bk + SM_EMBED;
+    const bool fold = a.ln_stats != nullptr;  // then: value = acc (2^-s r) + (b' - (mu r) c), r and mu of the TOKEN, c of the output dim
+    const float* cq = fold ? a.ln_c + head * SM_HEAD_DIM : bq;
+    const float* ck = cq + SM_EMBED;
+    const float* cv = ck + SM_EMBED;
     f16x8 qh[2][2], ql[2][2];  // [query tile][dim step s]: element j = dim 32 s + 16 (j >> 2) + 4 kg + (j & 3)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int key = wave * 32 + t * 16 + c16;
+        float rs = ws, mur = 0.f;
+        if (fold) {
+            const float2 lr = lnrow[key];
+            rs = ws * lr.y;
+            mur = lr.x;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 kh8, kl8;
@@ -509,8 +542,8 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int dt = 2 * s + (j >> 2), d = 16 * dt + 4 * kg + (j & 3);
-                qf[j] = acc[dt][t][j & 3] * ws + bq[d];
-                kf[j] = acc[4 + dt][t][j & 3] * ws + bk[d];
+                qf[j] = acc[dt][t][j & 3] * rs + (bq[d] - mur * cq[d]);
+                kf[j] = acc[4 + dt][t][j & 3] * rs + (bk[d] - mur * ck[d]);
             }
             split8(qf, qh[t][s], ql[t][s]);
             split8(kf, kh8, kl8);
@@ -522,11 +555,19 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {  // V^T row of head-dim 16 dt + c16: this wave's 32 tokens = key step `wave`
         const int d = 16 * dt + c16;
-        const float bias = bv[d];
+        const float bias = bv[d], cdim = cv[d];
         f16x8 vh8, vl8;
         float vf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vf[j] = acc[8 + dt][j >> 2][j & 3] * ws + bias;
+        for (int j = 0; j < 8; ++j) {  // token of element j: this wave's 32 j-th ... 16 (j >> 2) + 4 kg + (j & 3)
+            float rs = ws, mur = 0.f;
+            if (fold) {
+                const float2 lr = lnrow[wave * 32 + 16 * (j >> 2) + 4 * kg + (j & 3)];
+                rs = ws * lr.y;
+                mur = lr.x;
+            }
+            vf[j] = acc[8 + dt][j >> 2][j & 3] * rs + (bias - mur * cdim);
+        }
         split8(vf, vh8, vl8);
         char* vp = smm + QM_K_BYTES + d * QM_VLD + wave * 128;
         *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 0) * 16) = vh8;
@@ -723,6 +764,9 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
                a ? a->N : 0, sm::QA_KROWS);
     SM_REQUIRE(a->scale > 0.f, "sm_qkv_attention_w16: scale must be positive");
     SM_REQUIRE(a->mfma_terms == 0 || a->mfma_terms == 1 || a->mfma_terms == 3, "sm_qkv_attention_w16: mfma_terms must be 0/3 or 1");
+    if (a->ln_stats)
+        SM_REQUIRE(a->ln_c && a->ln_eps > 0.f && ((uintptr_t)a->ln_stats % 16) == 0,
+                   "sm_qkv_attention_w16: folded LayerNorm needs ln_c (1152 row sums of the gain-scaled weight), ln_eps and 16-B aligned statistics");
     int ex = 0;
     SM_REQUIRE(a->w_scale > 0.f && frexpf(a->w_scale, &ex) == 0.5f, "sm_qkv_attention_w16: w_scale must be the weight's 2^-s");
     SM_REQUIRE(a->ldx % 8 == 0 && a->ldx >= SM_EMBED && a->ldo % 8 == 0 && a->ldo >= SM_EMBED &&
@@ -734,7 +778,7 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
 #ifdef SM_TUNING
                             reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<32, 3>),
                             reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 2>), reinterpret_cast<const void*>(&sm::qkv_attention_kernel<16, 6>),
-                            reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2>), reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3>),
+                            reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<2>),
                             reinterpret_cast<const void*>(&sm::qkv_attention_m16_kernel<3, 3, 4>),
 #endif
         };
@@ -748,7 +792,7 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
     else if (mode == 6) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 3, 4>), grid, block, sm::QA_LDS, st, *a);
 #ifdef SM_TUNING
     else if (mode == 4) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2>), grid, block, sm::QA_LDS, st, *a);
-    else if (mode == 5) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3>), grid, block, sm::QA_LDS, st, *a);
+    else if (mode == 5) { sm::set_error("sm_qkv_attention_w16: SM_QKV_RING=m16x3 was retired (use m16x3L4)"); return SM_EINVAL; }
     else if (mode == 7) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<3, 3, 4>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 1) hipLaunchKernelGGL((sm::qkv_attention_kernel<32, 3>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 2) hipLaunchKernelGGL((sm::qkv_attention_kernel<16, 2>), grid, block, sm::QA_LDS, st, *a);

@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("lda", C.c_int32), ("ldw", C.c_int32), ("ldc", C.c_int32), ("ldr", C.c_int32),
                 ("batch", C.c_int32), ("epilogue", C.c_int32), ("alt_from_n", C.c_int32), ("split_k", C.c_int32),
                 ("patch_n", C.c_int32), ("ln_gamma", fp), ("ln_beta", fp), ("ln_eps", C.c_float), ("w_scale", C.c_float),
-                ("mfma_terms", C.c_int32)]
+                ("ln_stats", fp), ("ln_c", fp), ("ln_stats_out", fp), ("mfma_terms", C.c_int32)]
 
 
 class RowMap(C.Structure):
@@ -48,7 +48,7 @@ class AttnArgs(C.Structure):
 class QkvAttnArgs(C.Structure):
     _fields_ = [("Xn", fp), ("Wqkv", fp), ("bias", fp), ("O", fp), ("ldx", C.c_int64), ("ldo", C.c_int64),
                 ("B", C.c_int32), ("N", C.c_int32), ("w_scale", C.c_float), ("scale", C.c_float), ("out_f16x2", C.c_int32),
-                ("mfma_terms", C.c_int32)]
+                ("mfma_terms", C.c_int32), ("ln_stats", fp), ("ln_c", fp), ("ln_eps", C.c_float)]
 
 
 ENC_FIELDS = ["norm1_w", "norm1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "norm2_w", "norm2_b", "fc1_w", "fc1_b",
@@ -59,7 +59,8 @@ DEC_FIELDS = ["sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b"
 
 
 class EncLayer(C.Structure):
-    _fields_ = [(n, fp) for n in ENC_FIELDS] + [(n, C.c_float) for n in ("qkv_s", "proj_s", "fc1_s", "fc2_s")]
+    _fields_ = [(n, fp) for n in ENC_FIELDS] + [(n, fp) for n in ("qkv_fw", "qkv_fb", "qkv_c", "fc1_fw", "fc1_fb", "fc1_c")] + \
+               [(n, C.c_float) for n in ("qkv_s", "proj_s", "fc1_s", "fc2_s", "qkv_fs", "fc1_fs")]
 
 
 class DecLayer(C.Structure):
@@ -75,7 +76,7 @@ class Weights(C.Structure):
                 ("dec_kv_w", fp), ("dec_kv_b", fp), ("gemm_mode", C.c_int32), ("patch", C.c_int32), ("pos_grid", C.c_int32), ("n_queries", C.c_int32),
                 ("n_dec_layers", C.c_int32), ("patch_s", C.c_float), ("ffn0_s", C.c_float), ("ffn1_s", C.c_float),
                 ("dec_kv_s", C.c_float), ("ffn2_s", C.c_float), ("mask_head_ffn", C.c_int32), ("normalize_before", C.c_int32),
-                ("scale_factor", C.c_int32), ("no_objectness", C.c_int32)]
+                ("ln_fold", C.c_int32), ("scale_factor", C.c_int32), ("no_objectness", C.c_int32)]
 
 
 class ForwardIO(C.Structure):

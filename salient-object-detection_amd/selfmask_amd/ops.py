@@ -144,7 +144,7 @@ def split_w16(w: torch.Tensor):
 
 def gemm_w16(a_split: torch.Tensor, w16: torch.Tensor, w_scale: float, bias=None, epilogue: int = N.EPI_BIAS, residual=None,
              variant: Optional[int] = None, out=None, out_f16x2: bool = False, split_k: int = 1, a_alt=None, alt_from_n: int = 0,
-             patch_n: int = 0):
+             patch_n: int = 0, xs_out=None, stats_out=None, ln_stats=None, ln_c=None, ln_eps: float = 0.0):
     """C = epilogue(A W^T + bias), A in F16X2, W in W16 (split_w16); single-accumulator kernel.  variant None = the
     library's pick for the shape.  Test / tuning entry: the forward drives the kernel from C."""
     _dev(a_split, w16, bias, residual, a_alt)
@@ -164,6 +164,8 @@ def gemm_w16(a_split: torch.Tensor, w16: torch.Tensor, w_scale: float, bias=None
         g.R, g.ldr = residual.data_ptr(), residual.stride(0)
     if epilogue == N.EPI_PATCH:
         g.patch_n = patch_n
+    # LayerNorm folded into the GEMMs around it: producer outputs (F16X2 copy + row statistics) / consumer inputs (see the header)
+    g.C2, g.ln_stats_out, g.ln_stats, g.ln_c, g.ln_eps = _ptr(xs_out), _ptr(stats_out), _ptr(ln_stats), _ptr(ln_c), ln_eps
     lib = N.load()
     if variant is None:
         N.check(lib.sm_gemm_w16(g, 1 if out_f16x2 else 0, _stream()), "sm_gemm_w16")
@@ -219,17 +221,34 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float = 
     return o
 
 
+def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm(gamma, beta) folded into the Linear(weight, bias) it feeds -> (W16 tensor of weight * gamma, its 2^-s, folded
+    bias b + W beta, row sums c of the gain-scaled weight as rounded to W16): LN(x) W^T + b = r (x W'^T - mu c) + b'."""
+    w16, ws = split_w16((weight * gamma[None, :]).contiguous())
+    rows, K = weight.shape
+    h = w16.view(torch.float16).reshape(rows, K // 8, 2, 8).double()
+    c = ((h[:, :, 0, :] + h[:, :, 1, :]).reshape(rows, K).sum(1) * ws).float().contiguous()
+    b2 = (bias.double() + weight.double() @ beta.double()).float().contiguous()
+    return w16, ws, b2, c
+
+
 def qkv_attention(xn: torch.Tensor, w_qkv: torch.Tensor, b_qkv: torch.Tensor, B: int, scale: float = 0.125,
-                  out_f16x2: bool = False) -> torch.Tensor:
+                  out_f16x2: bool = False, ln=None) -> torch.Tensor:
     """Fused qkv Linear + softmax attention of an encoder block (sm_qkv_attention_w16): xn (B*N, 384) fp32 LayerNorm output
     (converted to F16X2 here), w_qkv (1152, 384) / b_qkv (1152) fp32 -> (B*N, 384) merged-head attention output."""
     _dev(xn, w_qkv, b_qkv)
     M = xn.shape[0]
     assert M % B == 0 and xn.shape[1] == N.EMBED
     xs = split_f16x2(xn.contiguous())
-    w16, ws = split_w16(w_qkv)
     o = torch.empty((M, N.EMBED), device=xn.device, dtype=torch.float32)
     a = N.QkvAttnArgs()
+    if ln is not None:  # (gamma, beta, eps, stats): xn is then the RAW stream whose LayerNorm is folded into the projection
+        gamma, beta, eps, stats = ln
+        w16, ws, b2, cvec = fold_layernorm(w_qkv, b_qkv, gamma, beta)
+        a.ln_stats, a.ln_c, a.ln_eps = stats.data_ptr(), cvec.data_ptr(), eps
+        b_qkv = b2
+    else:
+        w16, ws = split_w16(w_qkv)
     a.Xn, a.Wqkv, a.bias, a.O = xs.data_ptr(), w16.data_ptr(), b_qkv.data_ptr(), o.data_ptr()
     a.ldx, a.ldo, a.B, a.N, a.w_scale, a.scale, a.out_f16x2 = N.EMBED, N.EMBED, B, M // B, ws, scale, 1 if out_f16x2 else 0
     N.check(N.load().sm_qkv_attention_w16(a, _stream()), "sm_qkv_attention_w16")

@@ -111,3 +111,36 @@ def test_weight_outliers_and_agreement_with_two_accumulator_kernel():
     e1, e2, e32 = [(x - ref).abs().max().item() for x in (c1, c2, ref32)]
     print(f"\nK=1536 outlier weights: w16 {e1:.2e}  f16x2 {e2:.2e}  torch-fp32 {e32:.2e}  (max|ref| {ref.abs().max():.1f})")
     assert e1 <= 4e-6 * ref.abs().max().item() and e1 <= 3.0 * max(e2, e32)
+
+
+@pytest.mark.parametrize("variant,M", [(47, 12608 // 4), (42, 700), (44, 197), (45, 300), (40, 1000)])
+def test_layernorm_fold_producer_statistics_and_consumer(variant, M):
+    """LayerNorm folded into the GEMMs around it (sm_gemm_args.ln_stats / ln_stats_out): the residual epilogue's F16X2 copy and
+    its (mean, M2) partials per 32-column segment against numpy, then the consumer - raw stream x gain-scaled weight with
+    r (acc - mu c) + b' in the epilogue - against LayerNorm followed by the Linear in fp64."""
+    g = torch.Generator().manual_seed(variant + M)
+    a, w, b = torch.randn(M, 384, generator=g), torch.randn(384, 384, generator=g) * 0.05, torch.randn(384, generator=g) * 0.1
+    r = torch.randn(M, 384, generator=g) * 2 + torch.randn(M, 1, generator=g)          # a residual stream with per-row offsets
+    w16, ws = ops.split_w16(w.to(DEV))
+    xs = torch.zeros(M, 384, device=DEV)
+    stats = torch.zeros(M, 12, 2, device=DEV)
+    pvar = variant if variant != 40 else 47                                               # N = 384 is not a 256 x 256 shape
+    x = ops.gemm_w16(ops.split_f16x2(a.to(DEV)), w16, ws, b.to(DEV), epilogue=N.EPI_RESIDUAL, residual=r.to(DEV), variant=pvar,
+                     xs_out=xs, stats_out=stats)
+    xr = (a.double() @ w.double().T + b.double() + r.double())
+    assert (x.double().cpu() - xr).abs().max().item() <= 4e-6 * xr.abs().max().item()
+    assert torch.equal(ops.unsplit_f16x2(xs).cpu(), ops.unsplit_f16x2(ops.split_f16x2(x)).cpu())      # the copy IS split(x)
+    seg = x.cpu().double().reshape(M, 12, 32)
+    assert (stats[:, :, 0].cpu().double() - seg.mean(2)).abs().max().item() <= 2e-6
+    m2 = ((seg - seg.mean(2, keepdim=True)) ** 2).sum(2)
+    assert ((stats[:, :, 1].cpu().double() - m2).abs() <= 1e-5 * m2 + 1e-6).all()
+    # consumer: fc1-like GEMM on the raw stream
+    gamma, beta = torch.rand(384, generator=g) + 0.5, torch.randn(384, generator=g) * 0.2
+    w2, b2 = torch.randn(1536 if variant == 40 else 768, 384, generator=g) * 0.05, torch.randn(1536 if variant == 40 else 768, generator=g) * 0.1
+    fw, fs, fb, fc = ops.fold_layernorm(w2.to(DEV), b2.to(DEV), gamma.to(DEV), beta.to(DEV))
+    y = ops.gemm_w16(xs, fw, fs, fb, epilogue=N.EPI_GELU, variant=variant, out_f16x2=True, ln_stats=stats, ln_c=fc, ln_eps=1e-6)
+    xd = x.cpu().double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6) * gamma.double() + beta.double()
+    ref = F.gelu(ln @ w2.double().T + b2.double())
+    err = (ops.unsplit_f16x2(y).double().cpu() - ref).abs().max().item()
+    assert err <= 6e-6 * max(1.0, ref.abs().max().item()), err

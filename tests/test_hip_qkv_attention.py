@@ -72,3 +72,27 @@ def test_token_limit_is_reported():
     with pytest.raises(RuntimeError, match="N=209"):
         ops.qkv_attention(torch.zeros(209, 384, device=DEV), torch.zeros(1152, 384, device=DEV) + 0.01,
                           torch.zeros(1152, device=DEV), 1)
+
+
+@pytest.mark.parametrize("B,n", [(3, 197), (16, 197), (2, 65)])
+def test_fused_kernel_with_folded_layernorm(B, n):
+    """norm1 folded into the projection (sm_qkv_attn_args.ln_stats): raw residual stream in, the norm's gain in the weights,
+    (mu, r) per token from the producer's partial statistics - against LayerNorm + Attention.forward in fp64."""
+    g = torch.Generator().manual_seed(300 + n)
+    x = torch.randn(B * n, 384, generator=g) * 1.5 + torch.randn(B * n, 1, generator=g) * 0.5
+    gamma, beta = torch.rand(384, generator=g) + 0.5, torch.randn(384, generator=g) * 0.2
+    w = torch.randn(1152, 384, generator=g) * 0.05
+    b = torch.randn(1152, generator=g) * 0.1
+    xd = x.double()
+    xn = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6) * gamma.double() + beta.double()
+    ref = _ref(xn, w, b, B, 0.125)
+    seg = x.reshape(B * n, 12, 32)
+    mean = seg.mean(2)
+    stats = torch.stack([mean, ((seg - mean[..., None]) ** 2).sum(2)], dim=2).contiguous()   # what the residual GEMM emits
+    got = ops.qkv_attention(x.to(DEV), w.to(DEV), b.to(DEV), B, 0.125, ln=(gamma.to(DEV), beta.to(DEV), 1e-6, stats.to(DEV)))
+    err = (got.double().cpu() - ref).abs().max().item()
+    plain = ops.qkv_attention(xn.float().to(DEV), w.to(DEV), b.to(DEV), B, 0.125).double().cpu()
+    err_plain = (plain - ref).abs().max().item()
+    print(f"\nfolded LN, B={B} N={n}: folded-fp64 {err:.2e}  LayerNorm-first-fp64 {err_plain:.2e}  max|ref| {ref.abs().max():.2f}")
+    assert err <= 4e-6 * max(1.0, ref.abs().max().item())
+    assert err <= 3.0 * err_plain + 1e-6
