@@ -629,8 +629,12 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                     float t[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        if constexpr (CANFOLD) t[e] = acc[i][j][e] * rs + (brow[j][e] - mur * crow[j][e]);
-                        else t[e] = acc[i][j][e] * ws + brow[j][e];
+                        if constexpr (CANFOLD) {  // (wave-uniform branch: the plain path keeps its one fma per element)
+                            if (fold) t[e] = acc[i][j][e] * rs + (brow[j][e] - mur * crow[j][e]);
+                            else t[e] = acc[i][j][e] * ws + brow[j][e];
+                        } else {
+                            t[e] = acc[i][j][e] * ws + brow[j][e];
+                        }
                         if constexpr (EPI == SM_EPI_RELU) t[e] = fmaxf(t[e], 0.f);
                     }
                     if constexpr (EPI == SM_EPI_GELU) gelu4(t);

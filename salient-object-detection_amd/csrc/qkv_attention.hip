@@ -522,57 +522,69 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     const float* bk = bq + SM_EMBED;
     const float* bv = bk + SM_EMBED;
     const bool fold = a.ln_stats != nullptr;  // then: value = acc (2^-s r) + (b' - (mu r) c), r and mu of the TOKEN, c of the output dim
-    const float* cq = fold ? a.ln_c + head * SM_HEAD_DIM : bq;
-    const float* ck = cq + SM_EMBED;
-    const float* cv = ck + SM_EMBED;
+    // (two copies of the conversion behind one wave-uniform branch: the plain path must not pay for the fold's loads and multiplies)
     f16x8 qh[2][2], ql[2][2];  // [query tile][dim step s]: element j = dim 32 s + 16 (j >> 2) + 4 kg + (j & 3)
+    auto convert = [&](auto fold_tag) {
+        constexpr bool FOLD = decltype(fold_tag)::value;
+        const float* cq = FOLD ? a.ln_c + head * SM_HEAD_DIM : nullptr;
+        const float* ck = FOLD ? cq + SM_EMBED : nullptr;
+        const float* cv = FOLD ? ck + SM_EMBED : nullptr;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int key = wave * 32 + t * 16 + c16;
-        float rs = ws, mur = 0.f;
-        if (fold) {
-            const float2 lr = lnrow[key];
-            rs = ws * lr.y;
-            mur = lr.x;
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 kh8, kl8;
-            float qf[8], kf[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int dt = 2 * s + (j >> 2), d = 16 * dt + 4 * kg + (j & 3);
-                qf[j] = acc[dt][t][j & 3] * rs + (bq[d] - mur * cq[d]);
-                kf[j] = acc[4 + dt][t][j & 3] * rs + (bk[d] - mur * ck[d]);
-            }
-            split8(qf, qh[t][s], ql[t][s]);
-            split8(kf, kh8, kl8);
-            char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
-            *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 0) * 16) = kh8;
-            *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 1) * 16) = kl8;
-        }
-    }
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {  // V^T row of head-dim 16 dt + c16: this wave's 32 tokens = key step `wave`
-        const int d = 16 * dt + c16;
-        const float bias = bv[d], cdim = cv[d];
-        f16x8 vh8, vl8;
-        float vf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {  // token of element j: this wave's 32 j-th ... 16 (j >> 2) + 4 kg + (j & 3)
+        for (int t = 0; t < 2; ++t) {
+            const int key = wave * 32 + t * 16 + c16;
             float rs = ws, mur = 0.f;
-            if (fold) {
-                const float2 lr = lnrow[wave * 32 + 16 * (j >> 2) + 4 * kg + (j & 3)];
+            if constexpr (FOLD) {
+                const float2 lr = lnrow[key];
                 rs = ws * lr.y;
                 mur = lr.x;
             }
-            vf[j] = acc[8 + dt][j >> 2][j & 3] * rs + (bias - mur * cdim);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 kh8, kl8;
+                float qf[8], kf[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int dt = 2 * s + (j >> 2), d = 16 * dt + 4 * kg + (j & 3);
+                    if constexpr (FOLD) {
+                        qf[j] = acc[dt][t][j & 3] * rs + (bq[d] - mur * cq[d]);
+                        kf[j] = acc[4 + dt][t][j & 3] * rs + (bk[d] - mur * ck[d]);
+                    } else {
+                        qf[j] = acc[dt][t][j & 3] * ws + bq[d];
+                        kf[j] = acc[4 + dt][t][j & 3] * ws + bk[d];
+                    }
+                }
+                split8(qf, qh[t][s], ql[t][s]);
+                split8(kf, kh8, kl8);
+                char* kp = smm + key * 256 + ((s ^ (key & 1)) * 128);
+                *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 0) * 16) = kh8;
+                *reinterpret_cast<f16x8*>(kp + m16_slot(key, kg, 1) * 16) = kl8;
+            }
         }
-        split8(vf, vh8, vl8);
-        char* vp = smm + QM_K_BYTES + d * QM_VLD + wave * 128;
-        *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 0) * 16) = vh8;
-        *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 1) * 16) = vl8;
-    }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {  // V^T row of head-dim 16 dt + c16: this wave's 32 tokens = key step `wave`
+            const int d = 16 * dt + c16;
+            const float bias = bv[d];
+            f16x8 vh8, vl8;
+            float vf[8];
+            if constexpr (FOLD) {
+                const float cdim = cv[d];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {  // token of element j: 32 wave + 16 (j >> 2) + 4 kg + (j & 3)
+                    const float2 lr = lnrow[wave * 32 + 16 * (j >> 2) + 4 * kg + (j & 3)];
+                    vf[j] = acc[8 + dt][j >> 2][j & 3] * (ws * lr.y) + (bias - lr.x * cdim);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vf[j] = acc[8 + dt][j >> 2][j & 3] * ws + bias;
+            }
+            split8(vf, vh8, vl8);
+            char* vp = smm + QM_K_BYTES + d * QM_VLD + wave * 128;
+            *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 0) * 16) = vh8;
+            *reinterpret_cast<f16x8*>(vp + m16_slot(d, kg, 1) * 16) = vl8;
+        }
+    };
+    if (fold) convert(std::true_type{});
+    else convert(std::false_type{});
     __syncthreads();
     QKV_STAMP(4);
 
@@ -628,8 +640,17 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
         // step (MFMA, independent of this step's softmax), the exponentials / hi-lo split (VALU) and P V (MFMA) - is a single
         // basic block the scheduler can interleave.  Before, the scores were issued at the top of the body and two branches
         // stood between them and the softmax: the wave ran 24 MFMAs, then ~170 VALU instructions, then 24 MFMAs, each alone.
+        // wave-priority experiment (tuning build: SM_QKV_PRIO; bits 1-2 of out_f16x2, 0 in the product): the two waves of a SIMD are
+        // arbitrated by age, so wave w < 4 runs its attention steps nearly unimpeded (14.7k cycles) and its partner w + 4 gets the
+        // leftovers (22.7k: it finishes alone).  1 = the younger wave at priority 1 throughout, 2 = priorities swapped every step.
+        const int prio_mode = (a.out_f16x2 >> 1) & 3;
+        if (prio_mode == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
         auto step = [&](int stp, auto last_tag) {
             constexpr bool LAST = decltype(last_tag)::value;
+            if (prio_mode == 2) {
+                if (((stp & 1) != 0) == (wave >= 4)) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             if constexpr (LAST) {  // only the last step can hold keys >= N (K rows 197..223 repeat the last token)
     #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -722,7 +743,7 @@ __global__ __launch_bounds__(QA_WAVES * 64, 2) void qkv_attention_m16_kernel(sm_
     #pragma unroll
                     for (int e = 0; e < 4; ++e) x[e] = (om[dt][t][e] + oc[dt][t][e] * (1.0f / 2048.0f)) * inv;
                     const int d = head * SM_HEAD_DIM + 16 * dt + 4 * kg;  // this lane's four consecutive head-dims
-                    if (a.out_f16x2) store_f16x2_4(Orow, d, x);
+                    if (a.out_f16x2 & 1) store_f16x2_4(Orow, d, x);
                     else *reinterpret_cast<float4*>(Orow + d) = make_float4(x[0], x[1], x[2], x[3]);
                 }
             }
@@ -788,6 +809,13 @@ extern "C" int sm_qkv_attention_w16(const sm_qkv_attn_args* a, void* stream) {
     const int mode = qkv_mode();
     const dim3 grid(a->B * SM_HEADS), block(sm::QA_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
+    sm_qkv_attn_args args = *a;
+    args.out_f16x2 = a->out_f16x2 ? 1 : 0;
+#ifdef SM_TUNING
+    static const int prio = getenv("SM_QKV_PRIO") ? atoi(getenv("SM_QKV_PRIO")) & 3 : 0;
+    args.out_f16x2 |= prio << 1;
+#endif
+    a = &args;
     if (a->mfma_terms == 1) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 1, 4>), grid, block, sm::QA_LDS, st, *a);
     else if (mode == 6) hipLaunchKernelGGL((sm::qkv_attention_m16_kernel<2, 3, 4>), grid, block, sm::QA_LDS, st, *a);
 #ifdef SM_TUNING
