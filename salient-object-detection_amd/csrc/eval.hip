@@ -74,11 +74,74 @@ __device__ __forceinline__ void split_idx(int idx, int W, float inv_w, int& y, i
 
 constexpr int EV_QS = 32;  // query stride of the transposed mask copy (floats): one 128-B line per low-res pixel
 
+// ---- band walk ----------------------------------------------------------------------------------------------------------
+// When the ground truth is larger than the mask (the evaluator's case: a 28 x 28 mask against a 300-400 px GT, or the reference
+// mode's x8) the kernels walk an image in BANDS: the GT rows [ytab[i], ytab[i + 1]) whose upper tap is low-res row i.  A work
+// unit is (band i, 64 GT columns), one wave each, one lane per column:
+//   * a lane's horizontal interpolation top = p[i][j0] lx0 + p[i][j1] lx1, bot = p[i+1][..] is the same for every row of the
+//     band: computed once per unit, the per-pixel work shrinks to fma(top, ly0, bot * ly1) - exactly the last step of
+//     torch's arithmetic, so the values are bit-identical to the raster walk's;
+//   * the row's vertical weights are wave-uniform, the GT bytes of a row are one coalesced 64-byte read, and no pixel needs
+//     index arithmetic;
+//   * 0/1 counts are ballots + s_bcnt1 on the scalar unit or carry-in adds, not per-lane adds behind wave reductions.
+// The raster walk (2048-pixel chunks, taps staged in LDS) stays for images that are not up-sampled at least twice; the walk is
+// chosen PER IMAGE (a row of results must not depend on its neighbours in the batch): band_walk().
+constexpr int EV_BAND_MIN = 2;  // an image takes the band walk from H >= EV_BAND_MIN * mh (kernel argument band_min; the
+                                // tuning build reads SM_EVAL_BAND_MIN, 0 = raster walk for every image)
+constexpr int EV_NR = 4;        // GT rows per pass over the queries (query kernel)
+constexpr int EV_NW = EV_THREADS / 64;
+
+template <int N> struct IntTag { static constexpr int value = N; };
+
+__device__ __forceinline__ bool band_walk(const sm_eval_image& im, int mh, int band_min) {
+    return band_min > 0 && im.H >= band_min * mh;
+}
+__device__ __forceinline__ int band_units(const sm_eval_image& im, int mh) { return mh * ((im.W + 63) >> 6); }
+// partial-sum slots an image uses (its workgroups blockIdx.x < slots_of write one each): a workgroup's four waves take the
+// units 4 * blockIdx.x + wave, stepping by 4 * slots, or the raster chunk blockIdx.x
+__device__ __forceinline__ int slots_of(const sm_eval_image& im, int mh, int band_min, int nslot) {
+    if (!band_walk(im, mh, band_min)) return (im.H * im.W + EV_CHUNK - 1) / EV_CHUNK;
+    const int s = (band_units(im, mh) + EV_NW - 1) / EV_NW;
+    return s < nslot ? s : nslot;
+}
+
+// first destination index d in [0, n] whose (clamped) upper source tap is >= i: the map d -> tap is monotone, so the rows of
+// tap i are [first_dst(i), first_dst(i + 1)).  Same float expression as up_index (this file: contraction off).
+__device__ __forceinline__ int first_dst(int i, float scale, int n, int in_size) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        float src = scale * ((float)mid + 0.5f) - 0.5f;
+        src = src < 0.f ? 0.f : src;
+        int t = (int)src;
+        t = t < in_size - 1 ? t : in_size - 1;
+        if (t >= i) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// one lane's column of a unit: x, whether it exists, its two low-res columns and their weights
+struct BandCol { int x, j0, j1; bool in; float lx0, lx1; };
+__device__ __forceinline__ BandCol band_col(int seg, int lane, int W, float sx, int mw) {
+    BandCol c;
+    c.x = seg * 64 + lane;
+    c.in = c.x < W;
+    const UpIdx ux = up_index(c.in ? c.x : 0, sx, mw);
+    c.j0 = ux.i0; c.j1 = ux.i1; c.lx0 = ux.l0; c.lx1 = ux.l1;
+    return c;
+}
+
 // K0: maskT[b][p][q] = mask_pred[b][q][p] (q padded to 32) so the nq queries of one bilinear tap are one cache line
 // (models with more than 32 queries - the reference constructor's default is 100, maskformer.py:13 - take one pass of
 // the query kernel per group of 32: blockIdx.z, copy [pass][b][p][32])
-__global__ __launch_bounds__(256) void eval_transpose_kernel(sm_eval_args a, float* __restrict__ maskT) {
+// (+ the band table of the image, once: ytab[b][i] = first GT row of band i, ytab[b][mh] = H)
+__global__ __launch_bounds__(256) void eval_transpose_kernel(sm_eval_args a, float* __restrict__ maskT, int* __restrict__ ytab) {
     const int b = blockIdx.y, plane = a.mh * a.mw, qbase = blockIdx.z * EV_MAXQ;
+    if (blockIdx.x == 0 && blockIdx.z == 0) {
+        const sm_eval_image im = a.images[b];
+        const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
+        for (int i = threadIdx.x; i <= a.mh; i += 256) ytab[b * (a.mh + 1) + i] = i < a.mh ? first_dst(i, sy, im.H, a.mh) : im.H;
+    }
     const float* __restrict__ m0 = a.mask_pred + (int64_t)b * a.mask_stride_b;
     float* out = maskT + ((int64_t)blockIdx.z * a.B + b) * plane * EV_QS;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < plane * EV_QS; t += gridDim.x * 256) {
@@ -97,28 +160,145 @@ constexpr int EV_LDS_ROWS = 8;  // low-res rows staged per chunk (falls back to 
 constexpr int EV_LDS_BYTES = 60 * 1024;  // staging budget: wide masks stage fewer rows (lds_rows = budget / row bytes); with the
                                          // kernel's ~1.1 KiB of static LDS (red_u, red_g) the workgroup stays under the 64-KiB default limit
 
+// K1, band walk (see above).  Per unit: top / bot of every query of this pass for the lane's column (4 x 16-byte loads per 4
+// queries, once), then per GT row and query  mul, fma, cmp  on the vector unit and  and, bcnt, add, bcnt, add  on the scalar
+// unit; the per-query counts of a pass over EV_NR rows are parked in lane q of two registers.
+__device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval_image& im, const float* __restrict__ mt,
+                                            const unsigned char* __restrict__ gt, const int* __restrict__ ytab, int nqp,
+                                            bool first_pass, float sy, float sx, int slots, QueryStats* qslot, GtStats* gslot) {
+    __shared__ unsigned wc[EV_NW][2 * EV_MAXQ + 1];  // per wave: |bin & g|, |bin| per query; [2 * EV_MAXQ] = |g|
+    __shared__ unsigned long long wg[EV_NW][2];
+    static_assert(EV_MAXQ <= 64, "lane q of a wave carries the counts of query q");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nseg = (im.W + 63) >> 6, units = a.mh * nseg;
+    const int nq4 = (nqp + 3) >> 2;
+    unsigned acc_i = 0, acc_t = 0, ngw = 0;  // lane q of acc_i / acc_t: |bin & g| / |bin| of query q
+    unsigned long long sgx = 0, sgy = 0;  // sgy: wave-uniform
+    for (int u = blockIdx.x * EV_NW + wv; u < units; u += slots * EV_NW) {
+        const int i0 = u / nseg, seg = u - i0 * nseg, i1 = i0 + (i0 < a.mh - 1 ? 1 : 0);
+        const int ya = ytab[i0], yb = ytab[i0 + 1];
+        if (ya >= yb) continue;
+        const BandCol c = band_col(seg, lane, im.W, sx, a.mw);
+        float top[EV_MAXQ], bot[EV_MAXQ];
+        {
+            const float4* __restrict__ t00 = reinterpret_cast<const float4*>(mt + (i0 * a.mw + c.j0) * EV_QS);
+            const float4* __restrict__ t01 = reinterpret_cast<const float4*>(mt + (i0 * a.mw + c.j1) * EV_QS);
+            const float4* __restrict__ t10 = reinterpret_cast<const float4*>(mt + (i1 * a.mw + c.j0) * EV_QS);
+            const float4* __restrict__ t11 = reinterpret_cast<const float4*>(mt + (i1 * a.mw + c.j1) * EV_QS);
+#pragma unroll
+            for (int q4 = 0; q4 < EV_MAXQ / 4; ++q4) {
+                if (q4 < nq4) {
+                    const float4 p00 = t00[q4], p01 = t01[q4], p10 = t10[q4], p11 = t11[q4];
+                    const float v00[4] = {p00.x, p00.y, p00.z, p00.w}, v01[4] = {p01.x, p01.y, p01.z, p01.w};
+                    const float v10[4] = {p10.x, p10.y, p10.z, p10.w}, v11[4] = {p11.x, p11.y, p11.z, p11.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {  // a column past the image's width carries zeros: never above 0.5
+                        top[q4 * 4 + e] = c.in ? __builtin_fmaf(v00[e], c.lx0, v01[e] * c.lx1) : 0.f;
+                        bot[q4 * 4 + e] = c.in ? __builtin_fmaf(v10[e], c.lx0, v11[e] * c.lx1) : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { top[q4 * 4 + e] = 0.f; bot[q4 * 4 + e] = 0.f; }
+                }
+            }
+        }
+        unsigned cnt_g = 0;  // this lane's GT pixels in the unit (its column is c.x)
+        auto rows = [&](auto nr_tag, int y0) {
+            constexpr int NR = decltype(nr_tag)::value;
+            float ly0[NR], ly1[NR];
+            unsigned long long gm[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int y = y0 + r;
+                const UpIdx uy = up_index(y, sy, a.mh);
+                ly0[r] = uy.l0; ly1[r] = uy.l1;
+                const bool g = c.in && gt[y * im.W + c.x] != 0;
+                gm[r] = __ballot(g);
+                const unsigned ng_row = (unsigned)__popcll(gm[r]);
+                ngw += ng_row;
+                if (first_pass) { cnt_g += g ? 1u : 0u; sgy += (unsigned long long)ng_row * (unsigned)y; }
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < EV_MAXQ / 4; ++q4) {
+                if (q4 < nq4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = q4 * 4 + e;
+                        unsigned ci = 0, ct = 0;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const unsigned long long bm = __ballot(__builtin_fmaf(top[q], ly0[r], bot[q] * ly1[r]) > 0.5f);
+                            ci += (unsigned)__popcll(bm & gm[r]);
+                            ct += (unsigned)__popcll(bm);
+                        }
+                        // lane q of acc_i += ci, of acc_t += ct (both wave-uniform).  Not "lane == q ? ci : 0": the 32 compare
+                        // masks are loop invariants, get hoisted and spill the scalar file
+                        const unsigned ui = (unsigned)__builtin_amdgcn_readlane((int)acc_i, q) + ci;
+                        const unsigned ut = (unsigned)__builtin_amdgcn_readlane((int)acc_t, q) + ct;
+                        asm volatile("v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+                                     : "+v"(acc_i), "+v"(acc_t) : "s"(ui), "s"(ut), "n"(q));
+                    }
+                }
+            }
+        };
+        int y = ya;
+        for (; y + EV_NR <= yb; y += EV_NR) rows(IntTag<EV_NR>{}, y);
+        switch (yb - y) {
+            case 1: rows(IntTag<1>{}, y); break;
+            case 2: rows(IntTag<2>{}, y); break;
+            case 3: rows(IntTag<3>{}, y); break;
+            default: break;
+        }
+        static_assert(EV_NR == 4, "the remainder switch covers 1..3 rows");
+        if (first_pass) sgx += (unsigned long long)cnt_g * (unsigned)c.x;
+    }
+    if (lane < EV_MAXQ) { wc[wv][2 * lane] = acc_i; wc[wv][2 * lane + 1] = acc_t; }
+    if (lane == 0) wc[wv][2 * EV_MAXQ] = ngw;
+    if (first_pass) {
+        const unsigned long long tx = wave_total(sgx);
+        if (lane == 0) { wg[wv][0] = tx; wg[wv][1] = sgy; }
+    }
+    __syncthreads();
+    unsigned ng = 0;
+    for (int k = 0; k < EV_NW; ++k) ng += wc[k][2 * EV_MAXQ];
+    if (tid < nqp) {
+        unsigned in = 0, tot = 0;
+        for (int k = 0; k < EV_NW; ++k) { in += wc[k][2 * tid]; tot += wc[k][2 * tid + 1]; }
+        QueryStats o; o.inter = in; o.uni = tot + ng - in;  // |bin | g| = |bin| + |g| - |bin & g|
+        qslot[tid] = o;
+    }
+    if (tid == 0 && first_pass) {
+        GtStats o; o.sum_g = ng; o.sum_gx = 0; o.sum_gy = 0;
+        for (int k = 0; k < EV_NW; ++k) { o.sum_gx += wg[k][0]; o.sum_gy += wg[k][1]; }
+        *gslot = o;
+    }
+}
+
 __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, const float* __restrict__ maskT_all,
-                                                                QueryStats* qpart, GtStats* gpart, int nchunk, int lds_rows) {
-    extern __shared__ __attribute__((aligned(16))) float taps[];  // [rows][mw][EV_QS]
+                                                                const int* __restrict__ ytab, QueryStats* qpart, GtStats* gpart,
+                                                                int nslot, int lds_rows, int band_min) {
+    extern __shared__ __attribute__((aligned(16))) float taps[];  // [rows][mw][EV_QS] (raster walk)
     __shared__ unsigned red_u[EV_THREADS / 64][2 * EV_MAXQ];
     __shared__ unsigned long long red_g[EV_THREADS / 64][3];
     const int b = blockIdx.y;
     const int qbase = blockIdx.z * EV_MAXQ, nqp = min(EV_MAXQ, a.nq - qbase);  // this pass: queries qbase .. qbase+nqp-1
     const float* __restrict__ maskT = maskT_all + (int64_t)blockIdx.z * a.B * a.mh * a.mw * EV_QS;
     const sm_eval_image im = a.images[b];
+    const int slots = slots_of(im, a.mh, band_min, nslot);
+    if ((int)blockIdx.x >= slots) return;  // the reducers stop at slots_of() too
     const int npx = im.H * im.W;
     const int base = blockIdx.x * EV_CHUNK;
-    QueryStats* qslot = qpart + ((int64_t)b * nchunk + blockIdx.x) * a.nq + qbase;  // per-chunk partials: no atomics (thousands
-    GtStats* gslot = gpart + (int64_t)b * nchunk + blockIdx.x;                      // of adds on two cache lines serialise in L2)
-    if (base >= npx) {
-        if (threadIdx.x < nqp) { QueryStats z; z.inter = 0; z.uni = 0; qslot[threadIdx.x] = z; }
-        if (threadIdx.x == 0 && qbase == 0) { GtStats z; z.sum_g = 0; z.sum_gx = 0; z.sum_gy = 0; *gslot = z; }
-        return;
-    }
+    QueryStats* qslot = qpart + ((int64_t)b * nslot + blockIdx.x) * a.nq + qbase;  // per-slot partials: no atomics (thousands
+    GtStats* gslot = gpart + (int64_t)b * nslot + blockIdx.x;                      // of adds on two cache lines serialise in L2)
     const unsigned char* __restrict__ gt = a.gt + im.gt_off;
     const float* __restrict__ mt = maskT + (int64_t)b * a.mh * a.mw * EV_QS;
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
+    if (band_walk(im, a.mh, band_min)) {
+        query_bands(a, im, mt, gt, ytab + b * (a.mh + 1), nqp, qbase == 0, sy, sx, slots, qslot, gslot);
+        return;
+    }
     const float inv_w = 1.0f / (float)im.W;
     const int nq4 = (nqp + 3) >> 2;
     // low-res rows touched by this chunk
@@ -201,13 +381,14 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
 __device__ int select_query(const sm_eval_args& a, const QueryStats* qs, int b, int which, bool write_ious);
 
 __global__ __launch_bounds__(1024) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
-                                                               QueryStats* qs, GtStats* gs, int* sel, int nchunk) {
+                                                               QueryStats* qs, GtStats* gs, int* sel, int nslot, int band_min) {
     const int b = blockIdx.x, t = threadIdx.x;
+    const int nchunk = slots_of(a.images[b], a.mh, band_min, nslot);  // the slots this image's walk wrote
     if (t < a.nq) {
         QueryStats o; o.inter = 0; o.uni = 0;
         #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) {
-            const QueryStats p = qpart[((int64_t)b * nchunk + c) * a.nq + t];
+            const QueryStats p = qpart[((int64_t)b * nslot + c) * a.nq + t];
             o.inter += p.inter; o.uni += p.uni;
         }
         qs[b * a.nq + t] = o;
@@ -216,7 +397,7 @@ __global__ __launch_bounds__(1024) void eval_reduce_query_kernel(sm_eval_args a,
         GtStats o; o.sum_g = 0; o.sum_gx = 0; o.sum_gy = 0;
         #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) {
-            const GtStats p = gpart[(int64_t)b * nchunk + c];
+            const GtStats p = gpart[(int64_t)b * nslot + c];
             o.sum_g += p.sum_g; o.sum_gx += p.sum_gx; o.sum_gy += p.sum_gy;
         }
         gs[b] = o;
@@ -228,12 +409,13 @@ __global__ __launch_bounds__(1024) void eval_reduce_query_kernel(sm_eval_args a,
 }
 
 // K2b: adaptive threshold 2 * mean(p) of the selected masks (f_measure.py:76): fixed-order fp64 sum of K2's partials
-__global__ __launch_bounds__(64) void eval_adapt_kernel(sm_eval_args a, const double* part, float* thr_adapt, int nchunk) {
+__global__ __launch_bounds__(64) void eval_adapt_kernel(sm_eval_args a, const double* part, float* thr_adapt, int nslot, int band_min) {
     const int which = blockIdx.x, b = blockIdx.y;
     if (threadIdx.x != 0) return;
     const sm_eval_image im = a.images[b];
+    const int nchunk = slots_of(im, a.mh, band_min, nslot);
     double sp = 0.0;
-    const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC;
+    const double* p0 = part + (int64_t)(b * 2 + which) * nslot * EV_NACC;
     #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
     for (int k = 0; k < nchunk; ++k) sp += p0[(int64_t)k * EV_NACC];
     thr_adapt[b * 2 + which] = SM_MUL(2.0f, (float)(sp / (double)(im.H * im.W)));
@@ -291,18 +473,49 @@ __device__ float object_score(double n, double s, double ss) {
 }
 
 // K2: sum of the selected mask's probabilities per chunk (needed for the adaptive threshold 2*mean before K3)
-__global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, const int* __restrict__ sel, double* part,
-                                                              int nchunk) {
+__global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, const int* __restrict__ sel, const int* __restrict__ ytab_all,
+                                                              double* part, int nslot, int band_min) {
     __shared__ double red[EV_THREADS / 64];
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x;
     const sm_eval_image im = a.images[b];
+    const int slots = slots_of(im, a.mh, band_min, nslot);
+    if (c >= slots) return;
     const int npx = im.H * im.W, base = c * EV_CHUNK;
-    double* slot = part + ((int64_t)(b * 2 + which) * nchunk + c) * EV_NACC;
-    if (base >= npx) { if (threadIdx.x == 0) slot[0] = 0.0; return; }
+    double* slot = part + ((int64_t)(b * 2 + which) * nslot + c) * EV_NACC;
     const int sel_q = sel[b * 2 + which];
     const float* __restrict__ m = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)sel_q * a.mh * a.mw;
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
+    if (band_walk(im, a.mh, band_min)) {  // both selected queries in one walk (blockIdx.y = 1 has nothing to do)
+        if (which != 0) return;
+        __shared__ double red2[EV_NW][2];
+        const float* __restrict__ m1 = a.mask_pred + (int64_t)b * a.mask_stride_b + (int64_t)sel[b * 2 + 1] * a.mh * a.mw;
+        const int* __restrict__ ytab = ytab_all + b * (a.mh + 1);
+        const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nseg = (im.W + 63) >> 6, units = a.mh * nseg;
+        double s0 = 0.0, s1 = 0.0;
+        for (int u = c * EV_NW + wv; u < units; u += slots * EV_NW) {
+            const int i0 = u / nseg, seg = u - i0 * nseg, i1 = i0 + (i0 < a.mh - 1 ? 1 : 0);
+            const int ya = ytab[i0], yb = ytab[i0 + 1];
+            const BandCol k = band_col(seg, lane, im.W, sx, a.mw);
+            if (ya >= yb || !k.in) continue;
+            const float top0 = __builtin_fmaf(m[i0 * a.mw + k.j0], k.lx0, m[i0 * a.mw + k.j1] * k.lx1);
+            const float bot0 = __builtin_fmaf(m[i1 * a.mw + k.j0], k.lx0, m[i1 * a.mw + k.j1] * k.lx1);
+            const float top1 = __builtin_fmaf(m1[i0 * a.mw + k.j0], k.lx0, m1[i0 * a.mw + k.j1] * k.lx1);
+            const float bot1 = __builtin_fmaf(m1[i1 * a.mw + k.j0], k.lx0, m1[i1 * a.mw + k.j1] * k.lx1);
+            for (int y = ya; y < yb; ++y) {
+                const UpIdx uy = up_index(y, sy, a.mh);
+                s0 += (double)__builtin_fmaf(top0, uy.l0, bot0 * uy.l1);
+                s1 += (double)__builtin_fmaf(top1, uy.l0, bot1 * uy.l1);
+            }
+        }
+        s0 = wave_total(s0); s1 = wave_total(s1);
+        if (lane == 0) { red2[wv][0] = s0; red2[wv][1] = s1; }
+        __syncthreads();
+        if (threadIdx.x < 2)
+            (slot + (int64_t)threadIdx.x * nslot * EV_NACC)[0] = (red2[0][threadIdx.x] + red2[1][threadIdx.x]) + (red2[2][threadIdx.x] + red2[3][threadIdx.x]);
+        return;
+    }
     const float inv_w = 1.0f / (float)im.W;
     double sp = 0.0;
     for (int k = 0; k < EV_PPT; ++k) {
@@ -320,24 +533,129 @@ __global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, co
 
 struct MetricCounts { unsigned tp5, np5, ng, eq5, tpa, npa; unsigned hist[2][256]; };
 
+// number of F-max thresholds strictly below p: start from floor(p * 255) and correct (the table is ascending, ~k/255)
+__device__ __forceinline__ int thresholds_below(const float* thr, float p) {
+    int lo = (int)(p * 255.0f);
+    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+    while (lo > 0 && !(thr[lo - 1] < p)) --lo;
+    while (lo < 255 && thr[lo] < p) ++lo;
+    return lo;
+}
+
+// K3, band walk: the selected query's top / bot per lane once per unit, p = fma(top, ly0, bot * ly1) per pixel; every 0/1 count
+// a ballot; the S-measure moments of a unit's rows above / below the centroid row accumulate per lane (the row side is
+// wave-uniform: two loops) and are folded into the four quadrants by the lane's column side when the unit ends.
+__device__ __forceinline__ void metrics_bands(const sm_eval_args& a, const sm_eval_image& im, const float* __restrict__ m,
+                                              const unsigned char* __restrict__ gt, const int* __restrict__ ytab, float sy, float sx,
+                                              float thr_adapt, int X, int Y, int slots, unsigned (*hist)[256], const float* thr,
+                                              double (*red)[EV_NACC], double* slot, MetricCounts* mc) {
+    constexpr int NW = EV_NW;
+    __shared__ unsigned wcnt[NW][6], gq[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 4) gq[tid] = 0;
+    __syncthreads();
+    const int nseg = (im.W + 63) >> 6, units = a.mh * nseg;
+    unsigned tp5 = 0, np5 = 0, ng = 0, eq5 = 0, tpa = 0, npa = 0, g0 = 0, g1 = 0, g2 = 0, g3 = 0;  // wave-uniform (scalar registers)
+    double aabs = 0.0, fpp = 0.0, bo = 0.0, boo = 0.0;
+    double qp[4] = {0.0, 0.0, 0.0, 0.0}, qpp[4] = {0.0, 0.0, 0.0, 0.0}, qpg[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int u = blockIdx.x * NW + wv; u < units; u += slots * NW) {
+        const int i0 = u / nseg, seg = u - i0 * nseg, i1 = i0 + (i0 < a.mh - 1 ? 1 : 0);
+        const int ya = ytab[i0], yb = ytab[i0 + 1];
+        if (ya >= yb) continue;
+        const BandCol c = band_col(seg, lane, im.W, sx, a.mw);
+        float top = 0.f, bot = 0.f;
+        if (c.in) {
+            top = __builtin_fmaf(m[i0 * a.mw + c.j0], c.lx0, m[i0 * a.mw + c.j1] * c.lx1);
+            bot = __builtin_fmaf(m[i1 * a.mw + c.j0], c.lx0, m[i1 * a.mw + c.j1] * c.lx1);
+        }
+        const bool right = c.x >= X;
+        const unsigned long long vm = __ballot(c.in), rm = __ballot(c.in && right);
+        // rows [y_from, y_to) of the unit, all on one side of the centroid row: sums into (sp, spp, spg), GT counts left / right
+        auto walk = [&](int y_from, int y_to, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
+            for (int y = y_from; y < y_to; ++y) {
+                const UpIdx uy = up_index(y, sy, a.mh);
+                const float p = __builtin_fmaf(top, uy.l0, bot * uy.l1);  // columns past the width: top = bot = 0 -> p = 0
+                const bool g = c.in && gt[y * im.W + c.x] != 0;
+                const unsigned long long gm = __ballot(g);
+                const unsigned long long b5 = __ballot(c.in && p > 0.5f), ba = __ballot(c.in && p > thr_adapt);
+                tp5 += (unsigned)__popcll(b5 & gm); np5 += (unsigned)__popcll(b5); ng += (unsigned)__popcll(gm);
+                eq5 += (unsigned)__popcll(~(b5 ^ gm) & vm); tpa += (unsigned)__popcll(ba & gm); npa += (unsigned)__popcll(ba);
+                gr += (unsigned)__popcll(gm & rm); gl += (unsigned)__popcll(gm & ~rm);
+                if (c.in) atomicAdd(&hist[g ? 1 : 0][thresholds_below(thr, p)], 1u);
+                // absent columns carry p = 0, g = 0: they add 0 to every sum below except the background's (masked)
+                const float gf = g ? 1.0f : 0.0f;
+                const double pd = (double)p, pp = pd * pd;
+                aabs += (double)fabsf(p - gf);
+                sp += pd; spp += pp; spg += g ? pd : 0.0;
+                fpp += g ? pp : 0.0;
+                const double o = (double)(1.0f - p);
+                const bool bg = c.in && !g;
+                bo += bg ? o : 0.0; boo += bg ? o * o : 0.0;
+            }
+        };
+        double tp = 0.0, tpp = 0.0, tpg = 0.0, bp = 0.0, bpp = 0.0, bpg = 0.0;  // top rows (y < Y) / bottom rows (y >= Y)
+        const int ysplit = Y < ya ? ya : (Y > yb ? yb : Y);
+        walk(ya, ysplit, tp, tpp, tpg, g0, g1);
+        walk(ysplit, yb, bp, bpp, bpg, g2, g3);
+        qp[0] += right ? 0.0 : tp; qpp[0] += right ? 0.0 : tpp; qpg[0] += right ? 0.0 : tpg;
+        qp[1] += right ? tp : 0.0; qpp[1] += right ? tpp : 0.0; qpg[1] += right ? tpg : 0.0;
+        qp[2] += right ? 0.0 : bp; qpp[2] += right ? 0.0 : bpp; qpg[2] += right ? 0.0 : bpg;
+        qp[3] += right ? bp : 0.0; qpp[3] += right ? bpp : 0.0; qpg[3] += right ? bpg : 0.0;
+    }
+    // acc layout of the raster walk (EV_NACC): 1 = sum|p-g|; 2+4k.. = quadrant k {sum p, sum g, sum p^2, sum p g}; 18, 19 = fg
+    // {sum p, sum p^2}; 20, 21 = bg {sum (1-p), sum (1-p)^2}.  sum g is an integer count (gq), fg sum p the total of sum p g.
+    {
+        double v;
+        v = wave_total(aabs); if (lane == 0) red[wv][1] = v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v = wave_total(qp[k]); if (lane == 0) red[wv][2 + 4 * k] = v;
+            v = wave_total(qpp[k]); if (lane == 0) red[wv][4 + 4 * k] = v;
+            v = wave_total(qpg[k]); if (lane == 0) red[wv][5 + 4 * k] = v;
+        }
+        v = wave_total(fpp); if (lane == 0) red[wv][19] = v;
+        v = wave_total(bo); if (lane == 0) red[wv][20] = v;
+        v = wave_total(boo); if (lane == 0) red[wv][21] = v;
+    }
+    if (lane == 0) {
+        wcnt[wv][0] = tp5; wcnt[wv][1] = np5; wcnt[wv][2] = ng; wcnt[wv][3] = eq5; wcnt[wv][4] = tpa; wcnt[wv][5] = npa;
+        atomicAdd(&gq[0], g0); atomicAdd(&gq[1], g1); atomicAdd(&gq[2], g2); atomicAdd(&gq[3], g3);
+    }
+    __syncthreads();
+    if (tid > 0 && tid < EV_NACC) {
+        const int k = tid;
+        double v;
+        if (k >= 2 && k < 18 && ((k - 2) & 3) == 1) v = (double)gq[(k - 2) >> 2];
+        else if (k == 18) v = 0.0;  // filled below from the four sums of p g
+        else v = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+        if (k != 18) slot[k] = v;
+    }
+    if (tid == 0) {
+        double t = 0.0;
+        for (int k = 0; k < 4; ++k) t += (red[0][5 + 4 * k] + red[1][5 + 4 * k]) + (red[2][5 + 4 * k] + red[3][5 + 4 * k]);
+        slot[18] = t;
+    }
+    if (tid < 6) (&mc->tp5)[tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    mc->hist[0][tid] = hist[0][tid];
+    mc->hist[1][tid] = hist[1][tid];
+}
+
 // K3: everything else in one pass per chunk.  Integer counts and the 2x256-bin histogram use integer atomics;
 // the fp64 moments are written as per-chunk partials and summed in a fixed order by K4 (bit-reproducible).
 __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a, const int* __restrict__ sel, const float* __restrict__ thr_adapt_all,
-                                                                  const GtStats* gs, double* part, MetricCounts* cnt, int nchunk) {
+                                                                  const GtStats* gs, const int* __restrict__ ytab_all, double* part, MetricCounts* cnt,
+                                                                  int nslot, int band_min) {
     __shared__ unsigned hist[2][256];
     __shared__ float thr[256];
     __shared__ double red[EV_THREADS / 64][EV_NACC];
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
+    const int slots = slots_of(im, a.mh, band_min, nslot);
+    if (c >= slots) return;
     const int npx = im.H * im.W, base = c * EV_CHUNK;
-    double* slot = part + ((int64_t)(b * 2 + which) * nchunk + c) * EV_NACC;
-    if (base >= npx) {
-        if (tid < EV_NACC && tid > 0) slot[tid] = 0.0;
-        MetricCounts* mz = cnt + ((int64_t)(b * 2 + which) * nchunk + c);
-        if (tid < 6) (&mz->tp5)[tid] = 0;
-        mz->hist[0][tid] = 0; mz->hist[1][tid] = 0;
-        return;
-    }
+    double* slot = part + ((int64_t)(b * 2 + which) * nslot + c) * EV_NACC;
+    MetricCounts* mc = cnt + ((int64_t)(b * 2 + which) * nslot + c);
     const int sel_q = sel[b * 2 + which];
     hist[0][tid] = 0; hist[1][tid] = 0;
     thr[tid] = tid < 255 ? a.thresholds[tid] : INFINITY;
@@ -351,6 +669,10 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     const GtStats g0 = gs[b];
     // centroid (s_measure.py:13-31): round-half-even of the fp32 quotient of exact integer sums
     const int X = (int)rintf(SM_DIV((float)g0.sum_gx, (float)g0.sum_g)), Y = (int)rintf(SM_DIV((float)g0.sum_gy, (float)g0.sum_g));
+    if (band_walk(im, a.mh, band_min)) {
+        metrics_bands(a, im, m, gt, ytab_all + b * (a.mh + 1), sy, sx, thr_adapt, X, Y, slots, hist, thr, red, slot, mc);
+        return;
+    }
 
     unsigned tp5 = 0, np5 = 0, ng = 0, eq5 = 0, tpa = 0, npa = 0;
     double acc[EV_NACC];
@@ -405,7 +727,6 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     if (lane == 0) { redc[wv][0] = tp5; redc[wv][1] = np5; redc[wv][2] = ng; redc[wv][3] = eq5; redc[wv][4] = tpa; redc[wv][5] = npa; }
     __syncthreads();
     // per-chunk partial counts + histogram, plain stores (K4 sums them): no same-line atomic storms
-    MetricCounts* mc = cnt + ((int64_t)(b * 2 + which) * nchunk + c);
     if (tid > 0 && tid < EV_NACC) slot[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     if (tid < 6) (&mc->tp5)[tid] = redc[0][tid] + redc[1][tid] + redc[2][tid] + redc[3][tid];
     mc->hist[0][tid] = hist[0][tid];
@@ -415,14 +736,15 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
 // K4: finalise the 7 metrics of (image, which) with the reference's fp32 operation order; 256 threads: fixed-order
 // partial sums, suffix sums of the histogram and the 255 F-measures in parallel, the scalar tail on thread 0
 __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, const int* __restrict__ sel, const GtStats* gs,
-                                                            const double* part, const MetricCounts* cnt, int nchunk) {
+                                                            const double* part, const MetricCounts* cnt, int nslot, int band_min) {
     __shared__ double accs[EV_NACC];
     __shared__ unsigned s_tp[257], s_np[257];
     __shared__ float s_f[256];
     const int which = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W;
-    const MetricCounts* mcp = cnt + (int64_t)(b * 2 + which) * nchunk;
+    const int nchunk = slots_of(im, a.mh, band_min, nslot);  // the slots this image's walk wrote
+    const MetricCounts* mcp = cnt + (int64_t)(b * 2 + which) * nslot;
     __shared__ unsigned h0[256], h1[256], cts[6];
     {
         unsigned s0 = 0, s1 = 0;
@@ -438,7 +760,7 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     }
     __syncthreads();
     if (tid < EV_NACC) {
-        const double* p0 = part + (int64_t)(b * 2 + which) * nchunk * EV_NACC + tid;
+        const double* p0 = part + (int64_t)(b * 2 + which) * nslot * EV_NACC + tid;
         double sacc = 0.0;
         #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
         for (int c = 0; c < nchunk; ++c) sacc += p0[(int64_t)c * EV_NACC];  // chunk order: deterministic
@@ -526,9 +848,9 @@ __global__ __launch_bounds__(256) void eval_u8_to_f32_kernel(const unsigned char
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
 }
 
-struct EvalWs { QueryStats *qs, *qpart; GtStats *gs, *gpart; MetricCounts* cnt; double* part; float* maskT; int* sel; float* thr_adapt; size_t total; };
+struct EvalWs { QueryStats *qs, *qpart; GtStats *gs, *gpart; MetricCounts* cnt; double* part; float* maskT; int *sel, *ytab; float* thr_adapt; size_t total; };
 
-static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
+static EvalWs carve_eval(int B, int nq, int nchunk, int mh, int plane, char* base) {
     EvalWs w;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += (bytes + 255) & ~(size_t)255; return p; };
@@ -541,10 +863,19 @@ static EvalWs carve_eval(int B, int nq, int nchunk, int plane, char* base) {
     w.maskT = (float*)take((size_t)((nq + EV_MAXQ - 1) / EV_MAXQ) * B * plane * EV_QS * sizeof(float));
     w.sel = (int*)take((size_t)B * 2 * sizeof(int));
     w.thr_adapt = (float*)take((size_t)B * 2 * sizeof(float));
+    w.ytab = (int*)take((size_t)B * (mh + 1) * sizeof(int));
     w.total = off;
     return w;
 }
 
+}  // namespace sm
+
+namespace sm {
+// partial-sum slots per image: raster chunks of the largest image or low-res rows, whichever walk needs more
+static int eval_slots(int max_pixels, int mh) {
+    const int nchunk = (max_pixels + EV_CHUNK - 1) / EV_CHUNK;
+    return nchunk > mh ? nchunk : mh;
+}
 }  // namespace sm
 
 static const int SM_EVAL_MAX_PIXELS = 1 << 22;
@@ -552,7 +883,7 @@ static const int SM_EVAL_MAX_QUERIES = 960;  // one thread per query in the redu
 
 extern "C" size_t sm_evaluate_workspace_bytes(int32_t B, int32_t nq, int32_t mh, int32_t mw, int32_t max_pixels) {
     if (B <= 0 || nq <= 0 || nq > SM_EVAL_MAX_QUERIES || mh <= 0 || mw <= 0 || max_pixels <= 0 || max_pixels > SM_EVAL_MAX_PIXELS) return 0;
-    return sm::carve_eval(B, nq, (max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK, mh * mw, nullptr).total;
+    return sm::carve_eval(B, nq, sm::eval_slots(max_pixels, mh), mh, mh * mw, nullptr).total;
 }
 
 extern "C" int sm_upsample_selected_f64(const float* masks, int64_t mask_stride_b, const float* rows, int32_t sel_col, double* out,
@@ -583,22 +914,26 @@ extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
                    ((uintptr_t)a->workspace % 256) == 0,
                "sm_evaluate_masks_f32: workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;
-    const int nchunk = (a->max_pixels + sm::EV_CHUNK - 1) / sm::EV_CHUNK;
-    const sm::EvalWs w = sm::carve_eval(a->B, a->nq, nchunk, a->mh * a->mw, (char*)a->workspace);
+    const int nslot = sm::eval_slots(a->max_pixels, a->mh);
+    const sm::EvalWs w = sm::carve_eval(a->B, a->nq, nslot, a->mh, a->mh * a->mw, (char*)a->workspace);
     const int npass = (a->nq + sm::EV_MAXQ - 1) / sm::EV_MAXQ;
-    // tap staging: up to EV_LDS_ROWS low-res rows of [mw][32 queries] floats inside a 60-KiB budget; masks too wide for
-    // even one row (mw > 480) read their taps from global memory (the kernel's fallback path)
+    // tap staging of the raster walk: up to EV_LDS_ROWS low-res rows of [mw][32 queries] floats inside a 60-KiB budget; masks too
+    // wide for even one row (mw > 480) read their taps from global memory (the kernel's fallback path)
     const size_t row_bytes = (size_t)a->mw * sm::EV_QS * sizeof(float);
     const int lds_rows = (int)(sm::EV_LDS_BYTES / row_bytes) < sm::EV_LDS_ROWS ? (int)(sm::EV_LDS_BYTES / row_bytes) : sm::EV_LDS_ROWS;
+    int band_min = sm::EV_BAND_MIN;
+#ifdef SM_TUNING
+    if (const char* e = getenv("SM_EVAL_BAND_MIN")) band_min = atoi(e);  // 0: raster walk for every image
+#endif
     const int red_threads = ((a->nq + 1 + 63) / 64) * 64;  // one thread per query + a spare last lane for the GT sums
-    hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B, npass), dim3(256), 0, st, *a, w.maskT);
-    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nchunk, a->B, npass), dim3(sm::EV_THREADS), lds_rows * row_bytes, st, *a,
-                       w.maskT, w.qpart, w.gpart, nchunk, lds_rows);
-    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(red_threads), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, w.sel, nchunk);
-    hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.part, nchunk);
-    hipLaunchKernelGGL(sm::eval_adapt_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.part, w.thr_adapt, nchunk);
-    hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nchunk, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.thr_adapt, w.gs,
-                       w.part, w.cnt, nchunk);
-    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(256), 0, st, *a, w.sel, w.gs, w.part, w.cnt, nchunk);
+    hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B, npass), dim3(256), 0, st, *a, w.maskT, w.ytab);
+    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nslot, a->B, npass), dim3(sm::EV_THREADS), lds_rows * row_bytes, st, *a,
+                       w.maskT, w.ytab, w.qpart, w.gpart, nslot, lds_rows, band_min);
+    hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(red_threads), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, w.sel, nslot, band_min);
+    hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nslot, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.ytab, w.part, nslot, band_min);
+    hipLaunchKernelGGL(sm::eval_adapt_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.part, w.thr_adapt, nslot, band_min);
+    hipLaunchKernelGGL(sm::eval_metrics_kernel, dim3(nslot, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.thr_adapt, w.gs,
+                       w.ytab, w.part, w.cnt, nslot, band_min);
+    hipLaunchKernelGGL(sm::eval_finalize_kernel, dim3(2, a->B), dim3(256), 0, st, *a, w.sel, w.gs, w.part, w.cnt, nslot, band_min);
     return sm::check_launch("sm_evaluate_masks_f32");
 }

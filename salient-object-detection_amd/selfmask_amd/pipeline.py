@@ -342,7 +342,9 @@ class PrefetchingLoader:
             shapes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
             return (pack_images(rgbs, self.pack_size, pinned=True), shapes), (pack_gts(gts) if gts[0] is not None else None)
 
-        with ThreadPoolExecutor(max_workers=1) as packer:
+        # two packing threads: assembling a batch is ~30 MB of numpy copies (GIL released) - one thread tops out near 16k images/s,
+        # just above what 15 decode processes deliver; results are consumed in order through their futures
+        with ThreadPoolExecutor(max_workers=2) as packer:
             def submit_packed(k):
                 return packer.submit(assemble, submit(k))
             inflight = [submit_packed(k) for k in range(min(self.depth, len(batches)))]
