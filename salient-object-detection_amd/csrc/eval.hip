@@ -98,10 +98,13 @@ __device__ __forceinline__ bool band_walk(const sm_eval_image& im, int mh, int b
 }
 __device__ __forceinline__ int band_units(const sm_eval_image& im, int mh) { return mh * ((im.W + 63) >> 6); }
 // partial-sum slots an image uses (its workgroups blockIdx.x < slots_of write one each): a workgroup's four waves take the
-// units 4 * blockIdx.x + wave, stepping by 4 * slots, or the raster chunk blockIdx.x
-__device__ __forceinline__ int slots_of(const sm_eval_image& im, int mh, int band_min, int nslot) {
+// units 4 * blockIdx.x + wave, stepping by 4 * slots - `upw` units per wave - or the raster chunk blockIdx.x.
+// The query kernel takes one unit per wave (its epilogue is two stores); the sum / metrics kernels take EV_UPW: their waves
+// end with 16 fp64 wave reductions, a third of the instructions of a one-unit wave (measured, SQ_INSTS_VALU / _LDS).
+constexpr int EV_UPW = 4;
+__device__ __forceinline__ int slots_of(const sm_eval_image& im, int mh, int band_min, int nslot, int upw) {
     if (!band_walk(im, mh, band_min)) return (im.H * im.W + EV_CHUNK - 1) / EV_CHUNK;
-    const int s = (band_units(im, mh) + EV_NW - 1) / EV_NW;
+    const int s = (band_units(im, mh) + EV_NW * upw - 1) / (EV_NW * upw);
     return s < nslot ? s : nslot;
 }
 
@@ -180,7 +183,7 @@ __device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval
         const int ya = ytab[i0], yb = ytab[i0 + 1];
         if (ya >= yb) continue;
         const BandCol c = band_col(seg, lane, im.W, sx, a.mw);
-        float top[EV_MAXQ], bot[EV_MAXQ];
+        f32x2 top[EV_MAXQ / 2], bot[EV_MAXQ / 2];  // query pairs: the per-pixel mul and fma are packed (v_pk_mul_f32 / v_pk_fma_f32)
         {
             const float4* __restrict__ t00 = reinterpret_cast<const float4*>(mt + (i0 * a.mw + c.j0) * EV_QS);
             const float4* __restrict__ t01 = reinterpret_cast<const float4*>(mt + (i0 * a.mw + c.j1) * EV_QS);
@@ -194,12 +197,12 @@ __device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval
                     const float v10[4] = {p10.x, p10.y, p10.z, p10.w}, v11[4] = {p11.x, p11.y, p11.z, p11.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {  // a column past the image's width carries zeros: never above 0.5
-                        top[q4 * 4 + e] = c.in ? __builtin_fmaf(v00[e], c.lx0, v01[e] * c.lx1) : 0.f;
-                        bot[q4 * 4 + e] = c.in ? __builtin_fmaf(v10[e], c.lx0, v11[e] * c.lx1) : 0.f;
+                        top[q4 * 2 + (e >> 1)][e & 1] = c.in ? __builtin_fmaf(v00[e], c.lx0, v01[e] * c.lx1) : 0.f;
+                        bot[q4 * 2 + (e >> 1)][e & 1] = c.in ? __builtin_fmaf(v10[e], c.lx0, v11[e] * c.lx1) : 0.f;
                     }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { top[q4 * 4 + e] = 0.f; bot[q4 * 4 + e] = 0.f; }
+                    for (int e = 0; e < 2; ++e) { top[q4 * 2 + e] = f32x2{0.f, 0.f}; bot[q4 * 2 + e] = f32x2{0.f, 0.f}; }
                 }
             }
         }
@@ -228,7 +231,9 @@ __device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval
                         unsigned ci = 0, ct = 0;
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
-                            const unsigned long long bm = __ballot(__builtin_fmaf(top[q], ly0[r], bot[q] * ly1[r]) > 0.5f);
+                            // element e & 1 of the pair's packed fma(top, ly0, bot * ly1): the same roundings as the scalar form
+                            const f32x2 v = __builtin_elementwise_fma(top[q >> 1], f32x2{ly0[r], ly0[r]}, bot[q >> 1] * f32x2{ly1[r], ly1[r]});
+                            const unsigned long long bm = __ballot(v[e & 1] > 0.5f);
                             ci += (unsigned)__popcll(bm & gm[r]);
                             ct += (unsigned)__popcll(bm);
                         }
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
     const int qbase = blockIdx.z * EV_MAXQ, nqp = min(EV_MAXQ, a.nq - qbase);  // this pass: queries qbase .. qbase+nqp-1
     const float* __restrict__ maskT = maskT_all + (int64_t)blockIdx.z * a.B * a.mh * a.mw * EV_QS;
     const sm_eval_image im = a.images[b];
-    const int slots = slots_of(im, a.mh, band_min, nslot);
+    const int slots = slots_of(im, a.mh, band_min, nslot, 1);
     if ((int)blockIdx.x >= slots) return;  // the reducers stop at slots_of() too
     const int npx = im.H * im.W;
     const int base = blockIdx.x * EV_CHUNK;
@@ -383,7 +388,7 @@ __device__ int select_query(const sm_eval_args& a, const QueryStats* qs, int b, 
 __global__ __launch_bounds__(1024) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
                                                                QueryStats* qs, GtStats* gs, int* sel, int nslot, int band_min) {
     const int b = blockIdx.x, t = threadIdx.x;
-    const int nchunk = slots_of(a.images[b], a.mh, band_min, nslot);  // the slots this image's walk wrote
+    const int nchunk = slots_of(a.images[b], a.mh, band_min, nslot, 1);  // the slots this image's walk wrote
     if (t < a.nq) {
         QueryStats o; o.inter = 0; o.uni = 0;
         #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(64) void eval_adapt_kernel(sm_eval_args a, const do
     const int which = blockIdx.x, b = blockIdx.y;
     if (threadIdx.x != 0) return;
     const sm_eval_image im = a.images[b];
-    const int nchunk = slots_of(im, a.mh, band_min, nslot);
+    const int nchunk = slots_of(im, a.mh, band_min, nslot, EV_UPW);
     double sp = 0.0;
     const double* p0 = part + (int64_t)(b * 2 + which) * nslot * EV_NACC;
     #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, co
     __shared__ double red[EV_THREADS / 64];
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x;
     const sm_eval_image im = a.images[b];
-    const int slots = slots_of(im, a.mh, band_min, nslot);
+    const int slots = slots_of(im, a.mh, band_min, nslot, EV_UPW);
     if (c >= slots) return;
     const int npx = im.H * im.W, base = c * EV_CHUNK;
     double* slot = part + ((int64_t)(b * 2 + which) * nslot + c) * EV_NACC;
@@ -542,6 +547,17 @@ __device__ __forceinline__ int thresholds_below(const float* thr, float p) {
     return lo;
 }
 
+// The same count without data-dependent loops (each costs an LDS round trip and diverges): p in [0, 1] puts the count within
+// floor(p * 255) +- 2 (one unit for the rounding of the product, one for the table's own roundings), so four table entries
+// around it decide - the table is ascending: everything before the window is below p, everything after is not.
+constexpr int EV_THRP = 264;
+__device__ __forceinline__ int thresholds_below_window(const float* thrp, float p) {
+    int lo = (int)(p * 255.0f);
+    lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo);
+    const int c = lo - 2 + (thrp[lo] < p ? 1 : 0) + (thrp[lo + 1] < p ? 1 : 0) + (thrp[lo + 2] < p ? 1 : 0) + (thrp[lo + 3] < p ? 1 : 0);
+    return c < 0 ? 0 : c;  // NaN: every comparison false
+}
+
 // K3, band walk: the selected query's top / bot per lane once per unit, p = fma(top, ly0, bot * ly1) per pixel; every 0/1 count
 // a ballot; the S-measure moments of a unit's rows above / below the centroid row accumulate per lane (the row side is
 // wave-uniform: two loops) and are folded into the four quadrants by the lane's column side when the unit ends.
@@ -553,6 +569,8 @@ __device__ __forceinline__ void metrics_bands(const sm_eval_args& a, const sm_ev
     __shared__ unsigned wcnt[NW][6], gq[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ float thrp[EV_THRP];  // thrp[i] = thr[i - 2], -inf before, +inf after: thresholds_below_window()
+    for (int i = tid; i < EV_THRP; i += EV_THREADS) thrp[i] = i < 2 ? -INFINITY : (i - 2 < 255 ? thr[i - 2] : INFINITY);
     if (tid < 4) gq[tid] = 0;
     __syncthreads();
     const int nseg = (im.W + 63) >> 6, units = a.mh * nseg;
@@ -571,28 +589,41 @@ __device__ __forceinline__ void metrics_bands(const sm_eval_args& a, const sm_ev
         }
         const bool right = c.x >= X;
         const unsigned long long vm = __ballot(c.in), rm = __ballot(c.in && right);
-        // rows [y_from, y_to) of the unit, all on one side of the centroid row: sums into (sp, spp, spg), GT counts left / right
-        auto walk = [&](int y_from, int y_to, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
-            for (int y = y_from; y < y_to; ++y) {
-                const UpIdx uy = up_index(y, sy, a.mh);
-                const float p = __builtin_fmaf(top, uy.l0, bot * uy.l1);  // columns past the width: top = bot = 0 -> p = 0
-                const bool g = c.in && gt[y * im.W + c.x] != 0;
-                const unsigned long long gm = __ballot(g);
-                const unsigned long long b5 = __ballot(c.in && p > 0.5f), ba = __ballot(c.in && p > thr_adapt);
+        // NR rows of the unit from y0, all on one side of the centroid row: sums into (sp, spp, spg), GT counts left / right.
+        // The rows of a pass are independent chains (GT byte, table window, histogram add): their latencies overlap.
+        auto rows = [&](auto nr_tag, int y0, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
+            constexpr int NR = decltype(nr_tag)::value;
+            float p[NR];
+            bool g[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const UpIdx uy = up_index(y0 + r, sy, a.mh);
+                p[r] = __builtin_fmaf(top, uy.l0, bot * uy.l1);  // columns past the width: top = bot = 0 -> p = 0
+                g[r] = c.in && gt[(y0 + r) * im.W + c.x] != 0;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const unsigned long long gm = __ballot(g[r]);
+                const unsigned long long b5 = __ballot(c.in && p[r] > 0.5f), ba = __ballot(c.in && p[r] > thr_adapt);
                 tp5 += (unsigned)__popcll(b5 & gm); np5 += (unsigned)__popcll(b5); ng += (unsigned)__popcll(gm);
                 eq5 += (unsigned)__popcll(~(b5 ^ gm) & vm); tpa += (unsigned)__popcll(ba & gm); npa += (unsigned)__popcll(ba);
                 gr += (unsigned)__popcll(gm & rm); gl += (unsigned)__popcll(gm & ~rm);
-                if (c.in) atomicAdd(&hist[g ? 1 : 0][thresholds_below(thr, p)], 1u);
+                if (c.in) atomicAdd(&hist[g[r] ? 1 : 0][thresholds_below_window(thrp, p[r])], 1u);
                 // absent columns carry p = 0, g = 0: they add 0 to every sum below except the background's (masked)
-                const float gf = g ? 1.0f : 0.0f;
-                const double pd = (double)p, pp = pd * pd;
-                aabs += (double)fabsf(p - gf);
-                sp += pd; spp += pp; spg += g ? pd : 0.0;
-                fpp += g ? pp : 0.0;
-                const double o = (double)(1.0f - p);
-                const bool bg = c.in && !g;
+                const float gf = g[r] ? 1.0f : 0.0f;
+                const double pd = (double)p[r], pp = pd * pd;
+                aabs += (double)fabsf(p[r] - gf);
+                sp += pd; spp += pp; spg += g[r] ? pd : 0.0;
+                fpp += g[r] ? pp : 0.0;
+                const double o = (double)(1.0f - p[r]);
+                const bool bg = c.in && !g[r];
                 bo += bg ? o : 0.0; boo += bg ? o * o : 0.0;
             }
+        };
+        auto walk = [&](int y_from, int y_to, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
+            int y = y_from;
+            for (; y + EV_NR <= y_to; y += EV_NR) rows(IntTag<EV_NR>{}, y, sp, spp, spg, gl, gr);
+            for (; y < y_to; ++y) rows(IntTag<1>{}, y, sp, spp, spg, gl, gr);
         };
         double tp = 0.0, tpp = 0.0, tpg = 0.0, bp = 0.0, bpp = 0.0, bpg = 0.0;  // top rows (y < Y) / bottom rows (y >= Y)
         const int ysplit = Y < ya ? ya : (Y > yb ? yb : Y);
@@ -651,7 +682,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     __shared__ double red[EV_THREADS / 64][EV_NACC];
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
-    const int slots = slots_of(im, a.mh, band_min, nslot);
+    const int slots = slots_of(im, a.mh, band_min, nslot, EV_UPW);
     if (c >= slots) return;
     const int npx = im.H * im.W, base = c * EV_CHUNK;
     double* slot = part + ((int64_t)(b * 2 + which) * nslot + c) * EV_NACC;
@@ -743,7 +774,7 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     const int which = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W;
-    const int nchunk = slots_of(im, a.mh, band_min, nslot);  // the slots this image's walk wrote
+    const int nchunk = slots_of(im, a.mh, band_min, nslot, EV_UPW);  // the slots this image's walk wrote
     const MetricCounts* mcp = cnt + (int64_t)(b * 2 + which) * nslot;
     __shared__ unsigned h0[256], h1[256], cts[6];
     {
