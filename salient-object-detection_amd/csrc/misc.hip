@@ -18,14 +18,17 @@ void set_error(const char* fmt, ...) {
 // ---- im2col: cols[(b,gy,gx)][(c,i,j)] = img[b][c][gy*P+i][gx*P+j], zero beyond H/W ------------------------------
 // one thread per 4 consecutive j (16 B of one image row); consecutive threads walk k fastest so the cols rows are
 // written as full contiguous lines; image reads are P*4-byte runs.
-template <bool SPLIT>
+// (the patch size is a template parameter and the indices are 32-bit: the first version's four 64-bit divisions per float4 cost
+// more than the copy)
+template <bool SPLIT, int P>
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ cols, int B,
-                                                     int H, int W, int P, int gh, int gw, int64_t total4) {
-    const int K = 3 * P * P, K4 = K / 4;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total4; t += (int64_t)gridDim.x * 256) {
-        const int k4 = (int)(t % K4);
-        const int64_t m = t / K4;
-        const int gx = (int)(m % gw), gy = (int)((m / gw) % gh), b = (int)(m / ((int64_t)gw * gh));
+                                                     int H, int W, int gh, int gw, unsigned total4) {
+    constexpr int K = 3 * P * P, K4 = K / 4;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total4; t += gridDim.x * 256u) {
+        const unsigned m = t / K4;
+        const int k4 = (int)(t - m * K4);
+        const unsigned row = m / (unsigned)gw;  // (b, gy)
+        const int gx = (int)(m - row * gw), b = (int)(row / (unsigned)gh), gy = (int)(row - (unsigned)b * gh);
         const int k = k4 * 4, c = k / (P * P), i = (k / P) % P, j = k % P;
         const int y = gy * P + i, x = gx * P + j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -42,9 +45,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
         }
         if constexpr (SPLIT) {
             const float vv[4] = {v.x, v.y, v.z, v.w};
-            store_f16x2_4(cols + m * K, k, vv);
+            store_f16x2_4(cols + (int64_t)m * K, k, vv);
         } else {
-            *reinterpret_cast<float4*>(cols + m * K + k) = v;
+            *reinterpret_cast<float4*>(cols + (int64_t)m * K + k) = v;
         }
     }
 }
@@ -132,23 +135,34 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 // The mask einsum is linear in the up-sampled features and the up-sampling is linear in the tokens, so
 // einsum(Q, up(tok)) = up(einsum(Q, tok)): the GEMM runs on the gh x gw grid (4x fewer FLOPs, no 4n x 384 feature
 // map in HBM) and this kernel up-samples its (B, R, gh, gw) output with the same taps and weights as upsample2x_kernel.
+// One thread per output pixel of a GROUP of planes (blockIdx.y): the taps and weights of the pixel are computed once and used
+// for every plane of the group - the index arithmetic (the first version paid three 64-bit divisions per output: 28.6 us for
+// the 24 MB of a batch of 64) is off the per-element path, stores stay coalesced along x.
+constexpr int UPL_PLANES = 16;
 __global__ __launch_bounds__(256) void upsample2x_logits_kernel(const float* __restrict__ low, float* __restrict__ logits,
-                                                                float* __restrict__ prob, int gh, int gw, int64_t total, int sf, float inv) {
-    const int oh = sf * gh, ow = sf * gw;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-        const int ox = (int)(t % ow), oy = (int)((t / ow) % oh);
-        const int64_t plane = t / ((int64_t)ow * oh);  // (b, r)
-        float syf = inv * (oy + 0.5f) - 0.5f, sxf = inv * (ox + 0.5f) - 0.5f;
-        syf = syf < 0.f ? 0.f : syf;
-        sxf = sxf < 0.f ? 0.f : sxf;
-        const int y0 = (int)syf, x0 = (int)sxf;
-        const int y1 = y0 + (y0 < gh - 1 ? 1 : 0), x1 = x0 + (x0 < gw - 1 ? 1 : 0);
-        const float ly1 = syf - y0, ly0 = 1.f - ly1, lx1 = sxf - x0, lx0 = 1.f - lx1;
-        const float* base = low + plane * gh * gw;
-        const float p00 = base[y0 * gw + x0], p01 = base[y0 * gw + x1], p10 = base[y1 * gw + x0], p11 = base[y1 * gw + x1];
+                                                                float* __restrict__ prob, int gh, int gw, int64_t planes, int sf, float inv) {
+    const int oh = sf * gh, ow = sf * gw, opix = oh * ow, lpix = gh * gw;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= opix) return;
+    const int oy = i / ow, ox = i - oy * ow;
+    float syf = inv * (oy + 0.5f) - 0.5f, sxf = inv * (ox + 0.5f) - 0.5f;
+    syf = syf < 0.f ? 0.f : syf;
+    sxf = sxf < 0.f ? 0.f : sxf;
+    const int y0 = (int)syf, x0 = (int)sxf;
+    const int y1 = y0 + (y0 < gh - 1 ? 1 : 0), x1 = x0 + (x0 < gw - 1 ? 1 : 0);
+    const float ly1 = syf - y0, ly0 = 1.f - ly1, lx1 = sxf - x0, lx0 = 1.f - lx1;
+    const int o00 = y0 * gw + x0, o01 = y0 * gw + x1, o10 = y1 * gw + x0, o11 = y1 * gw + x1;
+    const int64_t p0 = (int64_t)blockIdx.y * UPL_PLANES;
+    const int np = planes - p0 < UPL_PLANES ? (int)(planes - p0) : UPL_PLANES;
+    const float* base = low + p0 * lpix;
+    float* lo = logits ? logits + p0 * opix + i : nullptr;
+    float* pr = prob + p0 * opix + i;
+#pragma unroll 4
+    for (int k = 0; k < np; ++k, base += lpix, pr += opix) {
+        const float p00 = base[o00], p01 = base[o01], p10 = base[o10], p11 = base[o11];
         const float o = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
-        if (logits) logits[t] = o;
-        prob[t] = 1.0f / (1.0f + expf(-o));
+        if (lo) { *lo = o; lo += opix; }
+        *pr = 1.0f / (1.0f + expf(-o));
     }
 }
 
@@ -205,12 +219,14 @@ static int im2col_impl(const float* img, float* cols, int32_t B, int32_t H, int3
                H, W, P);
     const int gh = (H + P - 1) / P, gw = (W + P - 1) / P;
     const int64_t total4 = (int64_t)B * gh * gw * (3 * P * P / 4);
-    if (split)
-        hipLaunchKernelGGL(sm::im2col_kernel<true>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, img, cols,
-                           B, H, W, P, gh, gw, total4);
-    else
-        hipLaunchKernelGGL(sm::im2col_kernel<false>, dim3(sm::grid_for(total4)), dim3(256), 0, (hipStream_t)stream, img, cols,
-                           B, H, W, P, gh, gw, total4);
+    SM_REQUIRE(total4 < ((int64_t)1 << 31), "sm_im2col_patches_f32: B=%d H=%d W=%d is beyond the kernel's 32-bit element index", B, H, W);
+    const dim3 grid(sm::grid_for(total4));
+    const hipStream_t st = (hipStream_t)stream;
+    const unsigned n = (unsigned)total4;
+    if (split && P == 16) hipLaunchKernelGGL((sm::im2col_kernel<true, 16>), grid, dim3(256), 0, st, img, cols, B, H, W, gh, gw, n);
+    else if (split) hipLaunchKernelGGL((sm::im2col_kernel<true, 8>), grid, dim3(256), 0, st, img, cols, B, H, W, gh, gw, n);
+    else if (P == 16) hipLaunchKernelGGL((sm::im2col_kernel<false, 16>), grid, dim3(256), 0, st, img, cols, B, H, W, gh, gw, n);
+    else hipLaunchKernelGGL((sm::im2col_kernel<false, 8>), grid, dim3(256), 0, st, img, cols, B, H, W, gh, gw, n);
     return sm::check_launch("sm_im2col_patches_f32");
 }
 extern "C" int sm_im2col_patches_f32(const float* img, float* cols, int32_t B, int32_t H, int32_t W, int32_t P, void* stream) {
@@ -258,9 +274,11 @@ extern "C" int sm_upsample_tokens_f16x2(const float* tok, int64_t strideb, float
 extern "C" int sm_upsample_logits_sigmoid_f32(const float* low, float* logits, float* prob, int64_t planes, int32_t gh, int32_t gw,
                                               int32_t scale, void* stream) {
     SM_REQUIRE(low && prob && planes > 0 && gh > 0 && gw > 0 && scale >= 1 && scale <= 16, "sm_upsample_logits_sigmoid_f32: bad arguments");
-    const int64_t total = planes * scale * scale * gh * gw;
-    hipLaunchKernelGGL(sm::upsample2x_logits_kernel, dim3(sm::grid_for(total)), dim3(256), 0, (hipStream_t)stream, low, logits,
-                       prob, gh, gw, total, scale, (float)(1.0 / scale));
+    const int64_t opix = (int64_t)scale * scale * gh * gw, groups = (planes + sm::UPL_PLANES - 1) / sm::UPL_PLANES;
+    SM_REQUIRE(opix < (1 << 30) && groups < 65536, "sm_upsample_logits_sigmoid_f32: %lld planes of %lld pixels are beyond the launch grid",
+               (long long)planes, (long long)opix);
+    hipLaunchKernelGGL(sm::upsample2x_logits_kernel, dim3((unsigned)((opix + 255) / 256), (unsigned)groups), dim3(256), 0, (hipStream_t)stream,
+                       low, logits, prob, gh, gw, planes, scale, (float)(1.0 / scale));
     return sm::check_launch("sm_upsample_logits_sigmoid_f32");
 }
 extern "C" int sm_upsample2x_tokens_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,

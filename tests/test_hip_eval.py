@@ -108,3 +108,53 @@ def test_strided_last_layer_view():
     rows = ops.evaluate_masks(fd[:, -1], od[:, -1, :, 0], [g, g], scale=8)
     ref = ops.evaluate_masks(torch.from_numpy(m)[None].to(DEV), torch.from_numpy(o)[None].to(DEV), [g], scale=8)
     assert torch.equal(rows[0], ref[0]) and torch.equal(rows[1], ref[0])
+
+
+def test_band_walk_and_raster_walk_give_the_same_rows():
+    """The product walks up-sampled images in bands (eval.hip); the tuning build can force the raster walk for every image
+    (SM_EVAL_BAND_MIN=0).  Same inputs through both: integer-count metrics and the selection bit-identical, the fp64-sum
+    metrics to the last fp32 digit or one ulp (the two walks add the same terms in a different order)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tuning = os.path.join(root, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so")
+    if not os.path.exists(tuning):
+        pytest.skip("tuning library not built (salient-object-detection_amd/build.py --tuning)")
+    code = r'''
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(sys.argv[1], "salient-object-detection_amd")); sys.path.insert(0, sys.argv[1])
+from selfmask_amd import ops
+def _scene(rng, h, w, nq, mh, mw):
+    yy, xx = np.mgrid[:h, :w]
+    gt = ((((yy - h * rng.uniform(.3, .7)) / (h * rng.uniform(.15, .3))) ** 2 +
+           ((xx - w * rng.uniform(.3, .7)) / (w * rng.uniform(.15, .3))) ** 2) <= 1).astype(np.uint8)
+    low = torch.nn.functional.interpolate(torch.from_numpy(gt.astype(np.float32))[None, None], size=(mh, mw), mode="bilinear",
+                                          align_corners=False)[0, 0].numpy()
+    masks = [1 / (1 + np.exp(-((low * 8 - 4) * rng.uniform(-0.5, 1.5) + rng.standard_normal((mh, mw)) * rng.uniform(0.5, 3.0))))
+             for _ in range(nq)]
+    return gt, np.stack(masks).astype(np.float32), rng.random(nq).astype(np.float32)
+rng = np.random.Generator(np.random.PCG64(77))
+out = {}
+for name, scale, mh, mw, sizes in (("resize", 0, 28, 28, [(300, 400), (371, 262), (224, 224), (130, 70)]),
+                                  ("x8", 8, 28, 42, [(224, 333), (199, 300)]), ("x4", 4, 56, 56, [(224, 224), (200, 211)])):
+    gts, masks, objs = zip(*[_scene(rng, h, w, 20, mh, mw) for (h, w) in sizes])
+    rows, ious = ops.evaluate_masks(torch.from_numpy(np.stack(masks)).cuda(), torch.from_numpy(np.stack(objs)).cuda(),
+                                    [torch.from_numpy(g).cuda() for g in gts], scale=scale, return_ious=True)
+    out[name] = {"rows": rows.cpu().numpy().view(np.uint32).tolist(), "ious": ious.cpu().numpy().view(np.uint32).tolist()}
+print("ROWS" + json.dumps(out))
+'''
+    res = {}
+    for tag, env in (("band", {}), ("raster", {"SM_HIP_LIB": tuning, "SM_EVAL_BAND_MIN": "0"})):
+        p = subprocess.run([sys.executable, "-c", code, root], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[tag] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("ROWS")][0][4:])
+    for name in res["band"]:
+        a = np.array(res["band"][name]["rows"], np.uint32).view(np.float32)
+        b = np.array(res["raster"][name]["rows"], np.uint32).view(np.float32)
+        assert res["band"][name]["ious"] == res["raster"][name]["ious"], name
+        exact = [0, 1, 2, 3, 7, 8, 9, 10, 14, 15]
+        assert np.array_equal(a[:, exact], b[:, exact]), name
+        rest = [4, 5, 6, 11, 12, 13]
+        assert np.allclose(a[:, rest], b[:, rest], rtol=3e-7, atol=0, equal_nan=True), (name, a[:, rest], b[:, rest])
