@@ -2,15 +2,18 @@
 //
 // Reference: evaluator.pyc@L199-228 (last layer -> bilinear up-sample -> crop -> upper-bound query by IoU ->
 // arg-max objectness -> _update_meters) and metrics/{iou,f_measure,mae,pixel_acc,s_measure}.py.  The reference does
-// ~14 device->host syncs per image and replicates the mask 255x for F-max (metrics/f_measure.py:61-62); here two
-// launches per BATCH leave 16 floats per image:
-//   K1  eval_query_kernel   one workgroup per (image, query): up-sample on the fly, |p>0.5 & g|, |p>0.5 | g|, sum p
-//                           (+ ground-truth moments once per image);
-//   K2  eval_metrics_kernel one workgroup per (image, {objectness pick, upper bound}): selection, then ONE pass that
-//                           gathers threshold counts, a 256-bin histogram split by GT (exactly the 255 strict '>'
-//                           thresholds k/255 of f_measure.py:65), |p-g|, per-quadrant and per-class moments for the
-//                           S-measure, and finalises the 7 values with the reference's fp32 operation order.
-// HBM-bound: every pass reads the (nq, h', w') probability maps (L2-resident) and the GT bytes once.
+// ~14 device->host syncs per image and replicates the mask 255x for F-max (metrics/f_measure.py:61-62); here seven
+// stream-ordered launches per BATCH leave 16 floats per image:
+//   K0  eval_transpose       masks -> [pixel][32 queries] per pass of 32 queries, + the band table of every image
+//   K1  eval_query           |p>0.5 & g|, |p>0.5 | g| of every query, ground-truth moments (per-slot partial counts)
+//   K1b eval_reduce_query    partials -> per-query counts, IoU, the two selected queries (arg-max objectness, arg-max IoU)
+//   K2  eval_sum / K2b eval_adapt   sum p of the selected masks -> adaptive threshold 2 * mean (f_measure.py:76)
+//   K3  eval_metrics         one pass per selected mask: threshold counts, the 2 x 256-bin histogram behind F-max (exactly the
+//                            255 strict '>' thresholds k/255 of f_measure.py:65), |p - g|, per-quadrant and per-class moments
+//   K4  eval_finalize        the 7 values with the reference's fp32 operation order
+// K1-K3 walk an image in one of two ways, chosen per image: the BAND walk (below) for up-sampled masks - the evaluator's
+// case - and the RASTER walk (2048-pixel chunks, taps staged in LDS) otherwise.  Bound: vector / scalar issue, not HBM (a batch
+// of 64 reads ~30 MB: its ground truths three times and the 28 x 28 masks; 169 us against 311 us for the raster walk alone).
 #include "common.h"
 #include <math.h>
 
@@ -93,17 +96,22 @@ constexpr int EV_NW = EV_THREADS / 64;
 
 template <int N> struct IntTag { static constexpr int value = N; };
 
-__device__ __forceinline__ bool band_walk(const sm_eval_image& im, int mh, int band_min) {
-    return band_min > 0 && im.H >= band_min * mh;
+constexpr int EV_UPW = 4;          // work units per wave: a wave ends with cross-lane reductions (16 fp64 sums in the metrics kernel,
+                                   // two counts per query in the query kernel) - a third of the instructions of a one-unit wave
+constexpr int EV_BAND_MAX_H = 16383;  // a lane of the query kernel counts rows in 16 bits: EV_UPW units x at most H rows each
+static_assert(EV_UPW * EV_BAND_MAX_H < 65536, "per-lane 16-bit row counts of the query kernel");
+// `walk` (a kernel argument) = band_min | units per wave << 8: EV_BAND_MIN | EV_UPW << 8 in the product, SM_EVAL_BAND_MIN /
+// SM_EVAL_UPW (<= EV_UPW) in the tuning build
+__device__ __forceinline__ bool band_walk(const sm_eval_image& im, int mh, int walk) {
+    const int band_min = walk & 255;
+    return band_min > 0 && im.H >= band_min * mh && im.H <= EV_BAND_MAX_H;
 }
 __device__ __forceinline__ int band_units(const sm_eval_image& im, int mh) { return mh * ((im.W + 63) >> 6); }
 // partial-sum slots an image uses (its workgroups blockIdx.x < slots_of write one each): a workgroup's four waves take the
 // units 4 * blockIdx.x + wave, stepping by 4 * slots - `upw` units per wave - or the raster chunk blockIdx.x.
-// The query kernel takes one unit per wave (its epilogue is two stores); the sum / metrics kernels take EV_UPW: their waves
-// end with 16 fp64 wave reductions, a third of the instructions of a one-unit wave (measured, SQ_INSTS_VALU / _LDS).
-constexpr int EV_UPW = 4;
-__device__ __forceinline__ int slots_of(const sm_eval_image& im, int mh, int band_min, int nslot, int upw) {
+__device__ __forceinline__ int slots_of(const sm_eval_image& im, int mh, int band_min, int nslot) {
     if (!band_walk(im, mh, band_min)) return (im.H * im.W + EV_CHUNK - 1) / EV_CHUNK;
+    const int upw = (band_min >> 8) > 0 ? band_min >> 8 : 1;
     const int s = (band_units(im, mh) + EV_NW * upw - 1) / (EV_NW * upw);
     return s < nslot ? s : nslot;
 }
@@ -122,6 +130,8 @@ __device__ __forceinline__ int first_dst(int i, float scale, int n, int in_size)
     }
     return lo;
 }
+
+constexpr int EV_GROUP = 16;  // GT rows whose bytes a lane requests together
 
 // one lane's column of a unit: x, whether it exists, its two low-res columns and their weights
 struct BandCol { int x, j0, j1; bool in; float lx0, lx1; };
@@ -163,34 +173,57 @@ constexpr int EV_LDS_ROWS = 8;  // low-res rows staged per chunk (falls back to 
 constexpr int EV_LDS_BYTES = 60 * 1024;  // staging budget: wide masks stage fewer rows (lds_rows = budget / row bytes); with the
                                          // kernel's ~1.1 KiB of static LDS (red_u, red_g) the workgroup stays under the 64-KiB default limit
 
+// bit r: the lane's GT pixel of row yg + r (r < EV_GROUP, rows < yb): EV_GROUP independent byte loads in flight
+__device__ __forceinline__ unsigned band_gt_bits(const unsigned char* __restrict__ gt, int W, const BandCol& c, int yg, int yb) {
+    // unconditional loads from clamped addresses, masked afterwards: a predicated load is a basic block of its own and the
+    // compiler waits for it before the next one (measured: sixteen serial round trips per group)
+    const unsigned char* col = gt + (c.in ? c.x : 0);
+    unsigned char v[EV_GROUP];
+#pragma unroll
+    for (int r = 0; r < EV_GROUP; ++r) v[r] = col[(yg + r < yb ? yg + r : yb - 1) * W];
+    unsigned bits = 0;
+#pragma unroll
+    for (int r = 0; r < EV_GROUP; ++r) bits |= (v[r] != 0 ? 1u : 0u) << r;
+    const int nr = yb - yg;
+    return c.in ? (nr >= 32 ? bits : bits & ((1u << nr) - 1u)) : 0u;
+}
+
 // K1, band walk (see above).  Per unit: top / bot of every query of this pass for the lane's column (4 x 16-byte loads per 4
-// queries, once), then per GT row and query  mul, fma, cmp  on the vector unit and  and, bcnt, add, bcnt, add  on the scalar
-// unit; the per-query counts of a pass over EV_NR rows are parked in lane q of two registers.
+// queries, once).  Per GT row and query pair one packed mul and one packed fma, per query one compare and one carry-in add that
+// shifts the outcome into a per-lane bit word (word = 2 word + bin): no scalar instruction, no cross-lane traffic per pixel.
+// Every 32 rows (and when the unit ends) the words are counted: |bin| += popc(word), |bin & g| += popc(word & gword), packed
+// 16 + 16 bits in one register per query (band_walk() bounds the rows a lane can see); the waves reduce the counts across
+// lanes once, at their end.  BQ4 = groups of four queries the registers are sized for (5: the shipped 20 queries, 8: a full pass).
+template <int BQ4>
 __device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval_image& im, const float* __restrict__ mt,
                                             const unsigned char* __restrict__ gt, const int* __restrict__ ytab, int nqp,
                                             bool first_pass, float sy, float sx, int slots, QueryStats* qslot, GtStats* gslot) {
+    constexpr int BQ = BQ4 * 4;
     __shared__ unsigned wc[EV_NW][2 * EV_MAXQ + 1];  // per wave: |bin & g|, |bin| per query; [2 * EV_MAXQ] = |g|
     __shared__ unsigned long long wg[EV_NW][2];
-    static_assert(EV_MAXQ <= 64, "lane q of a wave carries the counts of query q");
+    static_assert(BQ <= EV_MAXQ && EV_MAXQ <= 64, "lane q of a wave carries the counts of query q");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nseg = (im.W + 63) >> 6, units = a.mh * nseg;
     const int nq4 = (nqp + 3) >> 2;
-    unsigned acc_i = 0, acc_t = 0, ngw = 0;  // lane q of acc_i / acc_t: |bin & g| / |bin| of query q
-    unsigned long long sgx = 0, sgy = 0;  // sgy: wave-uniform
+    unsigned cnt[BQ];  // this lane: |bin| in the low, |bin & g| in the high 16 bits
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) cnt[q] = 0;
+    unsigned ngw = 0, sgx = 0;
+    unsigned long long sgy = 0;  // wave-uniform
     for (int u = blockIdx.x * EV_NW + wv; u < units; u += slots * EV_NW) {
         const int i0 = u / nseg, seg = u - i0 * nseg, i1 = i0 + (i0 < a.mh - 1 ? 1 : 0);
         const int ya = ytab[i0], yb = ytab[i0 + 1];
         if (ya >= yb) continue;
         const BandCol c = band_col(seg, lane, im.W, sx, a.mw);
-        f32x2 top[EV_MAXQ / 2], bot[EV_MAXQ / 2];  // query pairs: the per-pixel mul and fma are packed (v_pk_mul_f32 / v_pk_fma_f32)
+        f32x2 top[BQ / 2], bot[BQ / 2];  // query pairs: the per-pixel mul and fma are packed (v_pk_mul_f32 / v_pk_fma_f32)
         {
             const float4* __restrict__ t00 = reinterpret_cast<const float4*>(mt + (i0 * a.mw + c.j0) * EV_QS);
             const float4* __restrict__ t01 = reinterpret_cast<const float4*>(mt + (i0 * a.mw + c.j1) * EV_QS);
             const float4* __restrict__ t10 = reinterpret_cast<const float4*>(mt + (i1 * a.mw + c.j0) * EV_QS);
             const float4* __restrict__ t11 = reinterpret_cast<const float4*>(mt + (i1 * a.mw + c.j1) * EV_QS);
 #pragma unroll
-            for (int q4 = 0; q4 < EV_MAXQ / 4; ++q4) {
+            for (int q4 = 0; q4 < BQ4; ++q4) {
                 if (q4 < nq4) {
                     const float4 p00 = t00[q4], p01 = t01[q4], p10 = t10[q4], p11 = t11[q4];
                     const float v00[4] = {p00.x, p00.y, p00.z, p00.w}, v01[4] = {p01.x, p01.y, p01.z, p01.w};
@@ -206,62 +239,97 @@ __device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval
                 }
             }
         }
-        unsigned cnt_g = 0;  // this lane's GT pixels in the unit (its column is c.x)
-        auto rows = [&](auto nr_tag, int y0) {
+        unsigned word[BQ], gword = 0, cnt_g = 0;  // bit r of word[q] / gword: bin of query q / GT, r rows ago
+        int nbits = 0;
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) word[q] = 0;
+        auto flush = [&]() {
+#pragma unroll
+            for (int q4 = 0; q4 < BQ4; ++q4) {
+                if (q4 < nq4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int q = q4 * 4 + e;
+                        cnt[q] += (unsigned)__builtin_popcount(word[q]) + ((unsigned)__builtin_popcount(word[q] & gword) << 16);
+                        word[q] = 0;
+                    }
+                }
+            }
+            cnt_g += (unsigned)__builtin_popcount(gword);
+            gword = 0;
+            nbits = 0;
+        };
+        auto rows = [&](auto nr_tag, int y0, unsigned gb) {  // gb bit r: this lane's GT pixel of row y0 + r
             constexpr int NR = decltype(nr_tag)::value;
             float ly0[NR], ly1[NR];
-            unsigned long long gm[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int y = y0 + r;
                 const UpIdx uy = up_index(y, sy, a.mh);
                 ly0[r] = uy.l0; ly1[r] = uy.l1;
-                const bool g = c.in && gt[y * im.W + c.x] != 0;
-                gm[r] = __ballot(g);
-                const unsigned ng_row = (unsigned)__popcll(gm[r]);
+                const bool g = ((gb >> r) & 1u) != 0;
+                gword = gword + gword + (g ? 1u : 0u);
+                const unsigned ng_row = (unsigned)__popcll(__ballot(g));
                 ngw += ng_row;
-                if (first_pass) { cnt_g += g ? 1u : 0u; sgy += (unsigned long long)ng_row * (unsigned)y; }
+                if (first_pass) sgy += (unsigned long long)ng_row * (unsigned)y;
             }
 #pragma unroll
-            for (int q4 = 0; q4 < EV_MAXQ / 4; ++q4) {
+            for (int q4 = 0; q4 < BQ4; ++q4) {
                 if (q4 < nq4) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int q = q4 * 4 + e;
-                        unsigned ci = 0, ct = 0;
 #pragma unroll
                         for (int r = 0; r < NR; ++r) {
                             // element e & 1 of the pair's packed fma(top, ly0, bot * ly1): the same roundings as the scalar form
                             const f32x2 v = __builtin_elementwise_fma(top[q >> 1], f32x2{ly0[r], ly0[r]}, bot[q >> 1] * f32x2{ly1[r], ly1[r]});
-                            const unsigned long long bm = __ballot(v[e & 1] > 0.5f);
-                            ci += (unsigned)__popcll(bm & gm[r]);
-                            ct += (unsigned)__popcll(bm);
+                            // word = 2 word + (v > 0.5): compare into vcc, add with carry-in.  As inline assembly because the
+                            // compiler turns the C form into shift / select / or chains behind ALL the compares of a pass, whose
+                            // 64-bit masks then spill the scalar file.
+                            // (s_nop 0: a packed-fp32 result needs one wait state before a VALU reads it - hipcc pads its own
+                            // instructions, not the ones inside an asm statement.)
+                            asm("s_nop 0\n\tv_cmp_lt_f32_e32 vcc, 0.5, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(word[q]) : "v"(v[e & 1]) : "vcc");
                         }
-                        // lane q of acc_i += ci, of acc_t += ct (both wave-uniform).  Not "lane == q ? ci : 0": the 32 compare
-                        // masks are loop invariants, get hoisted and spill the scalar file
-                        const unsigned ui = (unsigned)__builtin_amdgcn_readlane((int)acc_i, q) + ci;
-                        const unsigned ut = (unsigned)__builtin_amdgcn_readlane((int)acc_t, q) + ct;
-                        asm volatile("v_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-                                     : "+v"(acc_i), "+v"(acc_t) : "s"(ui), "s"(ut), "n"(q));
                     }
                 }
             }
+            nbits += NR;
         };
-        int y = ya;
-        for (; y + EV_NR <= yb; y += EV_NR) rows(IntTag<EV_NR>{}, y);
-        switch (yb - y) {
-            case 1: rows(IntTag<1>{}, y); break;
-            case 2: rows(IntTag<2>{}, y); break;
-            case 3: rows(IntTag<3>{}, y); break;
-            default: break;
+        // The GT bytes of EV_GROUP rows are requested together, ahead of the passes that use them: a wave is a chain of
+        // dependent global loads (band table -> taps, GT -> counts) and with one load per pass its latency, not its
+        // instructions, set the kernel's time.
+        for (int yg = ya; yg < yb; yg += EV_GROUP) {
+            const unsigned gbits = band_gt_bits(gt, im.W, c, yg, yb);
+            const int ye = yg + EV_GROUP < yb ? yg + EV_GROUP : yb;
+            int y = yg;
+            for (; y + EV_NR <= ye; y += EV_NR) {
+                rows(IntTag<EV_NR>{}, y, gbits >> (y - yg));
+                if (nbits == 32) flush();
+            }
+            switch (ye - y) {  // only the last group has a remainder; at most 28 bits are in use here
+                case 1: rows(IntTag<1>{}, y, gbits >> (y - yg)); break;
+                case 2: rows(IntTag<2>{}, y, gbits >> (y - yg)); break;
+                case 3: rows(IntTag<3>{}, y, gbits >> (y - yg)); break;
+                default: break;
+            }
         }
-        static_assert(EV_NR == 4, "the remainder switch covers 1..3 rows");
-        if (first_pass) sgx += (unsigned long long)cnt_g * (unsigned)c.x;
+        static_assert(EV_NR == 4 && 32 % EV_NR == 0 && EV_GROUP % EV_NR == 0, "the remainder switch covers 1..3 rows; a word holds whole passes");
+        flush();
+        if (first_pass) sgx += cnt_g * (unsigned)c.x;
+    }
+    unsigned acc_i = 0, acc_t = 0;  // lane q: the wave's counts of query q
+#pragma unroll
+    for (int q = 0; q < BQ; ++q) {
+        if (q < nqp) {
+            const unsigned t = wave_total(cnt[q] & 0xffffu), i = wave_total(cnt[q] >> 16);
+            acc_t = lane == q ? t : acc_t;
+            acc_i = lane == q ? i : acc_i;
+        }
     }
     if (lane < EV_MAXQ) { wc[wv][2 * lane] = acc_i; wc[wv][2 * lane + 1] = acc_t; }
     if (lane == 0) wc[wv][2 * EV_MAXQ] = ngw;
     if (first_pass) {
-        const unsigned long long tx = wave_total(sgx);
+        const unsigned long long tx = wave_total((unsigned long long)sgx);
         if (lane == 0) { wg[wv][0] = tx; wg[wv][1] = sgy; }
     }
     __syncthreads();
@@ -280,6 +348,7 @@ __device__ __forceinline__ void query_bands(const sm_eval_args& a, const sm_eval
     }
 }
 
+template <int BQ4>
 __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, const float* __restrict__ maskT_all,
                                                                 const int* __restrict__ ytab, QueryStats* qpart, GtStats* gpart,
                                                                 int nslot, int lds_rows, int band_min) {
@@ -290,7 +359,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
     const int qbase = blockIdx.z * EV_MAXQ, nqp = min(EV_MAXQ, a.nq - qbase);  // this pass: queries qbase .. qbase+nqp-1
     const float* __restrict__ maskT = maskT_all + (int64_t)blockIdx.z * a.B * a.mh * a.mw * EV_QS;
     const sm_eval_image im = a.images[b];
-    const int slots = slots_of(im, a.mh, band_min, nslot, 1);
+    const int slots = slots_of(im, a.mh, band_min, nslot);
     if ((int)blockIdx.x >= slots) return;  // the reducers stop at slots_of() too
     const int npx = im.H * im.W;
     const int base = blockIdx.x * EV_CHUNK;
@@ -301,7 +370,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_query_kernel(sm_eval_args a, 
     const float sy = a.scale > 0.f ? 1.0f / a.scale : (float)a.mh / (float)im.H;
     const float sx = a.scale > 0.f ? 1.0f / a.scale : (float)a.mw / (float)im.W;
     if (band_walk(im, a.mh, band_min)) {
-        query_bands(a, im, mt, gt, ytab + b * (a.mh + 1), nqp, qbase == 0, sy, sx, slots, qslot, gslot);
+        query_bands<BQ4>(a, im, mt, gt, ytab + b * (a.mh + 1), nqp, qbase == 0, sy, sx, slots, qslot, gslot);
         return;
     }
     const float inv_w = 1.0f / (float)im.W;
@@ -388,7 +457,7 @@ __device__ int select_query(const sm_eval_args& a, const QueryStats* qs, int b, 
 __global__ __launch_bounds__(1024) void eval_reduce_query_kernel(sm_eval_args a, const QueryStats* qpart, const GtStats* gpart,
                                                                QueryStats* qs, GtStats* gs, int* sel, int nslot, int band_min) {
     const int b = blockIdx.x, t = threadIdx.x;
-    const int nchunk = slots_of(a.images[b], a.mh, band_min, nslot, 1);  // the slots this image's walk wrote
+    const int nchunk = slots_of(a.images[b], a.mh, band_min, nslot);  // the slots this image's walk wrote
     if (t < a.nq) {
         QueryStats o; o.inter = 0; o.uni = 0;
         #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
@@ -418,7 +487,7 @@ __global__ __launch_bounds__(64) void eval_adapt_kernel(sm_eval_args a, const do
     const int which = blockIdx.x, b = blockIdx.y;
     if (threadIdx.x != 0) return;
     const sm_eval_image im = a.images[b];
-    const int nchunk = slots_of(im, a.mh, band_min, nslot, EV_UPW);
+    const int nchunk = slots_of(im, a.mh, band_min, nslot);
     double sp = 0.0;
     const double* p0 = part + (int64_t)(b * 2 + which) * nslot * EV_NACC;
     #pragma unroll 8  // the loads do not depend on the running sum: keep eight in flight (add order unchanged)
@@ -483,7 +552,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_sum_kernel(sm_eval_args a, co
     __shared__ double red[EV_THREADS / 64];
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x;
     const sm_eval_image im = a.images[b];
-    const int slots = slots_of(im, a.mh, band_min, nslot, EV_UPW);
+    const int slots = slots_of(im, a.mh, band_min, nslot);
     if (c >= slots) return;
     const int npx = im.H * im.W, base = c * EV_CHUNK;
     double* slot = part + ((int64_t)(b * 2 + which) * nslot + c) * EV_NACC;
@@ -591,7 +660,7 @@ __device__ __forceinline__ void metrics_bands(const sm_eval_args& a, const sm_ev
         const unsigned long long vm = __ballot(c.in), rm = __ballot(c.in && right);
         // NR rows of the unit from y0, all on one side of the centroid row: sums into (sp, spp, spg), GT counts left / right.
         // The rows of a pass are independent chains (GT byte, table window, histogram add): their latencies overlap.
-        auto rows = [&](auto nr_tag, int y0, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
+        auto rows = [&](auto nr_tag, int y0, unsigned gb, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
             constexpr int NR = decltype(nr_tag)::value;
             float p[NR];
             bool g[NR];
@@ -599,7 +668,7 @@ __device__ __forceinline__ void metrics_bands(const sm_eval_args& a, const sm_ev
             for (int r = 0; r < NR; ++r) {
                 const UpIdx uy = up_index(y0 + r, sy, a.mh);
                 p[r] = __builtin_fmaf(top, uy.l0, bot * uy.l1);  // columns past the width: top = bot = 0 -> p = 0
-                g[r] = c.in && gt[(y0 + r) * im.W + c.x] != 0;
+                g[r] = ((gb >> r) & 1u) != 0;
             }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
@@ -621,9 +690,13 @@ __device__ __forceinline__ void metrics_bands(const sm_eval_args& a, const sm_ev
             }
         };
         auto walk = [&](int y_from, int y_to, double& sp, double& spp, double& spg, unsigned& gl, unsigned& gr) {
-            int y = y_from;
-            for (; y + EV_NR <= y_to; y += EV_NR) rows(IntTag<EV_NR>{}, y, sp, spp, spg, gl, gr);
-            for (; y < y_to; ++y) rows(IntTag<1>{}, y, sp, spp, spg, gl, gr);
+            for (int yg = y_from; yg < y_to; yg += EV_GROUP) {  // the GT bytes of EV_GROUP rows are requested together (query_bands)
+                const unsigned gbits = band_gt_bits(gt, im.W, c, yg, y_to);
+                const int ye = yg + EV_GROUP < y_to ? yg + EV_GROUP : y_to;
+                int y = yg;
+                for (; y + EV_NR <= ye; y += EV_NR) rows(IntTag<EV_NR>{}, y, gbits >> (y - yg), sp, spp, spg, gl, gr);
+                for (; y < ye; ++y) rows(IntTag<1>{}, y, gbits >> (y - yg), sp, spp, spg, gl, gr);
+            }
         };
         double tp = 0.0, tpp = 0.0, tpg = 0.0, bp = 0.0, bpp = 0.0, bpg = 0.0;  // top rows (y < Y) / bottom rows (y >= Y)
         const int ysplit = Y < ya ? ya : (Y > yb ? yb : Y);
@@ -682,7 +755,7 @@ __global__ __launch_bounds__(EV_THREADS) void eval_metrics_kernel(sm_eval_args a
     __shared__ double red[EV_THREADS / 64][EV_NACC];
     const int which = blockIdx.y, b = blockIdx.z, c = blockIdx.x, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
-    const int slots = slots_of(im, a.mh, band_min, nslot, EV_UPW);
+    const int slots = slots_of(im, a.mh, band_min, nslot);
     if (c >= slots) return;
     const int npx = im.H * im.W, base = c * EV_CHUNK;
     double* slot = part + ((int64_t)(b * 2 + which) * nslot + c) * EV_NACC;
@@ -774,7 +847,7 @@ __global__ __launch_bounds__(256) void eval_finalize_kernel(sm_eval_args a, cons
     const int which = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const sm_eval_image im = a.images[b];
     const int npx = im.H * im.W;
-    const int nchunk = slots_of(im, a.mh, band_min, nslot, EV_UPW);  // the slots this image's walk wrote
+    const int nchunk = slots_of(im, a.mh, band_min, nslot);  // the slots this image's walk wrote
     const MetricCounts* mcp = cnt + (int64_t)(b * 2 + which) * nslot;
     __shared__ unsigned h0[256], h1[256], cts[6];
     {
@@ -952,14 +1025,23 @@ extern "C" int sm_evaluate_masks_f32(const sm_eval_args* a, void* stream) {
     // wide for even one row (mw > 480) read their taps from global memory (the kernel's fallback path)
     const size_t row_bytes = (size_t)a->mw * sm::EV_QS * sizeof(float);
     const int lds_rows = (int)(sm::EV_LDS_BYTES / row_bytes) < sm::EV_LDS_ROWS ? (int)(sm::EV_LDS_BYTES / row_bytes) : sm::EV_LDS_ROWS;
-    int band_min = sm::EV_BAND_MIN;
+    int band_min = sm::EV_BAND_MIN | sm::EV_UPW << 8;  // the kernels' `walk` argument
 #ifdef SM_TUNING
-    if (const char* e = getenv("SM_EVAL_BAND_MIN")) band_min = atoi(e);  // 0: raster walk for every image
+    {
+        int bm = sm::EV_BAND_MIN, upw = sm::EV_UPW;
+        if (const char* e = getenv("SM_EVAL_BAND_MIN")) bm = atoi(e) & 255;  // 0: raster walk for every image
+        if (const char* e = getenv("SM_EVAL_UPW")) upw = atoi(e) < 1 ? 1 : (atoi(e) > sm::EV_UPW ? sm::EV_UPW : atoi(e));
+        band_min = bm | upw << 8;
+    }
 #endif
     const int red_threads = ((a->nq + 1 + 63) / 64) * 64;  // one thread per query + a spare last lane for the GT sums
     hipLaunchKernelGGL(sm::eval_transpose_kernel, dim3((a->mh * a->mw * sm::EV_QS + 255) / 256, a->B, npass), dim3(256), 0, st, *a, w.maskT, w.ytab);
-    hipLaunchKernelGGL(sm::eval_query_kernel, dim3(nslot, a->B, npass), dim3(sm::EV_THREADS), lds_rows * row_bytes, st, *a,
-                       w.maskT, w.ytab, w.qpart, w.gpart, nslot, lds_rows, band_min);
+    if (a->nq <= 20)  // the band walk's registers sized for the shipped 20 queries (4 waves per SIMD instead of 3)
+        hipLaunchKernelGGL(sm::eval_query_kernel<5>, dim3(nslot, a->B, npass), dim3(sm::EV_THREADS), lds_rows * row_bytes, st, *a,
+                           w.maskT, w.ytab, w.qpart, w.gpart, nslot, lds_rows, band_min);
+    else
+        hipLaunchKernelGGL(sm::eval_query_kernel<8>, dim3(nslot, a->B, npass), dim3(sm::EV_THREADS), lds_rows * row_bytes, st, *a,
+                           w.maskT, w.ytab, w.qpart, w.gpart, nslot, lds_rows, band_min);
     hipLaunchKernelGGL(sm::eval_reduce_query_kernel, dim3(a->B), dim3(red_threads), 0, st, *a, w.qpart, w.gpart, w.qs, w.gs, w.sel, nslot, band_min);
     hipLaunchKernelGGL(sm::eval_sum_kernel, dim3(nslot, 2, a->B), dim3(sm::EV_THREADS), 0, st, *a, w.sel, w.ytab, w.part, nslot, band_min);
     hipLaunchKernelGGL(sm::eval_adapt_kernel, dim3(2, a->B), dim3(64), 0, st, *a, w.part, w.thr_adapt, nslot, band_min);

@@ -8,6 +8,7 @@ echo "== product (band walk from H >= 2 mh)" | tee gpurun_out/r3j/eval_bench.log
 python scripts/eval_bench.py 2>&1 | tee -a gpurun_out/r3j/eval_bench.log
 echo "== tuning, raster walk for every image" | tee -a gpurun_out/r3j/eval_bench.log
 SM_HIP_LIB=$T SM_EVAL_BAND_MIN=0 python scripts/eval_bench.py 2>&1 | tee -a gpurun_out/r3j/eval_bench.log
+for u in 1 2; do echo "== tuning, band walk, $u unit(s) per wave" | tee -a gpurun_out/r3j/eval_bench.log; SM_HIP_LIB=$T SM_EVAL_UPW=$u python scripts/eval_bench.py 28 56 2>&1 | tee -a gpurun_out/r3j/eval_bench.log; done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r3j/prof -o ev -- python3 $GRAFT_REPO_ROOT/scripts/eval_bench.py 28 56 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
