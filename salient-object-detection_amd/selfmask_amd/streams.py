@@ -19,7 +19,12 @@ class StreamRing:
             raise ValueError("StreamRing needs at least one stream")
         self.device = device
         self.home = torch.cuda.current_stream(device)
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)] if n > 1 else [self.home]
+        # experiment hook (round 3, measured and left off: see DESIGN.md): SM_STREAM_PRIORITIES="-1,0,0" gives the ring's streams
+        # HIP priorities (lower = more urgent)
+        import os
+        prio = [int(v) for v in os.environ.get("SM_STREAM_PRIORITIES", "").split(",") if v.strip()]
+        self.streams = ([torch.cuda.Stream(device=device, priority=prio[i % len(prio)]) if prio else torch.cuda.Stream(device=device)
+                         for i in range(n)] if n > 1 else [self.home])
         self._k = 0
         self.fork()
 
