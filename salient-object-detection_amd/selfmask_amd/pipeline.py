@@ -96,6 +96,7 @@ class PinnedPool:
     def __init__(self):
         import threading
         self._free = {}  # (dtype, rounded size) -> list of [tensor, None (free) | _BUSY | event behind the last copy]
+        self._by_ptr = {}  # data_ptr of a buffer -> its entry (release_after is called twice per image at batch 1)
         self._lock = threading.Lock()
 
     @staticmethod
@@ -115,18 +116,18 @@ class PinnedPool:
                     return ent[0][:n]
             ent = [torch.empty(key[1], dtype=dtype).pin_memory(), self._BUSY]
             self._free[key].append(ent)
+            self._by_ptr[ent[0].data_ptr()] = ent
             return ent[0][:n]
 
     def release_after(self, tensors, stream) -> None:
         """The buffers behind ``tensors`` may be reused once the work queued on ``stream`` so far has finished."""
         ev = torch.cuda.Event()
         ev.record(stream)
-        ptrs = {t.data_ptr() for t in tensors}
         with self._lock:
-            for lst in self._free.values():
-                for ent in lst:
-                    if ent[0].data_ptr() in ptrs:
-                        ent[1] = ev
+            for t in tensors:
+                ent = self._by_ptr.get(t.data_ptr())  # a handed-out view starts at its buffer's first byte
+                if ent is not None:
+                    ent[1] = ev
 
 
 _POOL = PinnedPool()
