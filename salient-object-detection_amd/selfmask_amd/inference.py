@@ -59,6 +59,10 @@ class SelfMaskInference:
     def _to_rgb_array(image) -> np.ndarray:
         """app.py:215-219: a werkzeug FileStorage (anything with ``.stream``), a file object / path, a PIL image or an
         array - converted to RGB."""
+        if isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3:
+            # already what Image.fromarray(image).convert("RGB") would hand back, byte for byte: the round trip through Pillow
+            # (encode + decode of the raw bytes, 0.13 ms for 300 x 400) was paid twice per request
+            return np.ascontiguousarray(image)
         if hasattr(image, "stream"):
             image = Image.open(image.stream)
         elif isinstance(image, (str, bytes)) or hasattr(image, "read"):
