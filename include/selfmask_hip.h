@@ -158,6 +158,9 @@ typedef struct sm_ln_args {
     /* F16X2 outputs for the split-operand GEMM (sm_gemm_f16x2): */
     float* ys;                   /* NULL or F16X2 copy of y, same row map / stride as y (y itself may then be NULL)  */
     int32_t y2_f16x2;            /* != 0: y2 is written in F16X2 instead of fp32                                     */
+    float* raw;                  /* NULL, or (rows,384) fp32 with x's row map / stride: the value BEFORE normalisation (with
+                                    n_partials > 0 the reduced sum + pre_bias + residual: a pre-norm block's new residual
+                                    stream; may alias `residual`)                                                       */
 } sm_ln_args;
 int sm_layernorm_rows_f32(const sm_ln_args* args, void* stream);
 

@@ -42,6 +42,11 @@ struct TapScope {
     }
 };
 
+// Forwards this small (batch 1-2 at 224^2: serving) run the encoder's fc2 - K = 1536 on M/64 x 6 workgroups, a 48-step serial K
+// loop of ~20 us - split four ways along K; the LayerNorm launch that follows sums the slices (as the decoder's does).  Only on
+// the automatic path (sm_forward_io.attn_path = 0): the Evaluator pins a path so that rows do not depend on the batch size.
+static const int64_t SM_SPLIT_FC2_ROWS = 512;
+
 struct Shape {
     int B, H, W, P, gh, gw, n, N, L, nq, sf;  // sf: the pixel decoder's scale_factor (2 as shipped)
     int64_t M, Mp, Md, Mo;  // tokens, patch tokens, decoder rows, objectness rows
@@ -93,7 +98,8 @@ static Ws carve(const Shape& s, float* base) {
     w.Qc = take(s.Md * D);
     w.AOd = take(s.Md * D);             // (S)
     w.HIDd = take(s.Md * SM_MLP);       // (S)
-    w.PART = take(s.Md * D * 4);        // split-K partials of linear2
+    // split-K partials: the decoder's linear2, and the encoder's fc2 on forwards of at most SM_SPLIT_FC2_ROWS token rows
+    w.PART = take((s.M <= SM_SPLIT_FC2_ROWS && s.M > s.Md ? s.M : s.Md) * D * 4);
     w.QD = take(s.Mo * D);
     w.QDs = take(s.Mo * D);             // F16X2 copy of QD
     w.LOG = take(s.Mo * s.sf * s.sf * s.n);
@@ -193,6 +199,7 @@ struct LnOpt {
     int64_t partial_stride = 0;
     const float* pre_bias = nullptr;
     const float* residual = nullptr;
+    float* raw = nullptr;       // the value before normalisation (sm_ln_args.raw)
 };
 static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, float* y, int64_t rows, float eps,
               const LnOpt& o = LnOpt()) {
@@ -201,7 +208,7 @@ static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, fl
     a.out_map = o.out_map; a.y2 = o.y2; a.ldy2 = SM_EMBED; a.add = o.add; a.add_rows = o.add_rows;
     a.rows = (int)rows; a.eps = eps;
     a.n_partials = o.n_partials; a.partial_stride = o.partial_stride; a.pre_bias = o.pre_bias; a.residual = o.residual;
-    a.ys = o.ys; a.y2_f16x2 = o.y2_s ? 1 : 0;
+    a.ys = o.ys; a.y2_f16x2 = o.y2_s ? 1 : 0; a.raw = o.raw;
     TapScope tap(c.st, "layernorm384_kernel", 0.0, 2.0 * rows * SM_EMBED * 4);
     return sm_layernorm_rows_f32(&a, c.st);
 }
@@ -295,10 +302,12 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
     // pin as the attention path (sm_forward_io.attn_path: 2 = the small-batch kernels, 1 = the large-batch ones).
     const bool lnf = c.W16 && w->ln_fold != 0 && io->attn_path != 1 && (io->attn_path == 2 || s.B * SM_HEADS < 96);
     if (fuse_fc2) TRY(ln(c, ws.X, w->enc[0].norm1_w, w->enc[0].norm1_b, nullptr, s.M, 1e-6f, xs));
+    const bool split_fc2 = c.W16 && S && io->attn_path == 0 && s.M <= SM_SPLIT_FC2_ROWS && !fuse_fc2 && !ablate_ln;
     for (int i = 0; i < SM_ENC_DEPTH; ++i) {
         const sm_enc_layer& e = w->enc[i];
-        const bool f1 = lnf && i > 0;  // this block's norm1 is folded into its qkv projection
-        if (!fuse_fc2 && !f1 && !(ablate_ln && i > 0)) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
+        const bool n1_done = split_fc2 && i > 0;  // the previous block's split fc2 ended in this block's norm1
+        const bool f1 = lnf && i > 0 && !n1_done;  // this block's norm1 is folded into its qkv projection
+        if (!fuse_fc2 && !f1 && !n1_done && !(ablate_ln && i > 0)) TRY(ln(c, ws.X, e.norm1_w, e.norm1_b, S ? nullptr : ws.Xn, s.M, 1e-6f, xs));
         Fold fq;
         if (f1) { fq.stats = ws.ST; fq.cvec = e.qkv_c; fq.eps = 1e-6f; }
         const float* qkv_w = f1 ? e.qkv_fw : e.qkv_w;
@@ -337,6 +346,16 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
         if (fuse_fc2 && i + 1 < SM_ENC_DEPTH) {
             const sm_enc_layer& nx = w->enc[i + 1];
             TRY(linear_residual_ln(c, ws.HID, SM_MLP, e.fc2_w, e.fc2_b, ws.X, s.M, SM_MLP, nx.norm1_w, nx.norm1_b, 1e-6f, ws.Xn));
+        } else if (split_fc2 && i + 1 < SM_ENC_DEPTH) {
+            const sm_enc_layer& nx = w->enc[i + 1];
+            sm_gemm_args g = {};
+            g.A = ws.HID; g.W = e.fc2_w; g.C = ws.PART; g.M = (int)s.M; g.N = D; g.K = SM_MLP; g.lda = SM_MLP;
+            g.ldw = SM_MLP; g.ldc = D; g.batch = 1; g.epilogue = SM_EPI_BIAS; g.split_k = 4; g.strideC = s.M * D;
+            g.w_scale = e.fc2_s;
+            TRY(gemm(c, g));
+            LnOpt o;  // x += fc2 (slices + bias + residual, written back as the stream) and the next block's norm1 of it
+            o.ys = ws.Xn; o.n_partials = 4; o.partial_stride = s.M * D; o.pre_bias = e.fc2_b; o.residual = ws.X; o.raw = ws.X;
+            TRY(ln(c, ws.PART, nx.norm1_w, nx.norm1_b, nullptr, s.M, 1e-6f, o));
         } else {
             Fold fo;
             if (lnf && i + 1 < SM_ENC_DEPTH) { fo.xs = ws.Xn; fo.stats_out = ws.ST; }

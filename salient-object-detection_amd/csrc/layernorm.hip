@@ -56,6 +56,15 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
             }
         }
     }
+    if (a.raw && live) {  // the value itself (a pre-norm block's residual stream), before it is centred in place below
+        float* rw = a.raw + map_row(row, a.in_map) * a.ldx;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = (l16 + 16 * i) * 8;
+            *reinterpret_cast<float4*>(rw + k) = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+            *reinterpret_cast<float4*>(rw + k + 4) = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) s += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));

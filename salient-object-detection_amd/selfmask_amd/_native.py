@@ -34,7 +34,8 @@ class LnArgs(C.Structure):
     _fields_ = [("x", fp), ("ldx", C.c_int64), ("in_map", RowMap), ("gamma", fp), ("beta", fp),
                 ("y", fp), ("ldy", C.c_int64), ("out_map", RowMap), ("y2", fp), ("ldy2", C.c_int64),
                 ("add", fp), ("add_rows", C.c_int32), ("rows", C.c_int32), ("eps", C.c_float), ("n_partials", C.c_int32),
-                ("partial_stride", C.c_int64), ("pre_bias", fp), ("residual", fp), ("ys", fp), ("y2_f16x2", C.c_int32)]
+                ("partial_stride", C.c_int64), ("pre_bias", fp), ("residual", fp), ("ys", fp), ("y2_f16x2", C.c_int32),
+                ("raw", fp)]
 
 
 class AttnArgs(C.Structure):

@@ -149,12 +149,23 @@ def test_forward_vs_oracle_batch8_and_fp64_truth(mode):
 def test_forward_is_deterministic_and_batch_invariant():
     m = _model(16, 0, "soft")
     x = torch.from_numpy(synthetic_images(99, (4, 3, 224, 224))).to(DEV)
+    # with the encoder path pinned (as the Evaluator pins it): the automatic choice depends on the batch size - fused QKV +
+    # attention from 16 images up, fc2 split along K below 513 token rows - and those agree to rounding, not to the bit
+    m.attention_path = "unfused"
     a = m(x, return_logits=True)
     b = m(x, return_logits=True)
     assert torch.equal(a["mask_logits"], b["mask_logits"]) and torch.equal(a["objectness"], b["objectness"])
     # image i alone gives the same bits as image i inside the batch (no cross-image reduction anywhere)
     c = m(x[2:3], return_logits=True)
     assert torch.equal(c["mask_logits"][0], a["mask_logits"][2])
+    # the automatic path at batch 1 (the serving path: fc2 as four K-slices summed by the LayerNorm launch) against the pinned one
+    m.attention_path = "auto"
+    d = m(x[2:3], return_logits=True)
+    again = m(x[2:3], return_logits=True)
+    assert torch.equal(d["mask_logits"], again["mask_logits"])
+    err = (d["mask_logits"] - c["mask_logits"]).abs().max().item()
+    assert err < 1e-4, err  # two fp32-grade orders of the same sums (measured 3e-5 on logits up to ~30)
+    assert d["mask_pred"].shape == c["mask_pred"].shape and bool(d["mask_pred"].isfinite().all())
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -180,12 +191,13 @@ def test_full_bench_batch_64_properties(mode):
         one = m(x[i:i + 1].to(DEV), return_logits=True)
         assert torch.equal(one["mask_logits"][0], out["mask_logits"][i]), i
         assert torch.equal(one["objectness"][0], out["objectness"][i]), i
-    m.attention_path = "auto"  # B = 1 then takes the two-launch path: same result to rounding
+    # B = 1 on the automatic path: two-launch attention, folded pre-norms, fc2 as four K-slices - the same result to rounding
+    m.attention_path = "auto"
     one = m(x[29:30].to(DEV), return_logits=True)
-    assert (one["mask_logits"][0] - out["mask_logits"][29]).abs().max().item() <= 2e-5
+    assert (one["mask_logits"][0] - out["mask_logits"][29]).abs().max().item() <= 5e-5
     m.attention_path = "unfused"
     pair = m(x[29:30].to(DEV), return_logits=True)
-    assert torch.equal(pair["mask_logits"], one["mask_logits"])
+    assert (pair["mask_logits"] - one["mask_logits"]).abs().max().item() <= 5e-5
     o32 = O.forward(x[pick], sd, patch)
     d = (out["mask_logits"][pick].cpu() - o32["mask_logits"]).abs().max().item()
     print(f"\n[{mode}] B=64 calib, images {pick}: hip-oracle32={d:.2e}")

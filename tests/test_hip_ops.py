@@ -79,6 +79,13 @@ def test_gemm_split_k_and_alt_operand():
     Nn_.check(Nn_.load().sm_layernorm_rows_f32(la, torch.cuda.current_stream().cuda_stream))
     ref = F.layer_norm(res.double() + a.double() @ w.double().T + bias.double(), (384,), g.double(), b.double(), 1e-5)
     assert _maxerr(y, ref) <= 2e-5
+    # ... and the sum itself, in place over the residual (a pre-norm block's stream: the encoder's split fc2 at batch 1-2)
+    la.raw = resd.data_ptr()
+    y2 = torch.empty(M, 384, device=DEV)
+    la.y = y2.data_ptr()
+    Nn_.check(Nn_.load().sm_layernorm_rows_f32(la, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(y2, y)
+    assert _maxerr(resd, res.double() + a.double() @ w.double().T + bias.double()) <= 2e-5
     # A_alt: columns >= 768 use the second A operand (decoder self-attention q|k from tgt+qpos, v from tgt)
     a1, a2, w3, b3 = _rand(60, 384, seed=20), _rand(60, 384, seed=21), _rand(1152, 384, seed=22, scale=0.05), _rand(1152, seed=23)
     c = ops.gemm(a1.to(DEV), w3.to(DEV), b3.to(DEV), a_alt=a2.to(DEV), alt_from_n=768)
