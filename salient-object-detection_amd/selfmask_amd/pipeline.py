@@ -343,9 +343,11 @@ class PrefetchingLoader:
             shapes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
             return (pack_images(rgbs, self.pack_size, pinned=True), shapes), (pack_gts(gts) if gts[0] is not None else None)
 
-        # two packing threads: assembling a batch is ~30 MB of numpy copies (GIL released) - one thread tops out near 16k images/s,
-        # just above what 15 decode processes deliver; results are consumed in order through their futures
-        with ThreadPoolExecutor(max_workers=2) as packer:
+        # ONE packing thread: assembling a batch is ~30 MB of numpy copies (GIL released), 16k images/s on one thread - what 15
+        # decode processes deliver.  Measured over 12 288 files, two alternations (profiles/r03_pack_threads.log): 1 thread
+        # 14.5 / 14.0 k images/s end to end, 2: 14.0 / 12.8 k, 3: 12.2 / 14.2 k, 4: 11.8 / 11.2 k - every extra thread competes with
+        # the decode processes for the rank's cores.  (The first, 0.3-s version of the leg had favoured two.)
+        with ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("SM_PACK_THREADS", "1")))) as packer:
             def submit_packed(k):
                 return packer.submit(assemble, submit(k))
             inflight = [submit_packed(k) for k in range(min(self.depth, len(batches)))]
