@@ -79,9 +79,14 @@ class Evaluator(BaseStructure):
         rows_refined = torch.empty((len(mine), 16), dtype=torch.float32, device=device) if refine else None
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
         # recurring batch shapes replay one captured hipGraph per stream instead of ~150 launches (graphs.py)
-        # native-resolution mode meets a new shape with almost every image: graphs would only thrash there
+        # native-resolution mode meets a new shape with almost every image: graphs would only thrash there.  In token-grid
+        # buckets a shape is captured from its 32nd sighting per stream on: a capture costs ~10 ms, the bucketed run is
+        # GPU-bound (its 0.6 ms of launches per forward are hidden), and ~50 grids on three streams rarely come back that often -
+        # at batch 8 the admit-after-three policy spent 0.86 of 0.95 s capturing 86 graphs it replayed once or twice
+        # (scripts/native_batch_sizes.py)
         self._graphed = GraphedForward(self.model, enabled=hip_graph and (img_size is not None or bucketed) and
-                                       isinstance(self.model, torch.nn.Module), max_graphs=24 if bucketed else 8)
+                                       isinstance(self.model, torch.nn.Module), max_graphs=24 if bucketed else 8,
+                                       admit_after=getattr(self, "bucket_graph_admit_after", 31) if bucketed else 2)
         assert input_pipeline in ("device", "host"), input_pipeline
 
         def padded(shapes):

@@ -176,6 +176,9 @@ def test_native_resolution_buckets_equal_batch1_rows_bit_for_bit(tmp_path, patch
     assert np.array_equal(ev.last_rows, rows1)
     ref = D.average_rows(rows1)
     assert all(res[k] == ref[k] for k in ref)
-    # and through graph replay: a second pass sees every recurring bucket shape again
-    ev("ecssd", dir_ckpt=str(tmp_path / "ckpt8"), batch_size=8, device=DEV, input_pipeline=pipe)
+    # and through graph replay (bucket shapes are captured from their 32nd sighting per stream on by default: lowered here)
+    ev.bucket_graph_admit_after = 0
+    ev("ecssd", dir_ckpt=str(tmp_path / "ckpt8"), batch_size=2, device=DEV, input_pipeline=pipe, streams=1)
     assert np.array_equal(ev.last_rows, rows1)
+    if pipe == "device":
+        assert ev.graph_stats["failed"] is None and ev.graph_stats["captures"] >= 1
