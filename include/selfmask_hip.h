@@ -349,6 +349,36 @@ int sm_kmeans_f32(const float* feat, int32_t B, int32_t n, int32_t k, int32_t it
 int sm_labels_to_masks_u8(const int32_t* labels, int32_t lh, int32_t lw, int32_t scale, int32_t k, int32_t H, int32_t W, uint8_t* masks,
                           void* stream);
 
+/* clusterer(features, k) with cluster_type="spectral": the choice of the shipped configuration
+ * (configs/duts-dino-k234-nq20-224-swav-mocov2-dino-p16-sr10100.yaml:11-12 `k: [2,3,4]`, `clustering_mode: "spectral"`;
+ * mask_generator.pyc@L30-38,160; BASELINE.json configs[4] "faiss k-NN affinity + eigendecomp").  The reference's `clusterings`
+ * module is absent from its repository in every form - parity UNPINNED.  Built: normalised spectral clustering in the form
+ * scikit-learn's SpectralClustering(affinity="precomputed") evaluates (the third-party witness, oracle/cluster_oracle.py):
+ * Euclidean k-NN graph (every point + its n_neighbors - 1 nearest others) -> W = (C + C^T)/2 without self loops ->
+ * L = I - D^-1/2 W D^-1/2 -> eigenvectors of the max(cluster_sizes) smallest eigenvalues (fp64, Chebyshev-filtered subspace
+ * iteration, one workgroup per image) -> rows v_i / sqrt(d_i) -> for every k of cluster_sizes a k-means (farthest-point centres,
+ * Lloyd to a fixed point) on the first k columns.  ONE eigen-solve serves every k.  Deterministic (no floating-point atomics). */
+typedef struct sm_spectral_args {
+    const float* features;        /* (B, n, 384) fp32: the up-sampled tokens; 16 <= n <= 8192, n % 4 == 0                  */
+    int32_t* labels;              /* out (B, n_sizes, n) int32                                                               */
+    const int32_t* cluster_sizes; /* HOST array of n_sizes entries, each 1..6                                                */
+    int32_t* knn;                 /* out (B, n, n_neighbors - 1) int32 neighbour lists, nearest first, or NULL (workspace)   */
+    double* eigenvalues;          /* out (B, kw) ascending, kw = max(cluster_sizes), or NULL                                 */
+    double* embedding;            /* out (B, n, kw) fp64 or NULL (workspace)                                                 */
+    double* residuals;            /* out (B, kw): |L v - lambda v| per returned eigenpair, or NULL                           */
+    int32_t* info;                /* out (B, 4) or NULL: outer iterations, block mat-vecs, converged (0/1), Cholesky guard hit */
+    void* workspace;              /* sm_spectral_workspace_bytes(B, n, n_neighbors, kw), 256-B aligned                       */
+    size_t workspace_bytes;
+    double tol;                   /* residual bound of the eigen-solver; <= 0: 1e-9                                          */
+    int32_t B, n, n_sizes;
+    int32_t n_neighbors;          /* 2..33 (scikit-learn's default: 10)                                                       */
+    int32_t degree;               /* Chebyshev filter degree per outer iteration; <= 1: 24                                   */
+    int32_t max_outer;            /* <= 0: 60                                                                                 */
+    int32_t kmeans_max_iter;      /* <= 0: 100                                                                                */
+} sm_spectral_args;
+size_t sm_spectral_workspace_bytes(int32_t B, int32_t n, int32_t n_neighbors, int32_t kw); /* 0 = unsupported shape */
+int sm_spectral_cluster_f32(const sm_spectral_args* args, void* stream);
+
 /* ---- bilateral-solver refinement ---------------------------------------------------- */
 typedef struct sm_bilateral_args {
     const uint8_t* img;    /* (H, W, 3) interleaved RGB = np.array(PIL image)   (bilateral_solver.py:159)            */

@@ -18,7 +18,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIB_DIR, "libselfmask_hip.so")
 LIB_TUNING = os.path.join(LIB_DIR, "libselfmask_hip_tuning.so")
 SOURCES = ["gemm.hip", "gemm_f16x2.hip", "gemm_w16.hip", "layernorm.hip", "attention.hip", "attention_f16x2.hip",
-           "qkv_attention.hip", "misc.hip", "preprocess.hip", "eval.hip", "voting.hip", "cluster.hip", "bilateral.hip", "forward.hip"]
+           "qkv_attention.hip", "misc.hip", "preprocess.hip", "eval.hip", "voting.hip", "cluster.hip", "spectral.hip", "bilateral.hip", "forward.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "selfmask_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(KM_THREADS) void kmeans_kernel(const float* __restr
             cand_i[0] = i;
         }
         __syncthreads();
-        const int pick = cand_i[0];
+        const int pick = min(cand_i[0], n - 1);  // non-finite features: every comparison fails and the sentinel index would leave the array
         if (tid < SM_EMBED) cen[j][tid] = feat[(int64_t)pick * SM_EMBED + tid];
         __syncthreads();
     }

@@ -1,0 +1,745 @@
+// Spectral clustering of the up-sampled encoder features: the clusterer the shipped configuration selects for the pseudo-mask
+// generator (/root/reference/configs/duts-dino-k234-nq20-224-swav-mocov2-dino-p16-sr10100.yaml:11-12 `k: [2,3,4]`,
+// `clustering_mode: "spectral"`; mask_generator.pyc@L30-38,160: `self.clusterer(features, k)`; BASELINE.json configs[4] "faiss k-NN
+// affinity + eigendecomp").  The reference's `clusterings` module exists in NO form in its repository: PARITY UNPINNED.  What is
+// built is normalised spectral clustering as the paper names it (arXiv 2203.12614 section 3.1), in the exact form scikit-learn's
+// SpectralClustering(affinity="precomputed") evaluates - the third-party witness of oracle/cluster_oracle.py:
+//   1. Gram matrix G = F F^T of the n x 384 features on the matrix cores (sm_gemm_f16x2: fp32-grade products)
+//   2. k-NN: for every point the n_neighbors - 1 nearest others by (|f_i - f_j|^2, j)            [knn_select_kernel]
+//   3. W = (C + C^T) / 2 (C = connectivity, self loops dropped): the transposed lists by bitmap    [knn_graph_kernel]
+//   4. the kw smallest eigenpairs of L = I - D^-1/2 W D^-1/2 in fp64: Chebyshev-filtered subspace
+//      iteration (Zhou & Saad) on a block of 8 vectors, one workgroup per image; embedding rows
+//      u_i = v_i / sqrt(d_i)                                                                        [spectral_embed_kernel]
+//   5. k-means on the first k embedding columns for every requested k (ONE eigen-solve serves all)  [kmeans_embed_kernel]
+// Every sum runs in a fixed order (no floating-point atomics): labels are a function of the input alone.
+#include "common.h"
+
+namespace sm {
+
+constexpr int SP_B = 8;          // block of vectors iterated (wanted kw <= 6 + guards)
+constexpr int SP_THREADS = 512;  // one workgroup per image (8 waves: 256 registers per lane for the 36-entry Gram accumulations)
+constexpr int SP_WAVES = SP_THREADS / 64;
+constexpr int SP_MAXM = 32;      // neighbours kept per point (n_neighbors - 1)
+constexpr int SP_MAXN = 8192;    // points per image
+
+__device__ __forceinline__ double shfl_xor_d(double v, int o) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __shfl_xor((unsigned)u, o, 64), hi = __shfl_xor((unsigned)(u >> 32), o, 64);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+
+// sum of NV values over the workgroup, in a fixed order (butterfly inside a wave, then the waves in index order);
+// every thread returns with the totals in v.  `scratch` holds (SP_WAVES + 1) * NV doubles.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += shfl_xor_d(x, o);
+        v[i] = x;
+    }
+    __syncthreads();  // scratch may still be read from a previous call
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) scratch[wave * NV + i] = v[i];
+    __syncthreads();
+    if (tid < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < SP_WAVES; ++w) s += scratch[w * NV + tid];
+        scratch[SP_WAVES * NV + tid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = scratch[SP_WAVES * NV + i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 2. k-NN selection: one wave per row of the Gram matrix.  key_j = G_jj - 2 G_ij orders the points like |f_i - f_j|^2 (G_ii is
+// common to the row).  Every lane keeps the CAP smallest (key, j) of its strided share in registers (sorted, insertion by
+// compare-select), then the wave merges the 64 sorted lists: CAP... m rounds of a 64-lane arg-min over the list heads.
+template <int CAP>
+__global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict__ gram_all, const float* __restrict__ sq_all, int n, int m,
+                                                         int* __restrict__ idx_all) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float* g = gram_all + ((int64_t)blockIdx.y * n + row) * n;
+    const float* sq = sq_all + (int64_t)blockIdx.y * n;
+    float key[CAP];
+    int id[CAP];
+#pragma unroll
+    for (int p = 0; p < CAP; ++p) { key[p] = INFINITY; id[p] = 0x7fffffff; }
+    for (int j = lane; j < n; j += 64) {
+        if (j == row) continue;
+        const float kj = sq[j] - 2.0f * g[j];
+        if (kj < key[CAP - 1]) {  // j ascends within a lane: on equal keys the earlier index stays in front
+#pragma unroll
+            for (int p = CAP - 1; p > 0; --p) {
+                const bool up = kj < key[p - 1];  // the element above moves down
+                const bool here = !up && kj < key[p];
+                key[p] = up ? key[p - 1] : (here ? kj : key[p]);
+                id[p] = up ? id[p - 1] : (here ? j : id[p]);
+            }
+            if (kj < key[0]) { key[0] = kj; id[0] = j; }
+        }
+    }
+    int* out = idx_all + ((int64_t)blockIdx.y * n + row) * m;
+    for (int r = 0; r < m; ++r) {
+        float bk = key[0];
+        int bi = id[0];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ok = __shfl_xor(bk, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ok < bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+        }
+        // non-finite features leave the lists empty: any valid index keeps the later kernels inside their arrays
+        if (lane == 0) out[r] = (unsigned)bi < (unsigned)n ? bi : (row + 1 + r) % n;
+        if (id[0] == bi) {  // the owner pops its head (indices are unique across lanes)
+#pragma unroll
+            for (int p = 0; p < CAP - 1; ++p) { key[p] = key[p + 1]; id[p] = id[p + 1]; }
+            key[CAP - 1] = INFINITY;
+            id[CAP - 1] = 0x7fffffff;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3. the transposed neighbour lists (who lists me) in ascending source order, and 1 / sqrt(degree).  One workgroup per image:
+// bit (t, i) of a n x n bitmap (zeroed by a memset on the stream) <- i lists t (integer atomics: the RESULT does not depend on their order), then one wave per
+// row turns the set bits into a list.  d_t = (m + in_degree_t) / 2: every listed pair contributes 1/2 to both ends.
+__global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __restrict__ idx_all, int n, int m,
+                                                               unsigned long long* __restrict__ bits_all, int* __restrict__ inptr_all,
+                                                               int* __restrict__ incol_all, double* __restrict__ isd_all) {
+    __shared__ int part[SP_THREADS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img = blockIdx.x;
+    const int nw = (n + 63) / 64;
+    const int* idx = idx_all + (int64_t)img * n * m;
+    unsigned long long* bits = bits_all + (int64_t)img * n * nw;
+    int* inptr = inptr_all + (int64_t)img * (n + 1);
+    int* incol = incol_all + (int64_t)img * n * m;
+    double* isd = isd_all + (int64_t)img * n;
+    for (int64_t e = tid; e < (int64_t)n * m; e += SP_THREADS) {
+        const int i = (int)(e / m), t = idx[e];
+        atomicOr(&bits[(int64_t)t * nw + (i >> 6)], 1ull << (i & 63));
+    }
+    __threadfence();
+    __syncthreads();
+    // in-degree of this thread's contiguous chunk of rows, exclusive scan over the workgroup
+    const int per = (n + SP_THREADS - 1) / SP_THREADS, r0 = tid * per, r1 = min(n, r0 + per);
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) {
+        int c = 0;
+        for (int w = 0; w < nw; ++w) c += __popcll(__hip_atomic_load(&bits[(int64_t)r * nw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        inptr[r + 1] = c;  // count for now
+        isd[r] = 1.0 / sqrt(0.5 * (double)(m + c));
+        mine += c;
+    }
+    part[tid] = mine;
+    __syncthreads();
+    if (wave == 0) {  // the partial sums: SP_WAVES per lane, then a 64-lane inclusive scan
+        int s[SP_WAVES], tot = 0;
+#pragma unroll
+        for (int q = 0; q < SP_WAVES; ++q) { s[q] = tot; tot += part[lane * SP_WAVES + q]; }
+        int inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        const int base = inc - tot;
+#pragma unroll
+        for (int q = 0; q < SP_WAVES; ++q) part[lane * SP_WAVES + q] = base + s[q];
+    }
+    __syncthreads();
+    {
+        int run = part[tid];
+        for (int r = r0; r < r1; ++r) {
+            const int c = inptr[r + 1];
+            inptr[r] = run;
+            run += c;
+        }
+        if (r1 == n && r0 < n) inptr[n] = run;
+    }
+    __syncthreads();
+    for (int r = wave; r < n; r += SP_WAVES) {
+        int pos = inptr[r];
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned long long word = w < nw ? __hip_atomic_load(&bits[(int64_t)r * nw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            const int c = __popcll(word);
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += v;
+            }
+            int at = pos + inc - c;
+            while (word) {
+                incol[at++] = w * 64 + __builtin_ctzll(word);
+                word &= word - 1;
+            }
+            pos += __shfl(inc, 63, 64);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 4. eigen-solver
+struct SpGraph {
+    const int* out;
+    const int* inptr;
+    const int* incol;
+    const double* isd;
+    int n, m;
+};
+
+// (S x)_i * 2 / isd_i for column j: sum over the listed and the listing neighbours of isd_nb * x_nb (fixed order)
+__device__ __forceinline__ double sp_gather(const SpGraph& g, const double* __restrict__ X, int i, int j) {
+    double acc = 0.0;
+    const int* o = g.out + (int64_t)i * g.m;
+    for (int e = 0; e < g.m; ++e) {
+        const int nb = o[e];
+        acc += g.isd[nb] * X[(int64_t)nb * SP_B + j];
+    }
+    const int e1 = g.inptr[i + 1];
+    for (int e = g.inptr[i]; e < e1; ++e) {
+        const int nb = g.incol[e];
+        acc += g.isd[nb] * X[(int64_t)nb * SP_B + j];
+    }
+    return acc;
+}
+
+// cyclic Jacobi on the symmetric SP_B x SP_B matrix h (destroyed); eigenvalues ascending in th, eigenvectors in the columns of z
+__device__ void jacobi_eig(double (*h)[SP_B], double (*z)[SP_B], double* th) {
+    for (int i = 0; i < SP_B; ++i)
+        for (int j = 0; j < SP_B; ++j) z[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < SP_B; ++i)
+            for (int j = 0; j < SP_B; ++j) (i == j ? dia : off) += h[i][j] * h[i][j];
+        if (off <= 1e-34 * dia || off == 0.0) break;
+        for (int p = 0; p < SP_B - 1; ++p)
+            for (int q = p + 1; q < SP_B; ++q) {
+                const double apq = h[p][q];
+                if (apq == 0.0) continue;
+                const double tau = (h[q][q] - h[p][p]) / (2.0 * apq);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int k = 0; k < SP_B; ++k) {
+                    const double hkp = h[k][p], hkq = h[k][q];
+                    h[k][p] = c * hkp - s * hkq;
+                    h[k][q] = s * hkp + c * hkq;
+                }
+                for (int k = 0; k < SP_B; ++k) {
+                    const double hpk = h[p][k], hqk = h[q][k];
+                    h[p][k] = c * hpk - s * hqk;
+                    h[q][k] = s * hpk + c * hqk;
+                }
+                for (int k = 0; k < SP_B; ++k) {
+                    const double zkp = z[k][p], zkq = z[k][q];
+                    z[k][p] = c * zkp - s * zkq;
+                    z[k][q] = s * zkp + c * zkq;
+                }
+            }
+    }
+    for (int i = 0; i < SP_B; ++i) th[i] = h[i][i];
+    for (int i = 0; i < SP_B - 1; ++i) {  // selection sort, ascending; columns of z follow
+        int b = i;
+        for (int j = i + 1; j < SP_B; ++j)
+            if (th[j] < th[b]) b = j;
+        if (b != i) {
+            const double t = th[i];
+            th[i] = th[b];
+            th[b] = t;
+            for (int k = 0; k < SP_B; ++k) {
+                const double u = z[k][i];
+                z[k][i] = z[k][b];
+                z[k][b] = u;
+            }
+        }
+    }
+}
+
+struct SpShared {
+    double red[(SP_WAVES + 1) * 36];
+    double g[SP_B][SP_B];   // Gram / projected matrix
+    double z[SP_B][SP_B];   // R^-1 or the Ritz rotation
+    double th[SP_B];
+    double res[SP_B];
+    int flag;
+};
+
+// X <- X R^-1 with R^T R = X^T X + shift * trace * I (Cholesky QR); row-local after one workgroup reduction
+__device__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShared& sh, int* guard) {
+    const int tid = threadIdx.x;
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll 1
+    for (int r = tid; r < n; r += SP_THREADS) {
+        double x[SP_B];
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) x[j] = X[(int64_t)r * SP_B + j];
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a)
+#pragma unroll
+            for (int b = a; b < SP_B; ++b) acc[t++] += x[a] * x[b];
+    }
+    block_sum<36>(acc, sh.red);
+    if (tid == 0) {
+        double tr = 0.0;
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a)
+#pragma unroll
+            for (int b = a; b < SP_B; ++b) {
+                sh.g[a][b] = sh.g[b][a] = acc[t++];
+                if (a == b) tr += acc[t - 1];
+            }
+        for (int a = 0; a < SP_B; ++a) sh.g[a][a] += shift * tr;
+        // upper Cholesky factor R (R^T R = G), in place in the upper triangle
+        for (int a = 0; a < SP_B; ++a) {
+            double d = sh.g[a][a];
+            for (int k = 0; k < a; ++k) d -= sh.g[k][a] * sh.g[k][a];
+            if (!(d > 1e-300 * tr)) { d = fmax(1e-30 * tr, 1e-300); *guard = 1; }
+            const double raa = sqrt(d);
+            sh.g[a][a] = raa;
+            for (int b = a + 1; b < SP_B; ++b) {
+                double s = sh.g[a][b];
+                for (int k = 0; k < a; ++k) s -= sh.g[k][a] * sh.g[k][b];
+                sh.g[a][b] = s / raa;
+            }
+        }
+        // z = R^-1 (upper triangular)
+        for (int b = 0; b < SP_B; ++b) {
+            for (int a = 0; a < SP_B; ++a) sh.z[a][b] = 0.0;
+            sh.z[b][b] = 1.0 / sh.g[b][b];
+            for (int a = b - 1; a >= 0; --a) {
+                double s = 0.0;
+                for (int k = a + 1; k <= b; ++k) s += sh.g[a][k] * sh.z[k][b];
+                sh.z[a][b] = -s / sh.g[a][a];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r = tid; r < n; r += SP_THREADS) {
+        double x[SP_B], y[SP_B];
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) x[j] = X[(int64_t)r * SP_B + j];
+#pragma unroll
+        for (int b = 0; b < SP_B; ++b) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a <= b; ++a) s += x[a] * sh.z[a][b];
+            y[b] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) X[(int64_t)r * SP_B + j] = y[j];
+    }
+    __syncthreads();
+}
+
+// Rayleigh-Ritz on the orthonormal block Q with LQ = L Q: H = Q^T LQ, H = Z Theta Z^T, Q <- Q Z, LQ <- LQ Z, residual norms
+__device__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, int n, SpShared& sh) {
+    const int tid = threadIdx.x;
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+#pragma unroll 1
+    for (int r = tid; r < n; r += SP_THREADS) {
+        double q[SP_B], l[SP_B];
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) { q[j] = Q[(int64_t)r * SP_B + j]; l[j] = LQ[(int64_t)r * SP_B + j]; }
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a)
+#pragma unroll
+            for (int b = a; b < SP_B; ++b) acc[t++] += 0.5 * (q[a] * l[b] + q[b] * l[a]);  // the symmetric part
+    }
+    block_sum<36>(acc, sh.red);
+    if (tid == 0) {
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a)
+#pragma unroll
+            for (int b = a; b < SP_B; ++b) sh.g[a][b] = sh.g[b][a] = acc[t++];
+        jacobi_eig(sh.g, sh.z, sh.th);
+    }
+    __syncthreads();
+    double rs[SP_B];
+#pragma unroll
+    for (int j = 0; j < SP_B; ++j) rs[j] = 0.0;
+#pragma unroll 1
+    for (int r = tid; r < n; r += SP_THREADS) {
+        double q[SP_B], l[SP_B], qz[SP_B], lz[SP_B];
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) { q[j] = Q[(int64_t)r * SP_B + j]; l[j] = LQ[(int64_t)r * SP_B + j]; }
+#pragma unroll
+        for (int b = 0; b < SP_B; ++b) {
+            double s = 0.0, u = 0.0;
+#pragma unroll
+            for (int a = 0; a < SP_B; ++a) { s += q[a] * sh.z[a][b]; u += l[a] * sh.z[a][b]; }
+            qz[b] = s;
+            lz[b] = u;
+        }
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) {
+            Q[(int64_t)r * SP_B + j] = qz[j];
+            LQ[(int64_t)r * SP_B + j] = lz[j];
+            const double e = lz[j] - sh.th[j] * qz[j];
+            rs[j] += e * e;
+        }
+    }
+    block_sum<SP_B>(rs, sh.red);
+    if (tid == 0)
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) sh.res[j] = sqrt(rs[j]);
+    __syncthreads();
+}
+
+__device__ __forceinline__ double sp_init_value(int img, int i, int j) {  // splitmix64 of (image-independent) (i, j): uniform in (-1, 1)
+    unsigned long long x = ((unsigned long long)i * SP_B + j) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (double)(long long)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+__global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ idx_all, const int* __restrict__ inptr_all,
+                                                                    const int* __restrict__ incol_all, const double* __restrict__ isd_all,
+                                                                    int n, int m, int kw, int degree, int max_outer, double tol,
+                                                                    double* __restrict__ blocks_all, double* __restrict__ eig_all,
+                                                                    double* __restrict__ emb_all, double* __restrict__ res_all,
+                                                                    int* __restrict__ info_all) {
+    __shared__ SpShared sh;
+    const int tid = threadIdx.x, img = blockIdx.x;
+    SpGraph g;
+    g.out = idx_all + (int64_t)img * n * m;
+    g.inptr = inptr_all + (int64_t)img * (n + 1);
+    g.incol = incol_all + (int64_t)img * n * m;
+    g.isd = isd_all + (int64_t)img * n;
+    g.n = n;
+    g.m = m;
+    double* U = blocks_all + (int64_t)img * 2 * n * SP_B;  // the Ritz vectors
+    double* V = U + (int64_t)n * SP_B;                     // L U
+    int guard = 0, matvecs = 0, outer = 0, converged = 0;
+
+    for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
+        const int i = (int)(t / SP_B), j = (int)(t % SP_B);
+        U[t] = j == 0 ? 1.0 / g.isd[i] : sp_init_value(img, i, j);  // column 0: sqrt(d), the eigenvector of eigenvalue 0
+    }
+    __syncthreads();
+    chol_qr_pass(U, n, 1e-11, sh, &guard);
+    chol_qr_pass(U, n, 0.0, sh, &guard);
+    chol_qr_pass(U, n, 0.0, sh, &guard);
+    for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
+        const int i = (int)(t / SP_B), j = (int)(t % SP_B);
+        V[t] = U[t] - 0.5 * g.isd[i] * sp_gather(g, U, i, j);
+    }
+    ++matvecs;
+    __syncthreads();
+    rayleigh_ritz(U, V, n, sh);
+
+    double* X = U;
+    double* Y = V;
+    for (outer = 0;; ++outer) {
+        double worst = 0.0;
+        for (int j = 0; j < kw; ++j) worst = fmax(worst, sh.res[j]);
+        if (worst <= tol) { converged = 1; break; }
+        if (outer >= max_outer) break;
+        // Chebyshev filter of degree `degree` damping [a, 2] (a = the block's largest Ritz value), scaled so that the eigenvalue 0
+        // keeps the gain 1 (Zhou & Saad 2007, "Chebyshev-filtered subspace iteration", scaled filter): X_0 = U, X_1 = (L U - c U) s/e,
+        // X_{i+1} = (L X_i - c X_i) 2 s'/e - s s' X_{i-1}, written over X_{i-1} in place (it is read at (row, column) itself only)
+        const double a = fmin(fmax(sh.th[SP_B - 1], 1e-8), 1.9), ub = 2.0;
+        const double e = 0.5 * (ub - a), c0 = 0.5 * (ub + a);
+        double sig = e / (0.0 - c0);
+        const double tau = 2.0 / sig;
+        __syncthreads();  // everyone has read sh.res / sh.th
+        X = U;
+        Y = V;
+        {
+            const double f = sig / e;
+            for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) Y[t] = (Y[t] - c0 * X[t]) * f;
+        }
+        __syncthreads();
+        for (int it = 2; it <= degree; ++it) {
+            const double sn = 1.0 / (tau - sig);
+            const double f1 = 2.0 * sn / e, f2 = sig * sn;
+            for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
+                const int i = (int)(t / SP_B), j = (int)(t % SP_B);
+                const double y = Y[t];
+                const double ly = y - 0.5 * g.isd[i] * sp_gather(g, Y, i, j);
+                X[t] = (ly - c0 * y) * f1 - f2 * X[t];
+            }
+            ++matvecs;
+            __syncthreads();
+            double* sw = X;
+            X = Y;
+            Y = sw;
+            sig = sn;
+        }
+        // Y holds the filtered block, X is free
+        chol_qr_pass(Y, n, 1e-11, sh, &guard);
+        chol_qr_pass(Y, n, 0.0, sh, &guard);
+        chol_qr_pass(Y, n, 0.0, sh, &guard);
+        for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
+            const int i = (int)(t / SP_B), j = (int)(t % SP_B);
+            X[t] = Y[t] - 0.5 * g.isd[i] * sp_gather(g, Y, i, j);
+        }
+        ++matvecs;
+        __syncthreads();
+        rayleigh_ritz(Y, X, n, sh);
+        U = Y;
+        V = X;
+    }
+    // results: eigenvalues ascending, embedding rows v_i / sqrt(d_i), first kw columns
+    double* emb = emb_all + (int64_t)img * n * kw;
+    for (int64_t t = tid; t < (int64_t)n * kw; t += SP_THREADS) {
+        const int i = (int)(t / kw), j = (int)(t % kw);
+        emb[t] = U[(int64_t)i * SP_B + j] * g.isd[i];
+    }
+    if (tid < kw) {
+        if (eig_all) eig_all[(int64_t)img * kw + tid] = sh.th[tid];
+        if (res_all) res_all[(int64_t)img * kw + tid] = sh.res[tid];
+    }
+    if (tid == 0 && info_all) {
+        int* info = info_all + (int64_t)img * 4;
+        info[0] = outer;
+        info[1] = matvecs;
+        info[2] = converged;
+        info[3] = guard;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 5. k-means on the first K columns of the embedding, fp64, one workgroup per (cluster size, image): farthest-point initial
+// centres (first the point farthest from the mean; ties to the lowest index), Lloyd until no label changes (at most max_iter
+// updates), an emptied cluster keeps its centre - oracle/cluster_oracle.py kmeans_embedding.
+
+template <int K>
+__device__ void kmeans_embed_body(const double* __restrict__ emb, int n, int kw, int max_iter, int* __restrict__ labels, double* red,
+                                  double (*cen)[SP_B], double* cand_v, int* cand_i) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the embedding (n x kw doubles, L2-resident) is re-read per pass; the previous label of a point lives in `labels`
+    {
+        double s[K];
+#pragma unroll
+        for (int d = 0; d < K; ++d) s[d] = 0.0;
+#pragma unroll 1
+        for (int p = tid; p < n; p += SP_THREADS) {
+            labels[p] = -1;
+#pragma unroll
+            for (int d = 0; d < K; ++d) s[d] += emb[(int64_t)p * kw + d];
+        }
+        block_sum<K>(s, red);
+        __syncthreads();
+        if (tid == 0)
+            for (int d = 0; d < K; ++d) cen[SP_B - 1][d] = s[d] / (double)n;  // scratch slot: K <= 6
+        __syncthreads();
+    }
+    for (int j = 0; j < K; ++j) {  // farthest point from the mean, then from the nearest centre chosen so far
+        double bv = -1.0;
+        int bi = 0;  // a valid index even when every distance is NaN
+#pragma unroll 1
+        for (int p = tid; p < n; p += SP_THREADS) {
+            double x[K];
+#pragma unroll
+            for (int d = 0; d < K; ++d) x[d] = emb[(int64_t)p * kw + d];
+            double dist = INFINITY;
+            if (j == 0) {
+                dist = 0.0;
+#pragma unroll
+                for (int d = 0; d < K; ++d) { const double t = x[d] - cen[SP_B - 1][d]; dist += t * t; }
+            } else {
+                for (int c = 0; c < j; ++c) {
+                    double dc = 0.0;
+#pragma unroll
+                    for (int d = 0; d < K; ++d) { const double t = x[d] - cen[c][d]; dc += t * t; }
+                    dist = fmin(dist, dc);
+                }
+            }
+            if (dist > bv) { bv = dist; bi = p; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = shfl_xor_d(bv, o);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { cand_v[wave] = bv; cand_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double v = cand_v[0];
+            int i = cand_i[0];
+            for (int w = 1; w < SP_WAVES; ++w)
+                if (cand_v[w] > v || (cand_v[w] == v && cand_i[w] < i)) { v = cand_v[w]; i = cand_i[w]; }
+            i = min(max(i, 0), n - 1);
+            for (int d = 0; d < K; ++d) cen[j][d] = emb[(int64_t)i * kw + d];
+        }
+        __syncthreads();
+    }
+    for (int it = 0; it <= max_iter; ++it) {
+        constexpr int NV = K * K + K + 1;
+        double acc[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+#pragma unroll 1
+        for (int p = tid; p < n; p += SP_THREADS) {
+            double x[K];
+#pragma unroll
+            for (int d = 0; d < K; ++d) x[d] = emb[(int64_t)p * kw + d];
+            double bv = INFINITY;
+            int bc = 0;
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                double dist = 0.0;
+#pragma unroll
+                for (int d = 0; d < K; ++d) { const double t = x[d] - cen[c][d]; dist += t * t; }
+                if (dist < bv) { bv = dist; bc = c; }
+            }
+            if (bc != labels[p]) { acc[NV - 1] += 1.0; labels[p] = bc; }
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                const double w = bc == c ? 1.0 : 0.0;
+                acc[K * K + c] += w;
+#pragma unroll
+                for (int d = 0; d < K; ++d) acc[c * K + d] += w * x[d];
+            }
+        }
+        block_sum<NV>(acc, red);
+        __syncthreads();
+        if (acc[NV - 1] == 0.0 || it == max_iter) break;  // uniform: every thread holds the same totals
+        if (tid == 0)
+            for (int c = 0; c < K; ++c)
+                if (acc[K * K + c] > 0.0)
+                    for (int d = 0; d < K; ++d) cen[c][d] = acc[c * K + d] / acc[K * K + c];
+        __syncthreads();
+    }
+}
+
+struct KeSizes { int k[8]; };
+
+__global__ __launch_bounds__(SP_THREADS) void kmeans_embed_kernel(const double* __restrict__ emb_all, int n, int kw, KeSizes sizes, int n_sizes,
+                                                                  int max_iter, int* __restrict__ labels_all) {
+    __shared__ double red[(SP_WAVES + 1) * 43];
+    __shared__ double cen[SP_B][SP_B];
+    __shared__ double cand_v[SP_WAVES];
+    __shared__ int cand_i[SP_WAVES];
+    const int s = blockIdx.x, img = blockIdx.y;
+    const double* emb = emb_all + (int64_t)img * n * kw;
+    int* labels = labels_all + ((int64_t)img * n_sizes + s) * n;
+    switch (sizes.k[s]) {
+        case 1:
+            for (int p = threadIdx.x; p < n; p += SP_THREADS) labels[p] = 0;
+            break;
+        case 2: kmeans_embed_body<2>(emb, n, kw, max_iter, labels, red, cen, cand_v, cand_i); break;
+        case 3: kmeans_embed_body<3>(emb, n, kw, max_iter, labels, red, cen, cand_v, cand_i); break;
+        case 4: kmeans_embed_body<4>(emb, n, kw, max_iter, labels, red, cen, cand_v, cand_i); break;
+        case 5: kmeans_embed_body<5>(emb, n, kw, max_iter, labels, red, cen, cand_v, cand_i); break;
+        default: kmeans_embed_body<6>(emb, n, kw, max_iter, labels, red, cen, cand_v, cand_i); break;
+    }
+}
+
+// squared norms = the diagonal of the Gram matrix, compact (the selection reads them once per row of the matrix)
+__global__ __launch_bounds__(256) void gram_diag_kernel(const float* __restrict__ gram, int n, int64_t total, float* __restrict__ sq) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < total) sq[t] = gram[(t / n) * (int64_t)n * n + (t % n) * (int64_t)(n + 1)];
+}
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct SpLayout {
+    size_t fs, gram, sq, idx, bits, inptr, incol, isd, blocks, emb, total;
+};
+static SpLayout sp_layout(int B, int n, int m, int kw) {
+    SpLayout l;
+    size_t o = 0;
+    const size_t nw = (n + 63) / 64;
+    l.fs = o;     o += al256((size_t)B * n * SM_EMBED * 4);
+    l.gram = o;   o += al256((size_t)B * n * n * 4);
+    l.sq = o;     o += al256((size_t)B * n * 4);
+    l.idx = o;    o += al256((size_t)B * n * m * 4);
+    l.bits = o;   o += al256((size_t)B * n * nw * 8);
+    l.inptr = o;  o += al256((size_t)B * (n + 1) * 4);
+    l.incol = o;  o += al256((size_t)B * n * m * 4);
+    l.isd = o;    o += al256((size_t)B * n * 8);
+    l.blocks = o; o += al256((size_t)B * 2 * n * SP_B * 8);
+    l.emb = o;    o += al256((size_t)B * n * kw * 8);
+    l.total = o;
+    return l;
+}
+
+}  // namespace sm
+
+extern "C" size_t sm_spectral_workspace_bytes(int32_t B, int32_t n, int32_t n_neighbors, int32_t kw) {
+    if (B < 1 || n < 2 * sm::SP_B || n > sm::SP_MAXN || n_neighbors < 2 || n_neighbors - 1 > sm::SP_MAXM || kw < 1 || kw > 6) return 0;
+    const int m = n_neighbors - 1 < n - 1 ? n_neighbors - 1 : n - 1;
+    return sm::sp_layout(B, n, m, kw).total;
+}
+
+extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) {
+    SM_REQUIRE(a && a->features && a->labels && a->cluster_sizes && a->workspace, "sm_spectral_cluster_f32: null pointer");
+    SM_REQUIRE(a->B >= 1 && a->n >= 2 * sm::SP_B && a->n <= sm::SP_MAXN && a->n % 4 == 0,
+               "sm_spectral_cluster_f32: %d points (16 <= n <= %d, n %% 4 == 0)", a->n, sm::SP_MAXN);
+    SM_REQUIRE(a->n_neighbors >= 2 && a->n_neighbors - 1 <= sm::SP_MAXM, "sm_spectral_cluster_f32: n_neighbors %d (2..%d)", a->n_neighbors,
+               sm::SP_MAXM + 1);
+    SM_REQUIRE(a->n_sizes >= 1 && a->n_sizes <= 8, "sm_spectral_cluster_f32: 1..8 cluster sizes");
+    int kw = 0;
+    sm::KeSizes sizes = {};
+    for (int i = 0; i < a->n_sizes; ++i) {
+        SM_REQUIRE(a->cluster_sizes[i] >= 1 && a->cluster_sizes[i] <= 6, "sm_spectral_cluster_f32: cluster size %d (1..6)", a->cluster_sizes[i]);
+        sizes.k[i] = a->cluster_sizes[i];
+        if (sizes.k[i] > kw) kw = sizes.k[i];
+    }
+    const int B = a->B, n = a->n, m = a->n_neighbors - 1 < n - 1 ? a->n_neighbors - 1 : n - 1;
+    const sm::SpLayout l = sm::sp_layout(B, n, m, kw);
+    SM_REQUIRE(a->workspace_bytes >= l.total && ((uintptr_t)a->workspace % 256 == 0),
+               "sm_spectral_cluster_f32: workspace of %zu bytes, %zu needed (256-B aligned)", a->workspace_bytes, l.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    float* fs = (float*)(ws + l.fs);
+    float* gram = (float*)(ws + l.gram);
+    int* idx = a->knn ? a->knn : (int*)(ws + l.idx);
+    double* emb = a->embedding ? a->embedding : (double*)(ws + l.emb);
+    int rc = sm_split_f16x2(a->features, SM_EMBED, fs, SM_EMBED, (int64_t)B * n, SM_EMBED, stream);
+    if (rc) return rc;
+    sm_gemm_args g = {};
+    g.A = fs;
+    g.W = fs;
+    g.C = gram;
+    g.strideA = g.strideW = (int64_t)n * SM_EMBED;
+    g.strideC = (int64_t)n * n;
+    g.M = g.N = n;
+    g.K = SM_EMBED;
+    g.lda = g.ldw = SM_EMBED;
+    g.ldc = n;
+    g.batch = B;
+    g.epilogue = SM_EPI_BIAS;
+    rc = sm_gemm_f16x2(&g, 0, stream);
+    if (rc) return rc;
+    float* sq = (float*)(ws + l.sq);
+    hipLaunchKernelGGL(sm::gram_diag_kernel, dim3((unsigned)(((int64_t)B * n + 255) / 256)), dim3(256), 0, st, gram, n, (int64_t)B * n, sq);
+    if (m <= 16)
+        hipLaunchKernelGGL(sm::knn_select_kernel<16>, dim3((n + 3) / 4, B), dim3(256), 0, st, gram, sq, n, m, idx);
+    else
+        hipLaunchKernelGGL(sm::knn_select_kernel<32>, dim3((n + 3) / 4, B), dim3(256), 0, st, gram, sq, n, m, idx);
+    if (hipMemsetAsync(ws + l.bits, 0, (size_t)B * n * ((n + 63) / 64) * 8, st) != hipSuccess) {
+        sm::set_error("sm_spectral_cluster_f32: hipMemsetAsync failed");
+        return SM_ELAUNCH;
+    }
+    hipLaunchKernelGGL(sm::knn_graph_kernel, dim3(B), dim3(sm::SP_THREADS), 0, st, idx, n, m, (unsigned long long*)(ws + l.bits),
+                       (int*)(ws + l.inptr), (int*)(ws + l.incol), (double*)(ws + l.isd));
+    const int degree = a->degree > 1 ? a->degree : 24, max_outer = a->max_outer > 0 ? a->max_outer : 60;
+    const double tol = a->tol > 0.0 ? a->tol : 1e-9;
+    hipLaunchKernelGGL(sm::spectral_embed_kernel, dim3(B), dim3(sm::SP_THREADS), 0, st, idx, (const int*)(ws + l.inptr),
+                       (const int*)(ws + l.incol), (const double*)(ws + l.isd), n, m, kw, degree, max_outer, tol, (double*)(ws + l.blocks),
+                       a->eigenvalues, emb, a->residuals, a->info);
+    hipLaunchKernelGGL(sm::kmeans_embed_kernel, dim3(a->n_sizes, B), dim3(sm::SP_THREADS), 0, st, emb, n, kw, sizes, a->n_sizes,
+                       a->kmeans_max_iter > 0 ? a->kmeans_max_iter : 100, a->labels);
+    return sm::check_launch("sm_spectral_cluster_f32");
+}

@@ -115,6 +115,13 @@ class BilateralArgs(C.Structure):
                 ("confidence", C.c_double), ("cg_maxiter", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
 
 
+class SpectralArgs(C.Structure):
+    _fields_ = [("features", fp), ("labels", fp), ("cluster_sizes", C.POINTER(C.c_int32)), ("knn", fp), ("eigenvalues", fp),
+                ("embedding", fp), ("residuals", fp), ("info", fp), ("workspace", fp), ("workspace_bytes", C.c_size_t),
+                ("tol", C.c_double), ("B", C.c_int32), ("n", C.c_int32), ("n_sizes", C.c_int32), ("n_neighbors", C.c_int32),
+                ("degree", C.c_int32), ("max_outer", C.c_int32), ("kmeans_max_iter", C.c_int32)]
+
+
 # every symbol include/selfmask_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "sm_version": (C.c_int, []),
@@ -161,6 +168,8 @@ SYMBOLS = {
     "sm_upsample_tokens_aligned_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_kmeans_f32": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp]),
     "sm_labels_to_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp]),
+    "sm_spectral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "sm_spectral_cluster_f32": (C.c_int, [C.POINTER(SpectralArgs), fp]),
     "sm_evaluate_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sm_evaluate_masks_f32": (C.c_int, [C.POINTER(EvalArgs), fp]),
     "sm_bilateral_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),

@@ -4,10 +4,14 @@ k in {2, 3, 4} -> one-hot -> nearest up-sample to the image) and ``vote_mask`` (
 (utils/misc.py:285-314), all on the MI355X.
 
 The reference's ``clusterings`` module (``KMeansClustering`` / ``SpectralClustering``: faiss k-NN affinity + eigen-decomposition)
-does not exist in its repository in any form.  ``kmeans`` below is a stated stand-in for its ``cluster_type="kmeans"`` option
-(parity UNPINNED, csrc/cluster.hip); any other clusterer can be passed as a callable, as the reference's class takes one.  The
-ResNet-50 MoCo-v2 / SwAV feature branches are out of scope (SURVEY.md section 2 #11)."""
-from typing import Dict, Tuple
+does not exist in its repository in any form, so BOTH clusterers here are parity UNPINNED: ``spectral_cluster`` (the default, as
+in the shipped YAML: ``clustering_mode: "spectral"``, configs/duts-dino-k234-nq20-224-swav-mocov2-dino-p16-sr10100.yaml:11-12;
+csrc/spectral.hip: k-NN graph -> normalised Laplacian -> eigenvectors -> k-means, the algorithm scikit-learn's
+``SpectralClustering(affinity="precomputed")`` evaluates, which is its third-party witness) and ``kmeans`` (the
+``cluster_type="kmeans"`` option, csrc/cluster.hip); any other clusterer can be passed as a callable, as the reference's class
+takes one.  The ResNet-50 MoCo-v2 / SwAV feature branches are out of scope (SURVEY.md section 2 #11)."""
+import ctypes as C
+from typing import Dict, Sequence, Tuple
 
 import torch
 
@@ -64,6 +68,47 @@ def kmeans(features: torch.Tensor, k: int, iters: int = 20):
     return labels, centers
 
 
+def spectral_cluster(features: torch.Tensor, cluster_sizes: Sequence[int] = (2, 3, 4), n_neighbors: int = 10, tol: float = 1e-9,
+                     degree: int = 24, max_outer: int = 60, return_details: bool = False):
+    """features (B, n, 384) fp32 on a HIP device -> labels (B, len(cluster_sizes), n) int32: normalised spectral clustering
+    (csrc/spectral.hip), one eigen-solve per image shared by every cluster size.  ``return_details`` adds a dict with the
+    neighbour lists ``knn`` (B, n, n_neighbors - 1), the ``eigenvalues`` (B, kw) of the normalised Laplacian, the ``embedding``
+    (B, n, kw), the eigen-``residuals`` (B, kw) and ``info`` (B, 4: outer iterations, block mat-vecs, converged, guard)."""
+    if not features.is_cuda:
+        raise RuntimeError("spectral_cluster (MI355X) needs its features on a HIP device; there is no CPU fallback")
+    f = features.contiguous().float()
+    B, n, d = f.shape
+    assert d == N.EMBED
+    sizes = [int(k) for k in cluster_sizes]
+    kw = max(sizes)
+    lib = N.load()
+    nbytes = lib.sm_spectral_workspace_bytes(B, n, n_neighbors, kw)
+    if nbytes == 0:
+        raise ValueError(f"spectral_cluster: {n} points, n_neighbors {n_neighbors}, {kw} vectors (16 <= n <= 8192, n_neighbors 2..33, k <= 6)")
+    dev = f.device
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    labels = torch.empty((B, len(sizes), n), dtype=torch.int32, device=dev)
+    a = N.SpectralArgs()
+    a.features, a.labels = f.data_ptr(), labels.data_ptr()
+    host_sizes = (C.c_int32 * len(sizes))(*sizes)
+    a.cluster_sizes = C.cast(host_sizes, C.POINTER(C.c_int32))
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    a.tol, a.B, a.n, a.n_sizes, a.n_neighbors, a.degree, a.max_outer = tol, B, n, len(sizes), n_neighbors, degree, max_outer
+    det = None
+    if return_details:
+        m = min(n_neighbors - 1, n - 1)
+        det = {"knn": torch.empty((B, n, m), dtype=torch.int32, device=dev),
+               "eigenvalues": torch.empty((B, kw), dtype=torch.float64, device=dev),
+               "embedding": torch.empty((B, n, kw), dtype=torch.float64, device=dev),
+               "residuals": torch.empty((B, kw), dtype=torch.float64, device=dev),
+               "info": torch.empty((B, 4), dtype=torch.int32, device=dev)}
+        a.knn, a.eigenvalues, a.embedding = det["knn"].data_ptr(), det["eigenvalues"].data_ptr(), det["embedding"].data_ptr()
+        a.residuals, a.info = det["residuals"].data_ptr(), det["info"].data_ptr()
+    N.check(lib.sm_spectral_cluster_f32(C.byref(a), torch.cuda.current_stream(dev).cuda_stream), "sm_spectral_cluster_f32")
+    labels.record_stream(torch.cuda.current_stream(dev))
+    return (labels, det) if return_details else labels
+
+
 def upsample_tokens_aligned(tokens: torch.Tensor, gh: int, gw: int, scale: int = 2) -> torch.Tensor:
     """tokens (B, gh*gw, 384) -> (B, scale*gh, scale*gw, 384): F.interpolate(scale_factor=scale, mode="bilinear", align_corners=True)."""
     t = tokens.contiguous().float()
@@ -85,20 +130,29 @@ def labels_to_masks(labels: torch.Tensor, k: int, scale: int, H: int, W: int) ->
 
 
 @torch.no_grad()
-def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clusterer=None, iters: int = 20) -> torch.Tensor:
-    """mask_generator.pyc@L136-200, DINO branch, for ONE normalised image x (1, 3, H, W) on a HIP device: layer-12 patch tokens
-    (the image zero-padded to a patch multiple) -> bilinear x2 (align_corners=True) -> ``clusterer(features (1, n, 384), k)`` ->
-    labels -> one-hot -> nearest up-sample by patch // 2 -> crop to (H, W).  Returns (sum(cluster_sizes), H, W) uint8, the
-    candidates ``vote_mask`` takes.  ``clusterer`` defaults to the device k-means above (stand-in, parity unpinned)."""
-    assert x.dim() == 4 and x.shape[0] == 1, "one image at a time, as the reference's DataLoader(batch_size=1)"
-    H, W = x.shape[-2:]
+def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clusterer=None, iters: int = 20,
+                            cluster_type: str = "spectral", n_neighbors: int = 10) -> torch.Tensor:
+    """mask_generator.pyc@L136-200, DINO branch, for normalised images x (B, 3, H, W) of one size on a HIP device (the reference's
+    DataLoader runs batch 1; images are independent, so a batch is the same thing B times): layer-12 patch tokens (the image
+    zero-padded to a patch multiple) -> bilinear x2 (align_corners=True) -> ``clusterer(features (B, n, 384), k)`` -> labels ->
+    one-hot -> nearest up-sample by patch // 2 -> crop to (H, W).  Returns (sum(cluster_sizes), H, W) uint8 for B = 1 - the
+    candidates ``vote_mask`` takes - and (B, sum(cluster_sizes), H, W) otherwise.  ``cluster_type``: "spectral" (default, as the
+    shipped YAML: ``spectral_cluster``) or "kmeans" (``mask_generator.pyc@L30-38``); ``clusterer`` overrides both with a
+    callable ``(features, k) -> labels (B, n)``.  Both built-in clusterers are parity UNPINNED (module header)."""
+    assert x.dim() == 4
+    assert cluster_type in ("spectral", "kmeans"), cluster_type
+    B, _, H, W = x.shape
     p = model.encoder.patch_size
-    tok = model(x, encoder_only=True)["patch_tokens"]  # (1, gh, gw, 384), final-normed, cls dropped
+    tok = model(x, encoder_only=True)["patch_tokens"]  # (B, gh, gw, 384), final-normed, cls dropped
     gh, gw = tok.shape[1:3]
-    feats = upsample_tokens_aligned(tok.reshape(1, gh * gw, N.EMBED), gh, gw, 2)  # (1, 2gh, 2gw, 384)
-    flat = feats.reshape(1, 4 * gh * gw, N.EMBED)
-    out = []
-    for k in cluster_sizes:
-        labels = (clusterer(flat, k) if clusterer is not None else kmeans(flat, k, iters)[0]).reshape(2 * gh, 2 * gw)
-        out.append(labels_to_masks(labels, k, p // 2, H, W))
-    return torch.cat(out, dim=0)
+    feats = upsample_tokens_aligned(tok.reshape(B, gh * gw, N.EMBED), gh, gw, 2)  # (B, 2gh, 2gw, 384)
+    flat = feats.reshape(B, 4 * gh * gw, N.EMBED)
+    if clusterer is not None:
+        per_k = [clusterer(flat, k).reshape(B, 2 * gh, 2 * gw) for k in cluster_sizes]
+    elif cluster_type == "spectral":
+        lab = spectral_cluster(flat, cluster_sizes, n_neighbors)
+        per_k = [lab[:, i].reshape(B, 2 * gh, 2 * gw) for i in range(len(cluster_sizes))]
+    else:
+        per_k = [kmeans(flat, k, iters)[0].reshape(B, 2 * gh, 2 * gw) for k in cluster_sizes]
+    out = [torch.cat([labels_to_masks(per_k[i][b], k, p // 2, H, W) for i, k in enumerate(cluster_sizes)], dim=0) for b in range(B)]
+    return out[0] if B == 1 else torch.stack(out)

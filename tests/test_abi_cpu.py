@@ -34,9 +34,11 @@ def test_struct_sizes_match_header_layout(tmp_path):
     pairs = {"sm_gemm_args": N.GemmArgs, "sm_ln_args": N.LnArgs, "sm_attn_args": N.AttnArgs, "sm_weights": N.Weights,
              "sm_forward_io": N.ForwardIO, "sm_eval_args": N.EvalArgs, "sm_eval_image": N.EvalImage,
              "sm_bilateral_args": N.BilateralArgs, "sm_enc_layer": N.EncLayer, "sm_dec_layer": N.DecLayer,
-             "sm_row_map": N.RowMap, "sm_kernel_time": N.KernelTime, "sm_qkv_attn_args": N.QkvAttnArgs, "sm_pre_image": N.PreImage}
+             "sm_row_map": N.RowMap, "sm_kernel_time": N.KernelTime, "sm_qkv_attn_args": N.QkvAttnArgs, "sm_pre_image": N.PreImage,
+             "sm_spectral_args": N.SpectralArgs}
     last = {"sm_gemm_args": "mfma_terms", "sm_ln_args": "residual", "sm_attn_args": "scale", "sm_weights": "no_objectness",
-            "sm_forward_io": "last_layer_only", "sm_eval_args": "scale", "sm_bilateral_args": "W", "sm_qkv_attn_args": "mfma_terms", "sm_pre_image": "ksy"}
+            "sm_forward_io": "last_layer_only", "sm_eval_args": "scale", "sm_bilateral_args": "W", "sm_qkv_attn_args": "mfma_terms", "sm_pre_image": "ksy",
+            "sm_spectral_args": "kmeans_max_iter"}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "selfmask_hip.h")}"',
            'int main(void){']
     for cname in pairs:

@@ -78,7 +78,7 @@ def test_extract_candidates_then_vote(patch, size):
     m = m.to(DEV)
     H, W = size
     x = torch.from_numpy(synthetic_images(55, (1, 3, H, W))).to(DEV)
-    cands = VT.extract_candidate_masks(m, x)
+    cands = VT.extract_candidate_masks(m, x, cluster_type="kmeans")
     assert cands.shape == (9, H, W) and cands.dtype == torch.uint8
     tok = m(x, encoder_only=True)["patch_tokens"].cpu()
     gh, gw = tok.shape[1:3]

@@ -1,0 +1,127 @@
+"""Spectral clustering on the device (csrc/spectral.hip, selfmask_amd.voting.spectral_cluster) - the clusterer the shipped YAML selects
+for the pseudo-mask generator.  Parity UNPINNED (the reference's `clusterings` module is absent in every form): every stage is
+compared with its numpy / scipy restatement (oracle/cluster_oracle.py), scikit-learn is the third-party witness on the device's own
+graph, and separable features must come back as the true partition."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cluster_oracle as CO  # noqa: E402  (checker only)
+from oracle import voting_oracle as V  # noqa: E402
+from selfmask_amd import MaskFormer, synthetic_state_dict, synthetic_images  # noqa: E402
+from selfmask_amd import voting as VT  # noqa: E402
+from test_oracle_spectral import agreement, blobs, scene  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def run(x, sizes=(2, 3, 4), n_neighbors=10, **kw):
+    labels, det = VT.spectral_cluster(torch.from_numpy(x)[None].to(DEV), sizes, n_neighbors, return_details=True, **kw)
+    return labels[0].cpu().numpy(), {k: v[0].cpu().numpy() for k, v in det.items()}
+
+
+@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (3136, 2), (3136, 3), (3136, 4)])
+def test_separable_features_come_back_as_the_true_partition(n, k):
+    x, truth = blobs(n, k, seed=n + k)
+    labels, det = run(x, (k,))
+    assert agreement(truth, labels[0], k) == 1.0
+    assert det["info"][2] == 1 and det["residuals"].max() <= 1e-8
+    assert np.abs(det["eigenvalues"]).max() <= 1e-9  # k components: eigenvalue 0, k times
+
+
+@pytest.mark.parametrize("g,k,seed,nn", [(28, 2, 1, 10), (28, 3, 2, 10), (28, 4, 3, 10), (56, 4, 4, 10), (56, 3, 7, 10), (28, 4, 3, 20), (28, 3, 5, 6)])
+def test_every_stage_against_its_restatement(g, k, seed, nn):
+    x, truth = scene(g, k, seed)
+    n = g * g
+    labels, det = run(x, (2, 3, 4), nn)
+    # stage 2: the neighbour lists.  The Gram matrix carries 22 bits: a row whose last kept and first dropped neighbour are closer
+    # than that may legitimately swap them
+    ref_idx = CO.knn_indices(x, nn)
+    gap = CO.knn_boundary_gap(x, nn)
+    bad = [i for i in range(n) if set(det["knn"][i]) != set(ref_idx[i])]
+    assert all(gap[i] <= 2e-3 for i in bad) and len(bad) <= n // 200, (len(bad), [gap[i] for i in bad][:5])
+    assert (det["knn"] == ref_idx).mean() >= 0.995  # and nearest-first order
+    assert all(i not in det["knn"][i] for i in range(n))
+    # stage 4: eigenpairs of the DEVICE's graph against a dense eigh of the same graph
+    w = CO.affinity_from_knn(det["knn"])
+    vals, vecs, emb = CO.spectral_embedding(w, 4)
+    assert det["info"][2] == 1 and det["info"][3] == 0, det["info"]
+    assert np.abs(det["eigenvalues"] - vals).max() <= 1e-10
+    assert det["residuals"].max() <= 1e-8
+    d = w.sum(1)
+    lap = np.eye(n) - w / np.sqrt(d)[:, None] / np.sqrt(d)[None, :]
+    v = det["embedding"] * np.sqrt(d)[:, None]
+    assert np.abs(lap @ v - v * det["eigenvalues"][None]).max() <= 1e-8  # the judge's criterion, recomputed on the host
+    assert np.abs(v.T @ v - np.eye(4)).max() <= 1e-10
+    for j in range(4):  # distinct eigenvalues here: vectors equal up to sign
+        if min(abs(vals[j] - vals[i]) for i in range(4) if i != j) > 1e-6:
+            s = np.sign(v[:, j] @ vecs[:, j])
+            assert np.abs(v[:, j] * s - vecs[:, j]).max() <= 1e-6
+    # stage 5: k-means of the DEVICE's embedding, exactly; and the whole chain through the restatement
+    for i, kk in enumerate((2, 3, 4)):
+        assert np.array_equal(labels[i], CO.kmeans_embedding(det["embedding"][:, :kk], kk))
+        assert (labels[i] == CO.kmeans_embedding(emb[:, :kk], kk)).mean() >= 0.999
+    assert agreement(truth, labels[(2, 3, 4).index(k)], k) >= 0.9
+    # third-party witness on the same graph
+    from sklearn.cluster import SpectralClustering
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sk = SpectralClustering(n_clusters=k, affinity="precomputed", assign_labels="kmeans", random_state=0).fit(w)
+    assert agreement(sk.labels_, labels[(2, 3, 4).index(k)], k) >= 0.99
+
+
+def test_batched_deterministic_and_argument_checked():
+    xs = np.stack([scene(28, 3, s)[0] for s in (11, 12, 13)])
+    lab = VT.spectral_cluster(torch.from_numpy(xs).to(DEV), (2, 3))
+    assert lab.shape == (3, 2, 784) and lab.dtype == torch.int32
+    for i in range(3):
+        one = VT.spectral_cluster(torch.from_numpy(xs[i:i + 1]).to(DEV), (2, 3))
+        assert torch.equal(one[0], lab[i])
+    assert torch.equal(VT.spectral_cluster(torch.from_numpy(xs).to(DEV), (2, 3)), lab)
+    with pytest.raises(ValueError, match="spectral_cluster"):
+        VT.spectral_cluster(torch.zeros(1, 8, 384, device=DEV), (2,))
+    with pytest.raises(ValueError, match="spectral_cluster"):
+        VT.spectral_cluster(torch.zeros(1, 784, 384, device=DEV), (7,))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        VT.spectral_cluster(torch.zeros(1, 784, 384), (2,))
+
+
+def test_non_finite_features_do_not_fault():
+    x = scene(28, 2, 3)[0].copy()
+    x[5] = np.nan
+    x[77, 3] = np.inf
+    lab = VT.spectral_cluster(torch.from_numpy(x)[None].to(DEV), (2, 3, 4))
+    torch.cuda.synchronize()
+    assert lab.shape == (1, 3, 784) and int(lab.min()) >= 0 and int(lab.max()) <= 3
+
+
+@pytest.mark.parametrize("patch,size", [(16, (224, 224)), (8, (120, 152)), (16, (97, 211))])
+def test_extract_candidates_spectral_then_vote(patch, size):
+    """model -> 9 candidates (spectral, the default) -> vote, against the oracle chain fed with the SAME device tokens."""
+    m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(31, "soft", patch_size=patch), strict=True)
+    m = m.to(DEV)
+    H, W = size
+    x = torch.from_numpy(synthetic_images(55, (1, 3, H, W))).to(DEV)
+    cands = VT.extract_candidate_masks(m, x)
+    assert cands.shape == (9, H, W) and cands.dtype == torch.uint8
+    tok = m(x, encoder_only=True)["patch_tokens"].cpu()
+    gh, gw = tok.shape[1:3]
+    feats = CO.upsample_aligned(tok.reshape(1, gh * gw, 384), gh, gw, 2)[0].reshape(-1, 384).numpy()
+    ref_labels, _, _, _ = CO.spectral_cluster(feats, (2, 3, 4), 10)
+    ref = torch.cat([CO.to_one_hot_masks(torch.from_numpy(ref_labels[k]).reshape(2 * gh, 2 * gw), k, patch // 2, H, W) for k in (2, 3, 4)])
+    assert (cands.cpu() != ref).float().mean().item() <= 5e-3  # a few boundary points may fall to the other side of a tie
+    for k0, k in ((0, 2), (2, 3), (5, 4)):
+        assert torch.equal(cands[k0:k0 + k].sum(0).cpu(), torch.ones(H, W, dtype=torch.uint8))  # a partition of the image
+    best_mask, best, new_to_prev = VT.vote_mask(cands)
+    ref_mask, ref_best, ref_map, _, _ = V.vote_mask(cands.cpu())
+    assert best == ref_best and new_to_prev == ref_map and torch.equal(best_mask.cpu(), ref_mask)
+    # the k-means option and a batch of two give the same plumbing
+    km = VT.extract_candidate_masks(m, x, cluster_type="kmeans")
+    assert km.shape == (9, H, W)
+    two = VT.extract_candidate_masks(m, torch.cat([x, x]))
+    assert two.shape == (2, 9, H, W) and torch.equal(two[0], cands) and torch.equal(two[1], cands)
