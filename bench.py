@@ -397,6 +397,145 @@ def shape_leg(dev, P, S, B, streams, steps=20, warmup=5, cpu=True):
     return res
 
 
+def _event_ms(fn, reps, dev):
+    """average device time of fn() over `reps` calls on the current stream (HIP events on that stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def refine_leg(dev, streams, P=16, S=384, B=32, steps=12, warmup=3, cpu=True):
+    """BASELINE.json configs[2]: forward at 384^2 -> picked mask -> bilateral-solver refinement (bilateral_solver.py:152-193) ->
+    metrics, as Evaluator(img_size=384, refine="bilateral") runs it per batch; the same loop without the refinement beside it; the
+    batched solver alone with its algorithmic bytes / time; the CPU oracle solver on one image."""
+    import numpy as np
+    from selfmask_amd import ops
+    from selfmask_amd.bilateral_solver import bilateral_solver_batch_device
+    from selfmask_amd.datasets import MEAN, STD, synthetic_scene
+    w = Workload(dev, P, S, B, streams=streams)
+    rng = np.random.Generator(np.random.PCG64(77))
+    scenes = [synthetic_scene(rng, S, S) for _ in range(B)]
+    u8 = torch.from_numpy(np.stack([im for im, _ in scenes])).to(dev)  # (B, S, S, 3): what the solver refines against
+    mean, std = torch.tensor(MEAN, device=dev), torch.tensor(STD, device=dev)
+    w.x = ((u8.float() / 255.0 - mean) / std).permute(0, 3, 1, 2).contiguous()
+    w.gt_batch = ops.GtBatch([torch.from_numpy(g.astype(np.uint8)) for _, g in scenes], dev)
+    state = {}
+
+    def step_refined():
+        out = w.fwd(w.x)
+        mp, ob = out["mask_pred"][:, -1], out["objectness"][:, -1, :, 0]
+        rows = ops.evaluate_masks(mp, ob, w.gt_batch, scale=0.0)
+        target = ops.upsample_selected(mp, rows, (S, S), "pick")
+        _, binary, info = bilateral_solver_batch_device(u8, target, return_info=True)
+        refined = ops.mask_u8_to_f32(binary).unsqueeze(1)
+        state.update(target=target, info=info)
+        return ops.evaluate_masks(refined, rows[:, 0:1], w.gt_batch, scale=0.0)
+
+    plain = w.step
+    w.prime(warmup)
+    dt_plain = w.timed(steps)
+    w.step = step_refined
+    w.run_steps(2 * len(w.ring.streams))
+    dt_ref = w.timed(steps)
+    w.step = plain
+    target, info = state["target"], state["info"].cpu().numpy()
+    ms_solver = _event_ms(lambda: bilateral_solver_batch_device(u8, target), 5, dev)
+    V, iters = info[:, 0].astype(np.float64), info[:, 1].astype(np.float64)
+    npx = float(S * S)
+    nnz = 6.0 * V  # SURVEY.md 8d: nnz ~ V + sum of the blur matrices' entries ~ 6 V
+    alg = npx * (3 + 5 * 4 + 8 + 8) + 4 * npx * 16 + 4 * npx * (8 + 4) + 11 * (nnz * 12 + 3 * V * 8) + iters * (nnz * 12 + 10 * V * 8)
+    res = {"workload": f"ViT-S/{P} {S}x{S}, nq=20, batch={B}: forward + metrics + bilateral-solver refinement of the picked mask + metrics of "
+                       f"the refined mask (Evaluator(img_size={S}, refine='bilateral') per batch; synthetic ellipse scenes)",
+           "value": round(steps * B / dt_ref, 1), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt_ref / steps * 1e3, 3),
+           "without_refinement_images_per_sec": round(steps * B / dt_plain, 1),
+           "refined_over_plain": round(dt_plain / dt_ref, 3),
+           "solver_alone": {"batch": B, "ms_per_batch": round(ms_solver, 3), "ms_per_image": round(ms_solver / B, 4),
+                            "images_per_sec": round(B / ms_solver * 1e3, 1), "vertices_mean": round(float(V.mean()), 1),
+                            "pcg_iterations_mean": round(float(iters.mean()), 2),
+                            "algorithmic_bytes_per_image": round(float(alg.mean())),
+                            "roofline": {"bound": "hbm", "achieved": round(float(alg.sum()) / (ms_solver * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(float(alg.sum()) / (ms_solver * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                         "note": "latency / irregularity-bound by design (SURVEY.md 8d): a few thousand lattice vertices per "
+                                                 "image, 11 blurs + <= 25 PCG iterations of dependent sparse mat-vecs"}}}
+    if cpu:
+        from oracle import bilateral_oracle as BO  # the BASELINE beside it, never on the product path
+        img0, t0 = u8[0].cpu().numpy(), target[0].cpu().numpy()
+        BO.bilateral_solver_output(img0, t0)
+        n, ts = 0, time.perf_counter()
+        while time.perf_counter() - ts < 4.0:
+            BO.bilateral_solver_output(img0, t0)
+            n += 1
+        dtc = time.perf_counter() - ts
+        res["cpu_baseline"] = {"value": round(n / dtc, 2), "unit": "images/sec", "cores": 1, "kind": "port",
+                               "sample": f"{n} solves of one {S}x{S} image by oracle/bilateral_oracle.py (numpy / scipy restatement of "
+                                         f"bilateral_solver_output, single thread as the reference) in {dtc:.1f}s"}
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
+def pseudo_masks_leg(dev, streams, P=16, S=224, B=16, steps=10, warmup=3, cpu=True):
+    """BASELINE.json configs[4], DINO branch: encoder -> bilinear x2 -> spectral clustering for k = 2, 3, 4 (ONE eigen-solve per
+    image) -> 9 candidate masks -> vote (mask_generator.pyc@L136-230).  images/s of the whole chain, the clusterer alone, and the
+    CPU restatement (oracle/cluster_oracle.py: dense eigh) beside it.  The clusterer is parity UNPINNED (absent from the reference)."""
+    import numpy as np
+    from selfmask_amd import voting as VT
+    w = Workload(dev, P, S, B, streams=1, forward_only=True)
+    model, x = w.model, w.x
+
+    def chain():
+        cands = VT.extract_candidate_masks(model, x)  # (B, 9, S, S)
+        return [VT.vote_mask(cands[b])[1] for b in range(B)]
+
+    for _ in range(warmup):
+        chain()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        chain()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tok = model(x, encoder_only=True)["patch_tokens"]
+    gh, gw = tok.shape[1:3]
+    feats = VT.upsample_tokens_aligned(tok.reshape(B, gh * gw, 384), gh, gw, 2).reshape(B, 4 * gh * gw, 384)
+    ms_enc = _event_ms(lambda: model(x, encoder_only=True), 10, dev)
+    ms_spec = _event_ms(lambda: VT.spectral_cluster(feats, (2, 3, 4)), 10, dev)
+    ms_km = _event_ms(lambda: [VT.kmeans(feats, k) for k in (2, 3, 4)], 5, dev)
+    _, det = VT.spectral_cluster(feats, (2, 3, 4), return_details=True)
+    info = det["info"].cpu().numpy()
+    n = 4 * gh * gw
+    res = {"workload": f"ViT-S/{P} {S}x{S}, batch={B}: encoder -> bilinear x2 ({n} points x 384) -> spectral clustering k=2,3,4 (10-NN graph, "
+                       f"normalised Laplacian, 4 eigenvectors, k-means) -> 9 candidates -> vote",
+           "value": round(steps * B / dt, 1), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+           "encoder_ms_per_batch": round(ms_enc, 3), "spectral_cluster_ms_per_batch": round(ms_spec, 3),
+           "spectral_cluster_images_per_sec": round(B / ms_spec * 1e3, 1),
+           "kmeans_option_ms_per_batch": round(ms_km, 3),
+           "eigensolver": {"outer_iterations_mean": round(float(info[:, 0].mean()), 2), "block_matvecs_mean": round(float(info[:, 1].mean()), 1),
+                           "converged": int(info[:, 2].sum()), "of": B, "max_residual": float(det["residuals"].max())},
+           "parity": "UNPINNED: the reference's `clusterings` module is absent in every form; scikit-learn is the witness (tests)"}
+    if cpu:
+        from oracle import cluster_oracle as CO
+        f0 = feats[0].cpu().numpy()
+        CO.spectral_cluster(f0, (2, 3, 4), 10)
+        c, ts = 0, time.perf_counter()
+        while time.perf_counter() - ts < 4.0:
+            CO.spectral_cluster(f0, (2, 3, 4), 10)
+            c += 1
+        dtc = time.perf_counter() - ts
+        res["cpu_baseline"] = {"value": round(c / dtc, 2), "unit": "images/sec", "cores": _cores(), "kind": "port",
+                               "sample": f"{c} runs of oracle/cluster_oracle.spectral_cluster on one image's {n} x 384 features (numpy k-NN + "
+                                         f"scipy dense eigh + numpy k-means; clustering only, no encoder) in {dtc:.1f}s"}
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
 def throughput_mode_leg(dev, ref, steps=30, warmup=6):
     """SURVEY.md 7.2 (b) diagnostic - NOT the metric: the same pipeline with ONE f16 MFMA per product in the weight GEMMs and the
     encoder attention (gemm_mode "f16": plain f16 operands, fp32 accumulate, fp32 LayerNorm / softmax statistics, fp32-grade
@@ -533,6 +672,8 @@ def main():
                     help="GEMM back end (default w16; f16 = the one-MFMA-per-product diagnostic, not the metric)")
     ap.add_argument("--e2e-ranks", action="store_true", help="with --gpus N > 1: also run the end-to-end leg (files -> metrics) on all N ranks")
     ap.add_argument("--no-other-shapes", action="store_true", help="skip the ViT-S/8 224^2 and ViT-S/16 384^2 legs")
+    ap.add_argument("--only-leg", default=None, choices=["refine_384", "pseudo_masks"],
+                    help="run ONE of the extra legs and print its JSON (profiling runs); not the driver's contract")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU rehearsal of the N-rank launch path (gloo, no GPU): same spawn, barrier, gather and "
                          "max-over-ranks timing around a trivial step; used by tests/test_bench_launcher_cpu.py")
@@ -569,6 +710,10 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
 
+    if a.only_leg:
+        leg = {"refine_384": refine_leg, "pseudo_masks": pseudo_masks_leg}[a.only_leg]
+        print(json.dumps({a.only_leg: leg(dev, a.streams, cpu=not a.no_cpu_baseline)}), flush=True)
+        return
     P, S, B = a.patch, a.size, a.batch
     wl = Workload(dev, P, S, B, rank=rank, gemm_mode=a.gemm_mode, streams=a.streams, graph=not a.no_graph, zero_data=a.zero_data,
                   host_input=a.host_input, forward_only=a.forward_only)
@@ -678,6 +823,8 @@ def main():
                 # the shapes the shipped checkpoint (ViT-S/8, configs/duts-...yaml:39) and configs[2] (384^2) run at
                 res["other_shapes"] = {"vit_s8_224": shape_leg(dev, 8, 224, 16, len(ring.streams), cpu=not a.no_cpu_baseline),
                                        "vit_s16_384": shape_leg(dev, 16, 384, 32, len(ring.streams), cpu=not a.no_cpu_baseline)}
+                res["refine_384"] = refine_leg(dev, len(ring.streams), cpu=not a.no_cpu_baseline)       # configs[2]
+                res["pseudo_masks"] = pseudo_masks_leg(dev, len(ring.streams), cpu=not a.no_cpu_baseline)  # configs[4]
         if world == 1 and not a.no_cpu_baseline and not a.quick:
             res["cpu_baseline"] = cpu_baseline(P, S)
         print(json.dumps(res), flush=True)

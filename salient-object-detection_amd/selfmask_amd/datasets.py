@@ -67,6 +67,24 @@ def get_dataset(dir_dataset: str, dataset_name: str, mode: str = "test", eval_im
     return SaliencyTestDataset(dir_dataset, dataset_name, eval_img_size)
 
 
+def synthetic_scene(rng: np.random.Generator, h: int, w: int) -> Tuple[np.ndarray, np.ndarray]:
+    """One random-ellipse scene: (RGB uint8 (h, w, 3), ground truth bool (h, w)) - smooth background, one or two salient ellipses
+    of another colour, sensor noise."""
+    yy, xx = np.mgrid[:h, :w]
+    img = np.empty((h, w, 3), np.float32)
+    for c in range(3):
+        img[..., c] = 110 + 60 * np.sin(xx / rng.uniform(15, 60) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(15, 60))
+    gt = np.zeros((h, w), bool)
+    for _ in range(int(rng.integers(1, 3))):
+        cy, cx = rng.uniform(0.3, 0.7) * h, rng.uniform(0.3, 0.7) * w
+        ry, rx = rng.uniform(0.1, 0.3) * h, rng.uniform(0.1, 0.3) * w
+        e = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1
+        gt |= e
+        img[e] += rng.uniform(-90, 90, size=3).astype(np.float32)
+    img = np.clip(img + rng.standard_normal(img.shape) * 8, 0, 255).astype(np.uint8)
+    return img, gt
+
+
 def write_synthetic_dataset(dir_dataset: str, dataset_name: str, n_images: int, seed: int = 7,
                             size_range: Tuple[int, int] = (300, 400)) -> None:
     """Random-ellipse scenes in the reference's directory layout (there are no real datasets offline)."""
@@ -76,17 +94,6 @@ def write_synthetic_dataset(dir_dataset: str, dataset_name: str, n_images: int, 
     rng = np.random.Generator(np.random.PCG64(seed))
     for i in range(n_images):
         h, w = (int(v) for v in rng.integers(size_range[0], size_range[1] + 1, size=2))
-        yy, xx = np.mgrid[:h, :w]
-        img = np.empty((h, w, 3), np.float32)
-        for c in range(3):
-            img[..., c] = 110 + 60 * np.sin(xx / rng.uniform(15, 60) + rng.uniform(0, 6)) * np.cos(yy / rng.uniform(15, 60))
-        gt = np.zeros((h, w), bool)
-        for _ in range(int(rng.integers(1, 3))):
-            cy, cx = rng.uniform(0.3, 0.7) * h, rng.uniform(0.3, 0.7) * w
-            ry, rx = rng.uniform(0.1, 0.3) * h, rng.uniform(0.1, 0.3) * w
-            e = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1
-            gt |= e
-            img[e] += rng.uniform(-90, 90, size=3).astype(np.float32)
-        img = np.clip(img + rng.standard_normal(img.shape) * 8, 0, 255).astype(np.uint8)
+        img, gt = synthetic_scene(rng, h, w)
         Image.fromarray(img).save(join(dir_dataset, sub, di, f"{i:05d}.jpg"), quality=92)
         Image.fromarray((gt * 255).astype(np.uint8)).save(join(dir_dataset, sub, dg, f"{i:05d}.png"))
