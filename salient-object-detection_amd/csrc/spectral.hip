@@ -107,19 +107,21 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// 3. the transposed neighbour lists (who lists me) in ascending source order, and 1 / sqrt(degree).  One workgroup per image:
-// bit (t, i) of a n x n bitmap (zeroed by a memset on the stream) <- i lists t (integer atomics: the RESULT does not depend on their order), then one wave per
-// row turns the set bits into a list.  d_t = (m + in_degree_t) / 2: every listed pair contributes 1/2 to both ends.
+// 3. the graph as ONE adjacency list per point: its own m neighbours (nearest first), then the points that list it in ascending
+// order - and 1 / sqrt(degree).  One workgroup per image: bit (t, i) of a n x n bitmap (zeroed by a memset on the stream) <- i
+// lists t (integer atomics: the RESULT does not depend on their order), then one wave per row turns the set bits into a list.
+// A pair listed from both ends appears twice, once per direction: W_ij = (C_ij + C_ji) / 2 is "every entry weighs 1/2", and
+// d_t = (m + in_degree_t) / 2.
 __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __restrict__ idx_all, int n, int m,
-                                                               unsigned long long* __restrict__ bits_all, int* __restrict__ inptr_all,
-                                                               int* __restrict__ incol_all, double* __restrict__ isd_all) {
+                                                               unsigned long long* __restrict__ bits_all, int* __restrict__ ptr_all,
+                                                               int* __restrict__ col_all, double* __restrict__ isd_all) {
     __shared__ int part[SP_THREADS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img = blockIdx.x;
     const int nw = (n + 63) / 64;
     const int* idx = idx_all + (int64_t)img * n * m;
     unsigned long long* bits = bits_all + (int64_t)img * n * nw;
-    int* inptr = inptr_all + (int64_t)img * (n + 1);
-    int* incol = incol_all + (int64_t)img * n * m;
+    int* ptr = ptr_all + (int64_t)img * (n + 1);
+    int* col = col_all + (int64_t)img * 2 * n * m;
     double* isd = isd_all + (int64_t)img * n;
     for (int64_t e = tid; e < (int64_t)n * m; e += SP_THREADS) {
         const int i = (int)(e / m), t = idx[e];
@@ -127,15 +129,15 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
     }
     __threadfence();
     __syncthreads();
-    // in-degree of this thread's contiguous chunk of rows, exclusive scan over the workgroup
+    // list length (m + in-degree) of this thread's contiguous chunk of rows, exclusive scan over the workgroup
     const int per = (n + SP_THREADS - 1) / SP_THREADS, r0 = tid * per, r1 = min(n, r0 + per);
     int mine = 0;
     for (int r = r0; r < r1; ++r) {
         int c = 0;
         for (int w = 0; w < nw; ++w) c += __popcll(__hip_atomic_load(&bits[(int64_t)r * nw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        inptr[r + 1] = c;  // count for now
+        ptr[r + 1] = m + c;  // length for now
         isd[r] = 1.0 / sqrt(0.5 * (double)(m + c));
-        mine += c;
+        mine += m + c;
     }
     part[tid] = mine;
     __syncthreads();
@@ -157,15 +159,17 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
     {
         int run = part[tid];
         for (int r = r0; r < r1; ++r) {
-            const int c = inptr[r + 1];
-            inptr[r] = run;
+            const int c = ptr[r + 1];
+            ptr[r] = run;
             run += c;
         }
-        if (r1 == n && r0 < n) inptr[n] = run;
+        if (r1 == n && r0 < n) ptr[n] = run;
     }
     __syncthreads();
     for (int r = wave; r < n; r += SP_WAVES) {
-        int pos = inptr[r];
+        int pos = ptr[r];
+        if (lane < m) col[pos + lane] = idx[(int64_t)r * m + lane];  // m <= 32
+        pos += m;
         for (int w0 = 0; w0 < nw; w0 += 64) {
             const int w = w0 + lane;
             unsigned long long word = w < nw ? __hip_atomic_load(&bits[(int64_t)r * nw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
             }
             int at = pos + inc - c;
             while (word) {
-                incol[at++] = w * 64 + __builtin_ctzll(word);
+                col[at++] = w * 64 + __builtin_ctzll(word);
                 word &= word - 1;
             }
             pos += __shfl(inc, 63, 64);
@@ -189,91 +193,168 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
 // ---------------------------------------------------------------------------------------------------------------------------
 // 4. eigen-solver
 struct SpGraph {
-    const int* out;
-    const int* inptr;
-    const int* incol;
-    const double* isd;
-    int n, m;
+    const int* ptr;     // (n + 1) adjacency list starts
+    const int* col;     // 2 n m entries, each of weight 1/2
+    const double* isd;  // 1 / sqrt(d)
+    int n;
 };
 
-// (S x)_i * 2 / isd_i for column j: sum over the listed and the listing neighbours of isd_nb * x_nb (fixed order)
-__device__ __forceinline__ double sp_gather(const SpGraph& g, const double* __restrict__ X, int i, int j) {
+// sum over the adjacency list [s, t) of ylds[nb * CG + jj], in list order.  The neighbour indices are the only global loads left
+// on this path: the first 24 of a list are requested together from clamped addresses (a list is m + in-degree >= m long; the
+// padding re-reads its last entry and adds 0), longer lists (hubs) finish in a plain loop.
+template <int CG>
+__device__ __forceinline__ double sp_gather_lds(const int* __restrict__ col, int s, int t, const double* ylds, int jj) {
+    const int cnt = t - s;
+    int nb[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) nb[u] = col[s + min(u, cnt - 1)];
     double acc = 0.0;
-    const int* o = g.out + (int64_t)i * g.m;
-    for (int e = 0; e < g.m; ++e) {
-        const int nb = o[e];
-        acc += g.isd[nb] * X[(int64_t)nb * SP_B + j];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) {
+        const double y = ylds[nb[u] * CG + jj];
+        acc += u < cnt ? y : 0.0;
     }
-    const int e1 = g.inptr[i + 1];
-    for (int e = g.inptr[i]; e < e1; ++e) {
-        const int nb = g.incol[e];
-        acc += g.isd[nb] * X[(int64_t)nb * SP_B + j];
-    }
+    for (int e = s + 24; e < t; ++e) acc += ylds[col[e] * CG + jj];
     return acc;
 }
 
-// cyclic Jacobi on the symmetric SP_B x SP_B matrix h (destroyed); eigenvalues ascending in th, eigenvectors in the columns of z
-__device__ void jacobi_eig(double (*h)[SP_B], double (*z)[SP_B], double* th) {
-    for (int i = 0; i < SP_B; ++i)
-        for (int j = 0; j < SP_B; ++j) z[i][j] = i == j ? 1.0 : 0.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        for (int i = 0; i < SP_B; ++i)
-            for (int j = 0; j < SP_B; ++j) (i == j ? dia : off) += h[i][j] * h[i][j];
-        if (off <= 1e-34 * dia || off == 0.0) break;
-        for (int p = 0; p < SP_B - 1; ++p)
-            for (int q = p + 1; q < SP_B; ++q) {
-                const double apq = h[p][q];
-                if (apq == 0.0) continue;
-                const double tau = (h[q][q] - h[p][p]) / (2.0 * apq);
-                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                for (int k = 0; k < SP_B; ++k) {
-                    const double hkp = h[k][p], hkq = h[k][q];
-                    h[k][p] = c * hkp - s * hkq;
-                    h[k][q] = s * hkp + c * hkq;
-                }
-                for (int k = 0; k < SP_B; ++k) {
-                    const double hpk = h[p][k], hqk = h[q][k];
-                    h[p][k] = c * hpk - s * hqk;
-                    h[q][k] = s * hpk + c * hqk;
-                }
-                for (int k = 0; k < SP_B; ++k) {
-                    const double zkp = z[k][p], zkq = z[k][q];
-                    z[k][p] = c * zkp - s * zkq;
-                    z[k][q] = s * zkp + c * zkq;
-                }
-            }
-    }
-    for (int i = 0; i < SP_B; ++i) th[i] = h[i][i];
-    for (int i = 0; i < SP_B - 1; ++i) {  // selection sort, ascending; columns of z follow
-        int b = i;
-        for (int j = i + 1; j < SP_B; ++j)
-            if (th[j] < th[b]) b = j;
-        if (b != i) {
-            const double t = th[i];
-            th[i] = th[b];
-            th[b] = t;
-            for (int k = 0; k < SP_B; ++k) {
-                const double u = z[k][i];
-                z[k][i] = z[k][b];
-                z[k][b] = u;
-            }
+// One step of the Chebyshev recurrence on the scaled variables (see the kernel): Xw <- ((I - D^-1 W) Yr - c0 Yr) f1 - f2 Xw, the
+// gathered block Yr staged through the LDS in groups of CG columns (n * CG doubles fit the workgroup's share of the 160 KB)
+template <int CG>
+__device__ __forceinline__ void sp_filter_step(const SpGraph& g, const double* __restrict__ Yr, double* __restrict__ Xw, double* ylds,
+                                               double c0, double f1, double f2, bool last) {
+    const int n = g.n;
+#pragma unroll 1
+    for (int c = 0; c < SP_B; c += CG) {
+        for (int t = threadIdx.x; t < n * CG; t += SP_THREADS) ylds[t] = Yr[(t / CG) * SP_B + c + t % CG];
+        __syncthreads();
+#pragma unroll 2
+        for (int t = threadIdx.x; t < n * CG; t += SP_THREADS) {
+            const int i = t / CG, jj = t % CG;
+            const double w = g.isd[i], y = ylds[t];
+            const double ly = y - (0.5 * w * w) * sp_gather_lds<CG>(g.col, g.ptr[i], g.ptr[i + 1], ylds, jj);
+            const double xn = (ly - c0 * y) * f1 - f2 * Xw[i * SP_B + c + jj];
+            Xw[i * SP_B + c + jj] = last ? xn / w : xn;  // back to the symmetric variables on the way out
         }
+        __syncthreads();
     }
+}
+
+// the same with every term scaled by isd[nb] (the symmetric form: two loads per neighbour; once per outer iteration)
+__device__ __forceinline__ double sp_gather2(const int* __restrict__ col, int s, int t, const double* __restrict__ isd,
+                                             const double* __restrict__ Y, int j) {
+    double acc = 0.0;
+    int e = s;
+    for (; e + 4 <= t; e += 4) {
+        int nb[4];
+        double y[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nb[u] = col[e + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { y[u] = Y[(int64_t)nb[u] * SP_B + j]; w[u] = isd[nb[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += w[u] * y[u];
+    }
+    for (; e < t; ++e) acc += isd[col[e]] * Y[(int64_t)col[e] * SP_B + j];
+    return acc;
+}
+
+// Out = L In (L = I - D^-1/2 W D^-1/2), block of SP_B columns
+__device__ __forceinline__ void sp_apply_sym(const SpGraph& g, const double* __restrict__ In, double* __restrict__ Out) {
+#pragma unroll 2
+    for (int t = threadIdx.x; t < g.n * SP_B; t += SP_THREADS) {
+        const int i = t / SP_B, j = t % SP_B;
+        Out[t] = In[t] - 0.5 * g.isd[i] * sp_gather2(g.col, g.ptr[i], g.ptr[i + 1], g.isd, In, j);
+    }
+}
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, lane), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
 struct SpShared {
     double red[(SP_WAVES + 1) * 36];
-    double g[SP_B][SP_B];   // Gram / projected matrix
     double z[SP_B][SP_B];   // R^-1 or the Ritz rotation
     double th[SP_B];
     double res[SP_B];
-    int flag;
 };
 
+constexpr int sp_tri(int a, int b) { return a * SP_B - a * (a - 1) / 2 + (b - a); }  // index of (a, b), a <= b, in the packed upper triangle
+
+// Cyclic Jacobi on the symmetric SP_B x SP_B matrix `sym` (packed upper triangle, the same totals in every thread's registers),
+// run by the first wave with the matrix in REGISTERS: lane k < SP_B owns row k of the matrix and row k of the rotation product;
+// a rotation (p, q) is a column update local to every lane, a row update fed by v_readlane broadcasts of rows p and q, and the
+// angle from three broadcast entries (p, q are compile-time constants: the 28 rotations of a sweep are unrolled).  Eigenvalues
+// ascending to sh.th, eigenvectors to the columns of sh.z.  (A single thread walking the same matrices in LDS spent a millisecond per
+// call on dependent LDS round trips - three quarters of the eigen-solver's time.)
+__device__ __forceinline__ void jacobi_eig_wave(const double (&sym)[36], SpShared& sh) {
+    const int lane = threadIdx.x & 63;
+    double a[SP_B], z[SP_B];
+#pragma unroll
+    for (int j = 0; j < SP_B; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < SP_B; ++k) v = lane == k ? sym[k <= j ? sp_tri(k, j) : sp_tri(j, k)] : v;
+        a[j] = v;
+        z[j] = lane == j ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int j = 0; j < SP_B; ++j) {
+            const double sq = lane < SP_B ? a[j] * a[j] : 0.0;
+            if (lane == j) dia += sq; else off += sq;
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { off += shfl_xor_d(off, o); dia += shfl_xor_d(dia, o); }
+        off = readlane_d(off, 0);
+        dia = readlane_d(dia, 0);
+        if (off <= 1e-32 * dia) break;
+#pragma unroll
+        for (int p = 0; p < SP_B - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < SP_B; ++q) {
+                const double app = readlane_d(a[p], p), aqq = readlane_d(a[q], q), apq = readlane_d(a[q], p);
+                if (apq != 0.0) {  // wave-uniform
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                    const double akp = a[p], akq = a[q];  // columns p, q of every row
+                    a[p] = c * akp - s * akq;
+                    a[q] = s * akp + c * akq;
+#pragma unroll
+                    for (int j = 0; j < SP_B; ++j) {  // rows p, q
+                        const double rp = readlane_d(a[j], p), rq = readlane_d(a[j], q);
+                        if (lane == p) a[j] = c * rp - s * rq;
+                        if (lane == q) a[j] = s * rp + c * rq;
+                    }
+                    const double zkp = z[p], zkq = z[q];
+                    z[p] = c * zkp - s * zkq;
+                    z[q] = s * zkp + c * zkq;
+                }
+            }
+    }
+    double mine = 0.0;  // the eigenvalue this lane's diagonal entry became
+#pragma unroll
+    for (int j = 0; j < SP_B; ++j) mine = lane == j ? a[j] : mine;
+    int rank = 0;  // ascending order, ties by index
+#pragma unroll
+    for (int k = 0; k < SP_B; ++k) {
+        const double other = readlane_d(mine, k);
+        rank += (other < mine || (other == mine && k < lane)) ? 1 : 0;
+    }
+    if (lane < SP_B) sh.th[rank] = mine;
+#pragma unroll
+    for (int j = 0; j < SP_B; ++j) {
+        const int rj = __builtin_amdgcn_readlane(rank, j);
+        if (lane < SP_B) sh.z[lane][rj] = z[j];
+    }
+}
+
 // X <- X R^-1 with R^T R = X^T X + shift * trace * I (Cholesky QR); row-local after one workgroup reduction
-__device__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShared& sh, int* guard) {
+__device__ __forceinline__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShared& sh, int* guard) {
     const int tid = threadIdx.x;
     double acc[36];
 #pragma unroll
@@ -290,40 +371,45 @@ __device__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShar
             for (int b = a; b < SP_B; ++b) acc[t++] += x[a] * x[b];
     }
     block_sum<36>(acc, sh.red);
-    if (tid == 0) {
+    if (tid == 0) {  // everything below indexes with compile-time constants: the factor and its inverse live in registers
         double tr = 0.0;
-        int t = 0;
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a) tr += acc[sp_tri(a, a)];
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a) acc[sp_tri(a, a)] += shift * tr;
+        // upper Cholesky factor R (R^T R = G), in place in the packed upper triangle
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a) {
+            double d = acc[sp_tri(a, a)];
+#pragma unroll
+            for (int k = 0; k < a; ++k) d -= acc[sp_tri(k, a)] * acc[sp_tri(k, a)];
+            if (!(d > 1e-300 * tr)) { d = fmax(1e-30 * tr, 1e-300); *guard = 1; }
+            const double raa = sqrt(d);
+            acc[sp_tri(a, a)] = raa;
+#pragma unroll
+            for (int b = a + 1; b < SP_B; ++b) {
+                double sacc = acc[sp_tri(a, b)];
+#pragma unroll
+                for (int k = 0; k < a; ++k) sacc -= acc[sp_tri(k, a)] * acc[sp_tri(k, b)];
+                acc[sp_tri(a, b)] = sacc / raa;
+            }
+        }
+        double inv[36];  // R^-1, upper triangular
+#pragma unroll
+        for (int b = 0; b < SP_B; ++b) {
+            inv[sp_tri(b, b)] = 1.0 / acc[sp_tri(b, b)];
+#pragma unroll
+            for (int a = b - 1; a >= 0; --a) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = a + 1; k <= b; ++k) sacc += acc[sp_tri(a, k)] * inv[sp_tri(k, b)];
+                inv[sp_tri(a, b)] = -sacc / acc[sp_tri(a, a)];
+            }
+        }
 #pragma unroll
         for (int a = 0; a < SP_B; ++a)
 #pragma unroll
-            for (int b = a; b < SP_B; ++b) {
-                sh.g[a][b] = sh.g[b][a] = acc[t++];
-                if (a == b) tr += acc[t - 1];
-            }
-        for (int a = 0; a < SP_B; ++a) sh.g[a][a] += shift * tr;
-        // upper Cholesky factor R (R^T R = G), in place in the upper triangle
-        for (int a = 0; a < SP_B; ++a) {
-            double d = sh.g[a][a];
-            for (int k = 0; k < a; ++k) d -= sh.g[k][a] * sh.g[k][a];
-            if (!(d > 1e-300 * tr)) { d = fmax(1e-30 * tr, 1e-300); *guard = 1; }
-            const double raa = sqrt(d);
-            sh.g[a][a] = raa;
-            for (int b = a + 1; b < SP_B; ++b) {
-                double s = sh.g[a][b];
-                for (int k = 0; k < a; ++k) s -= sh.g[k][a] * sh.g[k][b];
-                sh.g[a][b] = s / raa;
-            }
-        }
-        // z = R^-1 (upper triangular)
-        for (int b = 0; b < SP_B; ++b) {
-            for (int a = 0; a < SP_B; ++a) sh.z[a][b] = 0.0;
-            sh.z[b][b] = 1.0 / sh.g[b][b];
-            for (int a = b - 1; a >= 0; --a) {
-                double s = 0.0;
-                for (int k = a + 1; k <= b; ++k) s += sh.g[a][k] * sh.z[k][b];
-                sh.z[a][b] = -s / sh.g[a][a];
-            }
-        }
+            for (int b = 0; b < SP_B; ++b) sh.z[a][b] = a <= b ? inv[sp_tri(a <= b ? a : b, a <= b ? b : a)] : 0.0;
     }
     __syncthreads();
 #pragma unroll 1
@@ -333,10 +419,10 @@ __device__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShar
         for (int j = 0; j < SP_B; ++j) x[j] = X[(int64_t)r * SP_B + j];
 #pragma unroll
         for (int b = 0; b < SP_B; ++b) {
-            double s = 0.0;
+            double sacc = 0.0;
 #pragma unroll
-            for (int a = 0; a <= b; ++a) s += x[a] * sh.z[a][b];
-            y[b] = s;
+            for (int a = 0; a <= b; ++a) sacc += x[a] * sh.z[a][b];
+            y[b] = sacc;
         }
 #pragma unroll
         for (int j = 0; j < SP_B; ++j) X[(int64_t)r * SP_B + j] = y[j];
@@ -345,7 +431,7 @@ __device__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShar
 }
 
 // Rayleigh-Ritz on the orthonormal block Q with LQ = L Q: H = Q^T LQ, H = Z Theta Z^T, Q <- Q Z, LQ <- LQ Z, residual norms
-__device__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, int n, SpShared& sh) {
+__device__ __forceinline__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, int n, SpShared& sh) {
     const int tid = threadIdx.x;
     double acc[36];
 #pragma unroll
@@ -362,14 +448,7 @@ __device__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, i
             for (int b = a; b < SP_B; ++b) acc[t++] += 0.5 * (q[a] * l[b] + q[b] * l[a]);  // the symmetric part
     }
     block_sum<36>(acc, sh.red);
-    if (tid == 0) {
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < SP_B; ++a)
-#pragma unroll
-            for (int b = a; b < SP_B; ++b) sh.g[a][b] = sh.g[b][a] = acc[t++];
-        jacobi_eig(sh.g, sh.z, sh.th);
-    }
+    if (tid < 64) jacobi_eig_wave(acc, sh);
     __syncthreads();
     double rs[SP_B];
 #pragma unroll
@@ -381,10 +460,10 @@ __device__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, i
         for (int j = 0; j < SP_B; ++j) { q[j] = Q[(int64_t)r * SP_B + j]; l[j] = LQ[(int64_t)r * SP_B + j]; }
 #pragma unroll
         for (int b = 0; b < SP_B; ++b) {
-            double s = 0.0, u = 0.0;
+            double sacc = 0.0, u = 0.0;
 #pragma unroll
-            for (int a = 0; a < SP_B; ++a) { s += q[a] * sh.z[a][b]; u += l[a] * sh.z[a][b]; }
-            qz[b] = s;
+            for (int a = 0; a < SP_B; ++a) { sacc += q[a] * sh.z[a][b]; u += l[a] * sh.z[a][b]; }
+            qz[b] = sacc;
             lz[b] = u;
         }
 #pragma unroll
@@ -402,7 +481,7 @@ __device__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, i
     __syncthreads();
 }
 
-__device__ __forceinline__ double sp_init_value(int img, int i, int j) {  // splitmix64 of (image-independent) (i, j): uniform in (-1, 1)
+__device__ __forceinline__ double sp_init_value(int i, int j) {  // splitmix64 of (i, j): uniform in (-1, 1)
     unsigned long long x = ((unsigned long long)i * SP_B + j) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
     x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
@@ -410,97 +489,79 @@ __device__ __forceinline__ double sp_init_value(int img, int i, int j) {  // spl
     return (double)(long long)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
-__global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ idx_all, const int* __restrict__ inptr_all,
-                                                                    const int* __restrict__ incol_all, const double* __restrict__ isd_all,
-                                                                    int n, int m, int kw, int degree, int max_outer, double tol,
-                                                                    double* __restrict__ blocks_all, double* __restrict__ eig_all,
-                                                                    double* __restrict__ emb_all, double* __restrict__ res_all,
-                                                                    int* __restrict__ info_all) {
+template <int CG>
+__global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ ptr_all, const int* __restrict__ col_all,
+                                                                    const double* __restrict__ isd_all, int n, int m, int kw, int degree,
+                                                                    int max_outer, double tol, double* __restrict__ blocks_all,
+                                                                    double* __restrict__ eig_all, double* __restrict__ emb_all,
+                                                                    double* __restrict__ res_all, int* __restrict__ info_all) {
     __shared__ SpShared sh;
+    extern __shared__ __attribute__((aligned(16))) double ylds[];  // n * CG doubles: the gathered block of a filter step
     const int tid = threadIdx.x, img = blockIdx.x;
     SpGraph g;
-    g.out = idx_all + (int64_t)img * n * m;
-    g.inptr = inptr_all + (int64_t)img * (n + 1);
-    g.incol = incol_all + (int64_t)img * n * m;
+    g.ptr = ptr_all + (int64_t)img * (n + 1);
+    g.col = col_all + (int64_t)img * 2 * n * m;
     g.isd = isd_all + (int64_t)img * n;
     g.n = n;
-    g.m = m;
     double* U = blocks_all + (int64_t)img * 2 * n * SP_B;  // the Ritz vectors
     double* V = U + (int64_t)n * SP_B;                     // L U
     int guard = 0, matvecs = 0, outer = 0, converged = 0;
 
-    for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
-        const int i = (int)(t / SP_B), j = (int)(t % SP_B);
-        U[t] = j == 0 ? 1.0 / g.isd[i] : sp_init_value(img, i, j);  // column 0: sqrt(d), the eigenvector of eigenvalue 0
+    for (int t = tid; t < n * SP_B; t += SP_THREADS) {
+        const int i = t / SP_B, j = t % SP_B;
+        U[t] = j == 0 ? 1.0 / g.isd[i] : sp_init_value(i, j);  // column 0: sqrt(d), the eigenvector of eigenvalue 0
     }
     __syncthreads();
-    chol_qr_pass(U, n, 1e-11, sh, &guard);
-    chol_qr_pass(U, n, 0.0, sh, &guard);
-    chol_qr_pass(U, n, 0.0, sh, &guard);
-    for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
-        const int i = (int)(t / SP_B), j = (int)(t % SP_B);
-        V[t] = U[t] - 0.5 * g.isd[i] * sp_gather(g, U, i, j);
-    }
-    ++matvecs;
-    __syncthreads();
-    rayleigh_ritz(U, V, n, sh);
-
-    double* X = U;
-    double* Y = V;
     for (outer = 0;; ++outer) {
+        // U holds the block to work on (the start block, then the filtered one): orthonormalise, V = L U, Rayleigh-Ritz
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) chol_qr_pass(U, n, pass == 0 ? 1e-11 : 0.0, sh, &guard);  // shifted Cholesky QR, three passes
+        sp_apply_sym(g, U, V);
+        ++matvecs;
+        __syncthreads();
+        rayleigh_ritz(U, V, n, sh);
         double worst = 0.0;
         for (int j = 0; j < kw; ++j) worst = fmax(worst, sh.res[j]);
         if (worst <= tol) { converged = 1; break; }
         if (outer >= max_outer) break;
         // Chebyshev filter of degree `degree` damping [a, 2] (a = the block's largest Ritz value), scaled so that the eigenvalue 0
         // keeps the gain 1 (Zhou & Saad 2007, "Chebyshev-filtered subspace iteration", scaled filter): X_0 = U, X_1 = (L U - c U) s/e,
-        // X_{i+1} = (L X_i - c X_i) 2 s'/e - s s' X_{i-1}, written over X_{i-1} in place (it is read at (row, column) itself only)
+        // X_{i+1} = (L X_i - c X_i) 2 s'/e - s s' X_{i-1}, written over X_{i-1} in place (it is read at (row, column) itself only).
+        // The recurrence runs on X^ = D^-1/2 X: D^-1/2 L D^1/2 = I - D^-1 W, whose mat-vec gathers ONE value per neighbour - from the
+        // LDS, where the gathered block is staged once per step (sp_filter_step).
         const double a = fmin(fmax(sh.th[SP_B - 1], 1e-8), 1.9), ub = 2.0;
         const double e = 0.5 * (ub - a), c0 = 0.5 * (ub + a);
         double sig = e / (0.0 - c0);
         const double tau = 2.0 / sig;
         __syncthreads();  // everyone has read sh.res / sh.th
-        X = U;
-        Y = V;
+        double* X = U;
+        double* Y = V;
         {
             const double f = sig / e;
-            for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) Y[t] = (Y[t] - c0 * X[t]) * f;
+            for (int t = tid; t < n * SP_B; t += SP_THREADS) {
+                const double w = g.isd[t / SP_B], x = X[t] * w;
+                X[t] = x;
+                Y[t] = (Y[t] * w - c0 * x) * f;
+            }
         }
         __syncthreads();
         for (int it = 2; it <= degree; ++it) {
             const double sn = 1.0 / (tau - sig);
             const double f1 = 2.0 * sn / e, f2 = sig * sn;
-            for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
-                const int i = (int)(t / SP_B), j = (int)(t % SP_B);
-                const double y = Y[t];
-                const double ly = y - 0.5 * g.isd[i] * sp_gather(g, Y, i, j);
-                X[t] = (ly - c0 * y) * f1 - f2 * X[t];
-            }
+            sp_filter_step<CG>(g, Y, X, ylds, c0, f1, f2, it == degree);
             ++matvecs;
-            __syncthreads();
             double* sw = X;
             X = Y;
             Y = sw;
             sig = sn;
         }
-        // Y holds the filtered block, X is free
-        chol_qr_pass(Y, n, 1e-11, sh, &guard);
-        chol_qr_pass(Y, n, 0.0, sh, &guard);
-        chol_qr_pass(Y, n, 0.0, sh, &guard);
-        for (int64_t t = tid; t < (int64_t)n * SP_B; t += SP_THREADS) {
-            const int i = (int)(t / SP_B), j = (int)(t % SP_B);
-            X[t] = Y[t] - 0.5 * g.isd[i] * sp_gather(g, Y, i, j);
-        }
-        ++matvecs;
-        __syncthreads();
-        rayleigh_ritz(Y, X, n, sh);
-        U = Y;
+        U = Y;  // the filtered block
         V = X;
     }
     // results: eigenvalues ascending, embedding rows v_i / sqrt(d_i), first kw columns
     double* emb = emb_all + (int64_t)img * n * kw;
-    for (int64_t t = tid; t < (int64_t)n * kw; t += SP_THREADS) {
-        const int i = (int)(t / kw), j = (int)(t % kw);
+    for (int t = tid; t < n * kw; t += SP_THREADS) {
+        const int i = t / kw, j = t % kw;
         emb[t] = U[(int64_t)i * SP_B + j] * g.isd[i];
     }
     if (tid < kw) {
@@ -666,7 +727,7 @@ static SpLayout sp_layout(int B, int n, int m, int kw) {
     l.idx = o;    o += al256((size_t)B * n * m * 4);
     l.bits = o;   o += al256((size_t)B * n * nw * 8);
     l.inptr = o;  o += al256((size_t)B * (n + 1) * 4);
-    l.incol = o;  o += al256((size_t)B * n * m * 4);
+    l.incol = o;  o += al256((size_t)B * 2 * n * m * 4);
     l.isd = o;    o += al256((size_t)B * n * 8);
     l.blocks = o; o += al256((size_t)B * 2 * n * SP_B * 8);
     l.emb = o;    o += al256((size_t)B * n * kw * 8);
@@ -736,9 +797,24 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
                        (int*)(ws + l.inptr), (int*)(ws + l.incol), (double*)(ws + l.isd));
     const int degree = a->degree > 1 ? a->degree : 24, max_outer = a->max_outer > 0 ? a->max_outer : 60;
     const double tol = a->tol > 0.0 ? a->tol : 1e-9;
-    hipLaunchKernelGGL(sm::spectral_embed_kernel, dim3(B), dim3(sm::SP_THREADS), 0, st, idx, (const int*)(ws + l.inptr),
-                       (const int*)(ws + l.incol), (const double*)(ws + l.isd), n, m, kw, degree, max_outer, tol, (double*)(ws + l.blocks),
-                       a->eigenvalues, emb, a->residuals, a->info);
+    {
+        // columns staged per filter pass: as many as fit 144 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950)
+        const int cg = (size_t)n * 8 * 8 <= 147456 ? 8 : (size_t)n * 4 * 8 <= 147456 ? 4 : 2;
+        const size_t lds = (size_t)n * cg * 8;
+        auto launch = [&](auto kern) {
+            static bool once = false;  // per instantiation (the lambda is instantiated per kernel type)
+            if (!once) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+                once = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(B), dim3(sm::SP_THREADS), lds, st, (const int*)(ws + l.inptr), (const int*)(ws + l.incol),
+                               (const double*)(ws + l.isd), n, m, kw, degree, max_outer, tol, (double*)(ws + l.blocks), a->eigenvalues, emb,
+                               a->residuals, a->info);
+        };
+        if (cg == 8) launch(&sm::spectral_embed_kernel<8>);
+        else if (cg == 4) launch(&sm::spectral_embed_kernel<4>);
+        else launch(&sm::spectral_embed_kernel<2>);
+    }
     hipLaunchKernelGGL(sm::kmeans_embed_kernel, dim3(a->n_sizes, B), dim3(sm::SP_THREADS), 0, st, emb, n, kw, sizes, a->n_sizes,
                        a->kmeans_max_iter > 0 ? a->kmeans_max_iter : 100, a->labels);
     return sm::check_launch("sm_spectral_cluster_f32");

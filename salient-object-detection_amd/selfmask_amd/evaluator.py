@@ -23,6 +23,13 @@ from .streams import DEFAULT_STREAMS, StreamRing
 from .distributed import HEADER, KEYS, SingleComm, TorchDistComm, average_rows, gather_rows, shard_indices
 
 
+# constants of evaluator.pyc@L164-309 (read from the bytecode as data: tests/golden/evaluator_constants.json pins them)
+REFERENCE_UPSAMPLE = {"scale_factor": 4, "mode": "bilinear", "align_corners": False}  # @L209-211: patch 8 // scale_factor 2
+MASK_THRESHOLD = 0.5          # @L216: pred_masks > 0.5 before the upper-bound search
+DATALOADER_WORKERS = 4        # @L174 (the product decodes on its own worker pool)
+VISUALISE_EVERY = 250         # @L230: batches between visualiser dumps (the visualiser is out of scope)
+
+
 class Evaluator(BaseStructure):
     def __init__(self, network: callable, arch: str = "vit_small", dir_dataset: str = "datasets",
                  visualizer: Optional[callable] = None, debug: bool = False):

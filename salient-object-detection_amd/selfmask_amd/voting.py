@@ -17,6 +17,14 @@ import torch
 
 from . import _native as N
 
+# MaskGenerator.__init__ defaults and CLI choices (mask_generator.pyc@L21-38,255-294), pinned by tests/golden/evaluator_constants.json
+CLUSTER_TYPES = ("k-means", "spectral")
+DEFAULT_CLUSTER_SIZES = (2, 3, 4)
+DEFAULT_CLUSTER_TYPE = "spectral"
+FEATURE_UPSAMPLE = {"scale_factor": 2, "mode": "bilinear", "align_corners": True}  # mask_generator.pyc@L159
+MASK_UPSAMPLE_MODE = "nearest"                                                       # mask_generator.pyc@L161
+DINO_TOTAL_STRIDE = 16                                                               # mask_generator.pyc@L150-157 (ResNets: 8)
+
 
 def vote_mask(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False):
     """batch_pred_masks (M, H, W) 0/1 on a HIP device -> (best mask (H, W), best index among the SURVIVORS,
@@ -137,10 +145,11 @@ def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clu
     zero-padded to a patch multiple) -> bilinear x2 (align_corners=True) -> ``clusterer(features (B, n, 384), k)`` -> labels ->
     one-hot -> nearest up-sample by patch // 2 -> crop to (H, W).  Returns (sum(cluster_sizes), H, W) uint8 for B = 1 - the
     candidates ``vote_mask`` takes - and (B, sum(cluster_sizes), H, W) otherwise.  ``cluster_type``: "spectral" (default, as the
-    shipped YAML: ``spectral_cluster``) or "kmeans" (``mask_generator.pyc@L30-38``); ``clusterer`` overrides both with a
+    shipped YAML and ``MaskGenerator.__init__``: ``spectral_cluster``) or "k-means" (the reference's spelling, ``mask_generator.pyc@L30-38``;
+    "kmeans" is accepted too); ``clusterer`` overrides both with a
     callable ``(features, k) -> labels (B, n)``.  Both built-in clusterers are parity UNPINNED (module header)."""
     assert x.dim() == 4
-    assert cluster_type in ("spectral", "kmeans"), cluster_type
+    assert cluster_type in CLUSTER_TYPES + ("kmeans",), cluster_type  # "kmeans": alias of the reference's "k-means"
     B, _, H, W = x.shape
     p = model.encoder.patch_size
     tok = model(x, encoder_only=True)["patch_tokens"]  # (B, gh, gw, 384), final-normed, cls dropped
@@ -149,7 +158,7 @@ def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clu
     flat = feats.reshape(B, 4 * gh * gw, N.EMBED)
     if clusterer is not None:
         per_k = [clusterer(flat, k).reshape(B, 2 * gh, 2 * gw) for k in cluster_sizes]
-    elif cluster_type == "spectral":
+    elif cluster_type == "spectral":  # mask_generator.pyc@L30-38: "k-means" -> KMeansClustering, anything else -> SpectralClustering
         lab = spectral_cluster(flat, cluster_sizes, n_neighbors)
         per_k = [lab[:, i].reshape(B, 2 * gh, 2 * gw) for i in range(len(cluster_sizes))]
     else:
