@@ -264,14 +264,29 @@ __device__ __forceinline__ void gelu4(float (&t)[4]) {
 }
 
 // LDS image of a 128-B stage row (four 8-k groups x [hi | lo]) for the fragment reads of v_mfma_f32_16x16x32_f16 (lane =
-// (row & 15, k-group)): 16-B slot of (k-group kg, x = 0 hi / 1 lo) in its row - see gemm_w16.hip
+// (row & 15, k-group)): chunk c = 2 kg + x (x = 0 hi / 1 lo) of a row lives in the 16-B slot c ^ swz(row), swz(row) = (row & 7) ^
+// ((row >> 3) & 1).  Found by exhaustive search over the XOR swizzles that are linear in the row bits (round 4,
+// profiles/r04_lds_slot_search.txt), for BOTH users of the image:
+//   * the ds_read_b128 fragment reads - the hardware serves them in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, ...;
+//     MI355X_MICROARCH.md, LDS), and the 16 lanes of every group must hit 16 different slots of the 256-B bank row: conflict-free
+//     for rows of 128 B (GEMM stages), of 256 B with the half select by row parity (K of the fused kernel) and of 896 B (V^T);
+//   * the ds_write_b128 stores of the fused kernel's K / V^T conversion - eight CONTIGUOUS lanes = eight consecutive rows of one
+//     (kg, x), bank row 128 B for stores: the eight slots must differ.  The round-2/3 image (a rotation by row bit 3, an XOR by row
+//     bit 1) served the reads but put those eight lanes on TWO slots - a 4-way conflict on every K / V^T store, the
+//     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.17 of profiles/r03_pmc_sq_counters.txt.
+#ifdef SM_M16_SLOT_R3  // the previous image, for A/B builds only (build.py --variant=slot_r3 -DSM_M16_SLOT_R3)
 __device__ __forceinline__ int m16_slot(int row, int kg, int x) { return 2 * ((kg + 2 * ((row >> 3) & 1)) & 3) + (x ^ ((row >> 1) & 1)); }
-// inverse, for the LDS-DMA source address: the chunk (2 kg + x) that lives in slot p of `row`
 __device__ __forceinline__ int m16_chunk_of_slot(int row, int p) { return 2 * (((p >> 1) + 2 * ((row >> 3) & 1)) & 3) + ((p & 1) ^ ((row >> 1) & 1)); }
+#else
+__device__ __forceinline__ int m16_swz(int row) { return (row & 7) ^ ((row >> 3) & 1); }
+__device__ __forceinline__ int m16_slot(int row, int kg, int x) { return (2 * kg + x) ^ m16_swz(row); }
+// inverse, for the LDS-DMA source address: the chunk (2 kg + x) that lives in slot p of `row` (an XOR is its own inverse)
+__device__ __forceinline__ int m16_chunk_of_slot(int row, int p) { return p ^ m16_swz(row); }
+#endif
 
 // row of a 32x32 MFMA accumulator held in register v by lane-half h  (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
 }  // namespace sm
 
-const char* sm_qkv_attention_kernel_name();  // qkv_attention.hip: rocprofv3 name of the selected fused kernel
+const char* sm_qkv_attention_kernel_name(int mfma_terms);  // qkv_attention.hip: rocprofv3 name of the fused kernel that is launched

@@ -319,7 +319,7 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
             q.B = s.B; q.N = s.N; q.w_scale = qkv_s; q.scale = 0.125f; q.out_f16x2 = 1; q.mfma_terms = c.terms;
             q.ln_stats = fq.stats; q.ln_c = fq.cvec; q.ln_eps = fq.eps;
             // algorithmic work of SURVEY.md 8d: 2 N 384 1152 + 4 N^2 384 FLOPs, x in + o out bytes per image
-            TapScope tap(c.st, sm_qkv_attention_kernel_name(), (double)s.B * (2.0 * s.N * D * 3 * D + 4.0 * s.N * s.N * D),
+            TapScope tap(c.st, sm_qkv_attention_kernel_name(c.terms), (double)s.B * (2.0 * s.N * D * 3 * D + 4.0 * s.N * s.N * D),
                          2.0 * s.M * D * 4);
             TRY(sm_qkv_attention_w16(&q, c.st));
         } else {

@@ -548,7 +548,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
     float* C = g.C + (split > 1 ? (int64_t)blockIdx.z : 0) * g.strideC;
     const bool out_split = g.patch_n < 0;
     const float ws = g.w_scale;
-    constexpr int EPLD = WTN * 4 + 16;
+    // Epilogue staging (the idle ring): 32 rows of this wave's WTN columns.  For 32-column slices (the 256 x 256 and 256 x 128
+    // shapes) rows are 128 B with the 16-B piece c of row r at slot c ^ (r & 7) and, for F16X2 output, the two 8-B halves of a piece
+    // swapped on rows with bit 3 set: the 8-lane groups of a float4 store, the 16-lane groups of an 8-B store and the four 16-lane
+    // groups of the read-back each cover a bank row once.  (Rounds 2-3 padded rows to 144 B: lanes r and r + 8 of every 8-B store met on
+    // one bank pair and two lanes of every read-back group shared a slot - the 0.14 conflict ratio of profiles/r03_pmc_sq_counters.txt
+    // was this epilogue, not the K loop.)  Other slice widths keep the padded rows.
+    constexpr bool SWZ = WTN == 32;
+    constexpr int EPLD = SWZ ? 128 : WTN * 4 + 16;
     constexpr int PIECES = WTN / 4;
     static_assert(NW * 32 * EPLD <= RING_BYTES, "epilogue staging must fit in the ring");
     __builtin_amdgcn_s_barrier();
@@ -641,11 +648,19 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
                     if constexpr (F) {  // F16X2: elements nl..nl+3 of group nl / 8: hi at 32 G + 8 (kg & 1), lo 16 B further
                         f16x4 hi, lo;
                         split4(t, hi, lo);
-                        char* p = ep + row * EPLD + (nl >> 3) * 32 + (kg & 1) * 8;
-                        *reinterpret_cast<f16x4*>(p) = hi;
-                        *reinterpret_cast<f16x4*>(p + 16) = lo;
+                        if constexpr (SWZ) {
+                            const int pc = 2 * (nl >> 3), half = ((kg & 1) ^ ((row >> 3) & 1)) * 8;
+                            char* p = ep + row * EPLD + half;
+                            *reinterpret_cast<f16x4*>(p + ((pc ^ (row & 7)) * 16)) = hi;
+                            *reinterpret_cast<f16x4*>(p + (((pc + 1) ^ (row & 7)) * 16)) = lo;
+                        } else {
+                            char* p = ep + row * EPLD + (nl >> 3) * 32 + (kg & 1) * 8;
+                            *reinterpret_cast<f16x4*>(p) = hi;
+                            *reinterpret_cast<f16x4*>(p + 16) = lo;
+                        }
                     } else {
-                        *reinterpret_cast<float4*>(ep + row * EPLD + nl * 4) = make_float4(t[0], t[1], t[2], t[3]);
+                        const int pc = SWZ ? ((nl >> 2) ^ (row & 7)) : (nl >> 2);
+                        *reinterpret_cast<float4*>(ep + row * EPLD + pc * 16) = make_float4(t[0], t[1], t[2], t[3]);
                     }
                 }
             }
@@ -685,7 +700,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
             };
             auto staged = [&](int it) {
                 const int idx = it * 64 + lane, row = idx / PIECES, pc = idx % PIECES;
-                float4 val = *reinterpret_cast<const float4*>(ep + row * EPLD + pc * 16);
+                float4 val = *reinterpret_cast<const float4*>(ep + row * EPLD + (SWZ ? (pc ^ (row & 7)) : pc) * 16);
+                if constexpr (SWZ && F) {  // rows with bit 3 set hold the halves of a piece swapped
+                    if (row & 8) val = make_float4(val.z, val.w, val.x, val.y);
+                }
                 if constexpr (HASR) { val.x = res[it].x + val.x; val.y = res[it].y + val.y; val.z = res[it].z + val.z; val.w = res[it].w + val.w; }
                 return val;
             };

@@ -770,7 +770,8 @@ static int qkv_mode() {
 #endif
 }
 // name rocprofv3 reports for the selected kernel (labels the in-situ taps of forward.hip)
-const char* sm_qkv_attention_kernel_name() {
+const char* sm_qkv_attention_kernel_name(int mfma_terms) {
+    if (mfma_terms == 1) return "qkv_attention_m16_kernel<2, 1, 4>";  // the one-MFMA diagnostic launches this instantiation whatever the mode
     static const char* names[] = {"qkv_attention_kernel<32, 2>", "qkv_attention_kernel<32, 3>", "qkv_attention_kernel<16, 2>",
                                   "qkv_attention_kernel<16, 6>", "qkv_attention_m16_kernel<2>", "qkv_attention_m16_kernel<3>",
                                   "qkv_attention_m16_kernel<2, 3, 4>", "qkv_attention_m16_kernel<3, 3, 4>"};

@@ -6,8 +6,13 @@ segments (files under /dev/shm), one per batch in flight; sample i of a batch ow
 no coordination to write its pixels.  ``decode_batch(slot, paths)`` returns zero-copy numpy views of the decoded images and
 ground truths inside the slot - exactly what ``pipeline.pack_images`` / ``pack_gts`` take - valid until the slot is reused.
 
-A sample larger than its window (``max_side``) is decoded in-process instead (rare; same function, same bytes).
+A sample larger than its window (``max_side``) is decoded in-process instead (same function, same bytes - but on the GIL-holding
+consumer thread and after the worker has decoded it once for nothing: a warning says so once; size ``max_side`` for the dataset).
+Requests and replies are JSON lines, so a path may hold tabs or newlines.  When a ring of slots is closed its files are unlinked
+and the workers are told to unmap them (``DecodePool.drop``): a worker keeps no mapping of a finished loader.
 """
+import importlib.util
+import json
 import os
 import queue
 import subprocess
@@ -20,6 +25,24 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 _WORKER = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sm_decode_worker.py"))
+
+
+def _worker_module():
+    """sm_decode_worker.py loaded from ITS path (not through sys.path: the file sits beside the package under a generic name)."""
+    mod = sys.modules.get("sm_decode_worker")
+    if mod is None or os.path.normpath(getattr(mod, "__file__", "")) != _WORKER:
+        spec = importlib.util.spec_from_file_location("sm_decode_worker", _WORKER)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        sys.modules["sm_decode_worker"] = mod
+    return mod
+
+
+def decode_item(p_img, p_gt=None):
+    return _worker_module().decode_item(p_img, p_gt)
+
+
+_WARNED_BIG = False
 
 
 def _cgroup_cpus() -> Optional[float]:
@@ -75,13 +98,17 @@ class BatchSlots:
                 self.maps.append(mmap.mmap(f.fileno(), 0))
             self.files.append(path)
 
-    def close(self) -> None:
-        for p in self.files:
+    def close(self, pool: Optional["DecodePool"] = None) -> None:
+        """unlink the segments (the parent's mappings of views still alive stay valid; the memory goes when they do) and, given the
+        pool that wrote into them, have every worker drop its mapping too"""
+        files, self.files = getattr(self, "files", []), []
+        for p in files:
             try:
-                os.unlink(p)  # the mappings of views still alive stay valid; the memory goes when they do
+                os.unlink(p)
             except OSError:
                 pass
-        self.files = []
+        if pool is not None and files:
+            pool.drop(files)
 
     def __del__(self):
         self.close()
@@ -91,19 +118,21 @@ class DecodePool:
     def __init__(self, workers: Optional[int] = None):
         self.n = workers or default_workers()
         self._q: "queue.Queue" = queue.Queue()
-        self._procs, self._threads = [], []
+        self._procs, self._threads, self._locks = [], [], []
         self._closed = False
         env = dict(os.environ)
         env["OMP_NUM_THREADS"] = "1"
         for _ in range(self.n):
             p = subprocess.Popen([sys.executable, "-u", _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
                                  bufsize=1, env=env, close_fds=True)
-            t = threading.Thread(target=self._feed, args=(p,), daemon=True)
+            lock = threading.Lock()  # one conversation at a time on a worker's pipes (its feeder thread, or drop())
+            t = threading.Thread(target=self._feed, args=(p, lock), daemon=True)
             t.start()
             self._procs.append(p)
             self._threads.append(t)
+            self._locks.append(lock)
 
-    def _feed(self, p) -> None:
+    def _feed(self, p, lock) -> None:
         """One thread per worker: blocked on the queue or on the worker's pipe, i.e. outside the GIL almost always."""
         while True:
             item = self._q.get()
@@ -111,17 +140,37 @@ class DecodePool:
                 return
             lines, fut = item  # a chunk of samples: one write, then one reply line per sample
             try:
-                p.stdin.write("".join(lines))
-                p.stdin.flush()
-                replies = []
-                for _ in lines:
-                    reply = p.stdout.readline()
-                    if not reply:
-                        raise RuntimeError("decode worker exited")
-                    replies.append(reply.rstrip("\n").split("\t"))
+                with lock:
+                    p.stdin.write("".join(lines))
+                    p.stdin.flush()
+                    replies = []
+                    for _ in lines:
+                        reply = p.stdout.readline()
+                        if not reply:
+                            raise RuntimeError("decode worker exited")
+                        replies.append(json.loads(reply))
                 fut.set_result(replies)
             except Exception as e:  # noqa: BLE001
                 fut.set_exception(e)
+
+    def drop(self, files: Sequence[str]) -> int:
+        """Tell every worker that these shared segments are gone; returns the number of mappings released.  Best effort: a worker
+        that has died is skipped (shared_pool replaces the pool on its next use)."""
+        released = 0
+        if self._closed:
+            return 0
+        msg = json.dumps(["drop"] + list(files)) + "\n"
+        for p, lock in zip(self._procs, self._locks):
+            try:
+                with lock:
+                    p.stdin.write(msg)
+                    p.stdin.flush()
+                    reply = p.stdout.readline()
+                if reply:
+                    released += int(json.loads(reply)[1])
+            except (OSError, ValueError, IndexError):
+                pass
+        return released
 
     def decode_batch(self, slots: BatchSlots, slot: int, paths: Sequence[Tuple[str, Optional[str]]]):
         """Decode ``paths`` = [(image path, GT path or None)] into windows 0.. of ``slots`` segment ``slot``.  Returns a Future-like
@@ -136,7 +185,7 @@ class DecodePool:
             for i in range(c0, min(c0 + chunk, len(paths))):
                 pi, pg = paths[i]
                 ro = i * slots.stride
-                lines.append(f"{pi}\t{pg or '-'}\t{slots.files[slot]}\t{ro}\t{slots.rgb_cap}\t{ro + slots.rgb_cap}\t{slots.gt_cap}\n")
+                lines.append(json.dumps([pi, pg, slots.files[slot], ro, slots.rgb_cap, ro + slots.rgb_cap, slots.gt_cap]) + "\n")
             f: Future = Future()
             self._q.put((lines, f))
             futs.append(f)
@@ -150,7 +199,12 @@ class DecodePool:
                     raise RuntimeError(f"decode worker: {r[1]} ({paths[i][0]})")
                 h, w, gh, gw = (int(v) for v in r[1:5])
                 if r[0] == "big":  # beyond the window: decode here (same function)
-                    from sm_decode_worker import decode_item
+                    global _WARNED_BIG
+                    if not _WARNED_BIG:
+                        import warnings
+                        _WARNED_BIG = True
+                        warnings.warn(f"decode_pool: {paths[i][0]} ({h}x{w}) does not fit its {slots.rgb_cap // 3}-pixel shared-memory window; such "
+                                      f"samples are decoded a second time on the consumer thread (BatchSlots(max_side=...) sizes the window)")
                     rgb, m = decode_item(*paths[i])
                 else:
                     ro = i * slots.stride

@@ -13,17 +13,81 @@ KEYS = ("iou", "pixel_accuarcy", "f_score", "f_max", "f_mean", "mae", "s_measure
 
 
 def rank_cores(local_rank: int, local_world: int, cores: Sequence[int]) -> List[int]:
-    """This rank's share of the node's cores: a contiguous block (neighbouring cores share caches / a NUMA node)."""
+    """This rank's share of a set of cores: a contiguous block (neighbouring cores share caches / a NUMA node)."""
     cores = sorted(cores)
     per = max(1, len(cores) // max(1, local_world))
     lo = min(local_rank * per, max(0, len(cores) - per))
     return cores[lo:lo + per]
 
 
-def pin_rank_cores() -> List[int]:
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_numa_topology(sysfs: str = "/sys") -> List[dict]:
+    """The node's GPUs in HIP device order with the host cores next to each: [{"numa_node": int, "cpus": [...]}, ...].
+    KFD lists every compute node under class/kfd/kfd/topology/nodes/<i>/properties; the ones with SIMDs are GPUs, in the order
+    the runtime enumerates them, and `drm_render_minor` names their DRM render node, whose PCI device directory holds
+    `numa_node` and `local_cpulist`.  HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (index lists) are applied.  Empty when the
+    tree is absent (no GPU, another OS): the caller then falls back to contiguous blocks."""
+    import os
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    gpus = []
+    try:
+        nodes = sorted((d for d in os.listdir(base) if d.isdigit()), key=int)
+    except OSError:
+        return []
+    for d in nodes:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(base, d, "properties")) if " " in line.strip())
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) <= 0:
+            continue  # a CPU node
+        dev = os.path.join(sysfs, "class", "drm", f"renderD{int(props.get('drm_render_minor', '-1'))}", "device")
+        try:
+            numa = int(open(os.path.join(dev, "numa_node")).read())
+            cpus = _parse_cpulist(open(os.path.join(dev, "local_cpulist")).read())
+        except (OSError, ValueError):
+            numa, cpus = -1, []
+        gpus.append({"numa_node": numa, "cpus": cpus})
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):  # ROCR filters first, HIP indexes what is left
+        sel = os.environ.get(var)
+        if sel:
+            try:
+                gpus = [gpus[int(i)] for i in sel.split(",") if i.strip() != ""]
+            except (ValueError, IndexError):
+                return []  # UUID lists or stale indices: do not guess
+    return gpus
+
+
+def numa_rank_cores(local_rank: int, local_world: int, affinity: Sequence[int], topology: Sequence[dict]) -> List[int]:
+    """Rank r drives GPU r: its decode workers belong on the cores of that GPU's NUMA node.  The ranks whose GPUs
+    hang off the same node split that node's cores (within the affinity mask) into contiguous blocks, in rank order.  Falls back to
+    the plain contiguous split when the topology is unknown, a GPU reports no node (-1), or a node has fewer usable cores than ranks."""
+    plain = rank_cores(local_rank, local_world, affinity)
+    if len(topology) < local_world or any(t["numa_node"] < 0 or not t["cpus"] for t in topology[:local_world]):
+        return plain
+    node = topology[local_rank]["numa_node"]
+    peers = [r for r in range(local_world) if topology[r]["numa_node"] == node]
+    usable = sorted(set(affinity) & set(topology[local_rank]["cpus"]))
+    if len(usable) < len(peers):
+        return plain
+    return rank_cores(peers.index(local_rank), len(peers), usable)
+
+
+def pin_rank_cores(sysfs: str = "/sys") -> List[int]:
     """One process per GPU, eight of them on one host: give each rank its own block of the host's cores (its decode workers
-    inherit it) instead of 8 x N threads fighting over all of them.  Reads LOCAL_RANK / LOCAL_WORLD_SIZE (torch.distributed.run);
-    a no-op for a single rank.  Sets SM_RANK_CORES_PINNED so that decode_pool.default_workers does not divide again."""
+    inherit it) instead of 8 x N threads fighting over all of them - the cores of the NUMA node its GPU hangs off when sysfs says
+    which (gpu_numa_topology), a contiguous block of the affinity mask otherwise.  Reads LOCAL_RANK / LOCAL_WORLD_SIZE
+    (torch.distributed.run); a no-op for a single rank.  Sets SM_RANK_CORES_PINNED so that decode_pool.default_workers does not
+    divide again."""
     import os
     lw, lr = int(os.environ.get("LOCAL_WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
     try:
@@ -32,7 +96,7 @@ def pin_rank_cores() -> List[int]:
         return []
     if lw <= 1 or os.environ.get("SM_RANK_CORES_PINNED") == "1":
         return cur
-    mine = rank_cores(lr, lw, cur)
+    mine = numa_rank_cores(lr, lw, cur, gpu_numa_topology(sysfs))
     os.sched_setaffinity(0, mine)
     os.environ["SM_RANK_CORES_PINNED"] = "1"
     return mine

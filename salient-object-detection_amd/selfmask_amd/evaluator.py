@@ -80,8 +80,7 @@ class Evaluator(BaseStructure):
         # One encoder attention path for the whole run (maskformer.attention_path): ragged last batches, token-grid buckets of
         # any size and shards of any world size then give the same bits per image as every other way of batching them
         prev_path = getattr(self.model, "attention_path", None)
-        if prev_path == "auto":
-            self.model.attention_path = "fused" if (img_size is not None and batch_size >= 16) else "unfused"
+        pin_path = ("fused" if (img_size is not None and batch_size >= 16) else "unfused") if prev_path == "auto" else None
         rows_local = torch.empty((len(mine), 16), dtype=torch.float32, device=device)
         rows_refined = torch.empty((len(mine), 16), dtype=torch.float32, device=device) if refine else None
         ring = StreamRing(device, streams)  # consecutive batches in flight on different HIP streams (streams.py)
@@ -134,6 +133,8 @@ class Evaluator(BaseStructure):
 
         bucket_pos, bucket_rows = [], []
         try:
+            if pin_path is not None:  # inside the try: whatever fails below, the shared model gets its "auto" back
+                self.model.attention_path = pin_path
             for s, x, gts in batches():
                 with ring.next():
                     u8 = None

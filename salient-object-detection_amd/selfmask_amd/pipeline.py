@@ -269,12 +269,15 @@ def preprocess_on_device(images, S: Optional[int], device, pinned: bool = False,
     return views
 
 
-from sm_decode_worker import decode_item  # noqa: E402  (numpy + Pillow only: also what the decode worker processes run)
+from .decode_pool import decode_item  # noqa: E402  (sm_decode_worker.decode_item, loaded from the file's own path)
 
 
 class PrefetchingLoader:
-    """Batches of a SaliencyTestDataset decoded by ``workers`` host threads, ``depth`` batches ahead of the consumer.
-    Iterating yields (list of rgb uint8 arrays, list of GT uint8 arrays, list of dataset indices)."""
+    """Batches of a SaliencyTestDataset decoded by ``workers`` host processes (or threads), ``depth`` batches ahead of the consumer.
+    Iterating yields (list of rgb uint8 arrays, list of GT uint8 arrays, list of dataset indices).  Lifetime: without ``pack`` the
+    arrays are the caller's own (copied out of the shared-memory slots: ``list(loader)`` is safe); with ``pack=True`` the yielded
+    page-locked staging buffers belong to the pipeline and are recycled once the copy they feed has run - consume a batch before
+    asking for the one ``depth`` further on.  If /dev/shm cannot hold the slots the loader falls back to the thread decoder."""
 
     def __init__(self, dataset, indices: Sequence[int], batch_size: int, workers: Optional[int] = None, depth: int = 3,
                  pack: bool = False, pack_size: Optional[int] = None, batches: Optional[Sequence[Sequence[int]]] = None,
@@ -305,15 +308,21 @@ class PrefetchingLoader:
         batches = self.batches if self.batches is not None else [self.idx[s:s + self.bs] for s in range(0, len(self.idx), self.bs)]
         if not batches:
             return
+        slots = None
         if self.decode == "process":
             from .decode_pool import BatchSlots, shared_pool
-            dpool, slots = shared_pool(self.workers), BatchSlots(self.depth + 1, max(len(b) for b in batches))
+            try:
+                dpool, slots = shared_pool(self.workers), BatchSlots(self.depth + 1, max(len(b) for b in batches))
+            except OSError as e:  # no /dev/shm, or not enough of it: the thread decoder needs none
+                import warnings
+                warnings.warn(f"PrefetchingLoader: shared-memory slots unavailable ({e}); decoding on threads instead")
+        if slots is not None:
             try:
                 def submit(k):  # -> callable returning (rgb views, GT views) inside shared slot k % (depth + 1)
                     return dpool.decode_batch(slots, k % (self.depth + 1), [(self.ds.p_imgs[i], self.ds.p_gts[i]) for i in batches[k]])
                 yield from self._run(batches, submit)
             finally:
-                slots.close()  # (the worker processes stay: shared_pool keeps them for the next loader)
+                slots.close(dpool)  # files unlinked, the workers unmap them (the processes stay for the next loader)
             return
         with ThreadPoolExecutor(max_workers=self.workers) as pool:
             def submit(k):
@@ -335,7 +344,8 @@ class PrefetchingLoader:
                 if k + self.depth < len(batches):
                     inflight.append(submit(k + self.depth))
                 rgbs, gts = wait()
-                yield rgbs, gts, batches[k]
+                # the caller's own arrays: the views of a shared-memory slot are overwritten depth + 1 batches later
+                yield [np.array(r) for r in rgbs], [None if g is None else np.array(g) for g in gts], batches[k]
             return
 
         def assemble(wait):  # runs on the packing thread: waits for the batch's decodes, copies into pinned staging

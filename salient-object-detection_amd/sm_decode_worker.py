@@ -10,14 +10,19 @@ Why processes: Pillow releases the GIL only inside libjpeg / zlib; everything ar
 Threads therefore top out near 1 / (GIL-held time): measured 595 images/s on ONE thread, 414 on four and 482 on eight threads
 of the same 8-core host; 16 threads of a GPU box reach 1.6-2.0k images/s where 16 cores could decode 9k.
 
-Worker protocol (one request per line on stdin, one reply per line on stdout, tab separated):
-    request   <image path> <GT path or -> <shm file> <rgb offset> <rgb capacity> <gt offset> <gt capacity>
-    reply     ok <H> <W> <gtH> <gtW>      pixels written to the shared segment: (H, W, 3) uint8 at rgb offset, (gtH, gtW) uint8
+Worker protocol: one JSON array per line on stdin, one per line on stdout (paths may hold any character):
+    request   [image path, GT path or null, shm file, rgb offset, rgb capacity, gt offset, gt capacity]
+    reply     ["ok", H, W, gtH, gtW]      pixels written to the shared segment: (H, W, 3) uint8 at rgb offset, (gtH, gtW) uint8
                                            {0, 1} at gt offset (gtH = gtW = 0 without a GT)
-              big <H> <W> <gtH> <gtW>     a capacity is too small: nothing written, the parent decodes this sample itself
-              err <message>
+              ["big", H, W, gtH, gtW]     a capacity is too small: nothing written, the parent decodes this sample itself
+              ["err", message]
+    request   ["drop", shm file, ...]     the segments are gone (their loader finished): unmap them;  reply ["dropped", count]
+A worker also unmaps every segment whose file has disappeared whenever it meets a new one, so an unlinked ring of slots never
+outlives the next loader even without the message.
 """
+import json
 import mmap
+import os
 import sys
 
 import numpy as np
@@ -36,29 +41,50 @@ def decode_item(p_img: str, p_gt=None):
     return rgb, m
 
 
+def _unmap(maps: dict, path: str) -> bool:
+    mm = maps.pop(path, None)
+    if mm is None:
+        return False
+    try:
+        mm.close()
+    except BufferError:  # a numpy view still alive (cannot happen between requests); the mapping goes with it
+        pass
+    return True
+
+
 def _serve() -> None:
     maps = {}
     out = sys.stdout
     for line in sys.stdin:
         try:
-            p_img, p_gt, shm, ro, rc, go, gc = line.rstrip("\n").split("\t")
-            ro, rc, go, gc = int(ro), int(rc), int(go), int(gc)
-            rgb, m = decode_item(p_img, None if p_gt == "-" else p_gt)
-            h, w = rgb.shape[:2]
-            gh, gw = (m.shape if m is not None else (0, 0))
-            if rgb.size > rc or (m is not None and m.size > gc):
-                out.write(f"big\t{h}\t{w}\t{gh}\t{gw}\n")
+            req = json.loads(line)
+            if req and req[0] == "drop" and not (len(req) == 7 and isinstance(req[3], int)):
+                reply = ["dropped", sum(_unmap(maps, f) for f in req[1:])]
             else:
-                mm = maps.get(shm)
-                if mm is None:
-                    with open(shm, "r+b") as f:  # the segment's file under /dev/shm (no resource tracker involved)
-                        mm = maps[shm] = mmap.mmap(f.fileno(), 0)
-                np.frombuffer(mm, np.uint8, rgb.size, ro)[:] = rgb.reshape(-1)
-                if m is not None:
-                    np.frombuffer(mm, np.uint8, m.size, go)[:] = m.reshape(-1)
-                out.write(f"ok\t{h}\t{w}\t{gh}\t{gw}\n")
+                p_img, p_gt, shm, ro, rc, go, gc = req
+                rgb, m = decode_item(p_img, p_gt)
+                h, w = rgb.shape[:2]
+                gh, gw = (m.shape if m is not None else (0, 0))
+                if rgb.size > rc or (m is not None and m.size > gc):
+                    reply = ["big", h, w, gh, gw]
+                else:
+                    mm = maps.get(shm)
+                    if mm is None:
+                        for stale in [f for f in maps if not os.path.exists(f)]:
+                            _unmap(maps, stale)
+                        with open(shm, "r+b") as f:  # the segment's file under /dev/shm (no resource tracker involved)
+                            mm = maps[shm] = mmap.mmap(f.fileno(), 0)
+                    dst = np.frombuffer(mm, np.uint8, rgb.size, ro)
+                    dst[:] = rgb.reshape(-1)
+                    del dst
+                    if m is not None:
+                        dst = np.frombuffer(mm, np.uint8, m.size, go)
+                        dst[:] = m.reshape(-1)
+                        del dst
+                    reply = ["ok", h, w, gh, gw]
         except Exception as e:  # noqa: BLE001 - reported to the parent, which raises
-            out.write("err\t" + repr(e).replace("\n", " ").replace("\t", " ") + "\n")
+            reply = ["err", repr(e)]
+        out.write(json.dumps(reply) + "\n")
         out.flush()
 
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the shipped kernels, alone (guide's recipe: counters in their own passes, no tracing domains): wave cycles,
-# waits, MFMA-busy cycles, LDS conflicts, clock.  Three kernels x three counter sets -> gpurun_out/r03_pmc_sq_counters.txt
+# waits, MFMA-busy cycles, LDS conflicts, clock.  Three kernels x three counter sets -> gpurun_out/${TAG:-r04}_pmc_sq_counters.txt
 #   fc1  = gemm_w16m16<256,256>, M 12608, N 1536, K 384, GELU + F16X2 out   (variant 40)
 #   proj = gemm_w16m16<256,128,3,4,4,4>, N 384, K 384, residual             (variant 47)
 #   fused QKV + attention (B 64, N 197)
@@ -17,7 +17,7 @@ for S in "${SETS[@]}"; do
   rocprofv3 --pmc $S --output-format csv -d gpurun_out/sq_proj_$i -- python3 scripts/one_gemm_w16.py 12608 384 384 47 residual 0 > gpurun_out/sq_proj_$i.log 2>&1
   rocprofv3 --pmc $S --output-format csv -d gpurun_out/sq_qkv_$i -- python3 scripts/qkv_attn_bench.py > gpurun_out/sq_qkv_$i.log 2>&1
 done
-python3 - <<'PY' > gpurun_out/r03_pmc_sq_counters.txt
+python3 - <<'PY' > gpurun_out/${TAG:-r04}_pmc_sq_counters.txt
 import csv, glob, collections
 want = {"fc1": "gemm_w16m16_kernel<256, 256", "proj": "gemm_w16m16_kernel<256, 128", "qkv": "qkv_attention_m16_kernel"}
 print("SQ counters per launch (average over the launches of one process; rocprofv3 --pmc, one counter set per pass;")
@@ -56,4 +56,4 @@ for tag, frag in want.items():
         print(f"   {'VALU instructions (MFMA included) per MFMA':48s} {vals['SQ_INSTS_VALU'] / mf:6.2f}")
     print()
 PY
-cat gpurun_out/r03_pmc_sq_counters.txt
+cat gpurun_out/${TAG:-r04}_pmc_sq_counters.txt

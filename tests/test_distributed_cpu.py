@@ -96,3 +96,76 @@ def test_rank_cores_partition_the_host():
     assert all(len(b) == 16 for b in blocks) and sorted(sum(blocks, [])) == cores   # disjoint, complete, contiguous
     assert all(b == list(range(b[0], b[0] + 16)) for b in blocks)
     assert rank_cores(0, 1, cores) == cores and len(rank_cores(5, 8, list(range(6)))) == 1   # fewer cores than ranks: one each
+
+
+def _fake_sysfs(root, gpus, cpu_nodes=2):
+    """a sysfs tree as KFD / DRM lay it out: `cpu_nodes` CPU nodes first, then one node per GPU = (numa_node, local_cpulist)"""
+    import os
+    nodes = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    for i in range(cpu_nodes):
+        os.makedirs(os.path.join(nodes, str(i)))
+        open(os.path.join(nodes, str(i), "properties"), "w").write("cpu_cores_count 48\nsimd_count 0\ndrm_render_minor 0\n")
+    for g, (numa, cpulist) in enumerate(gpus):
+        d = os.path.join(nodes, str(cpu_nodes + g))
+        os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {128 + g}\n")
+        dev = os.path.join(root, "class", "drm", f"renderD{128 + g}", "device")
+        os.makedirs(dev)
+        open(os.path.join(dev, "numa_node"), "w").write(f"{numa}\n")
+        open(os.path.join(dev, "local_cpulist"), "w").write(cpulist + "\n")
+
+
+def test_rank_cores_follow_the_numa_node_of_the_ranks_gpu(tmp_path, monkeypatch):
+    """'each rank needs its own decode workers pinned to its NUMA node' (VERDICT r3 #12).  A two-socket host, GPUs
+    0-3 on node 0 (cores 0-47, 96-143), GPUs 4-7 on node 1 (cores 48-95, 144-191)."""
+    from selfmask_amd.distributed import gpu_numa_topology, numa_rank_cores, rank_cores
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    root = str(tmp_path / "sys")
+    _fake_sysfs(root, [(0, "0-47,96-143")] * 4 + [(1, "48-95,144-191")] * 4)
+    topo = gpu_numa_topology(root)
+    assert [t["numa_node"] for t in topo] == [0, 0, 0, 0, 1, 1, 1, 1] and topo[5]["cpus"][:2] == [48, 49] and len(topo[0]["cpus"]) == 96
+    affinity = list(range(192))
+    blocks = [numa_rank_cores(r, 8, affinity, topo) for r in range(8)]
+    assert sorted(c for b in blocks for c in b) == affinity  # a partition of the host
+    for r, b in enumerate(blocks):
+        assert set(b) <= set(topo[r]["cpus"]) and len(b) == 24  # every rank on its GPU's node
+    # a container that may only use cores 0-63: node 0 keeps 48 of them for its four ranks, node 1 the other 16
+    blocks = [numa_rank_cores(r, 8, list(range(64)), topo) for r in range(8)]
+    assert [len(b) for b in blocks] == [12] * 4 + [4] * 4 and set(blocks[6]) <= set(range(48, 64))
+    # visible-device lists re-index the GPUs
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "6,1")
+    assert [t["numa_node"] for t in gpu_numa_topology(root)] == [1, 0]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # unknown topology, a GPU without a node, or fewer usable cores than ranks: the plain contiguous split
+    assert numa_rank_cores(3, 8, affinity, []) == rank_cores(3, 8, affinity)
+    assert gpu_numa_topology(str(tmp_path / "nothing")) == []
+    bad = [dict(t) for t in topo]
+    bad[2]["numa_node"] = -1
+    assert numa_rank_cores(2, 8, affinity, bad) == rank_cores(2, 8, affinity)
+    assert numa_rank_cores(7, 8, list(range(3)), topo) == rank_cores(7, 8, list(range(3)))
+
+
+def test_pin_rank_cores_uses_the_topology(tmp_path, monkeypatch):
+    import os
+    from selfmask_amd import distributed as D
+    if not hasattr(os, "sched_getaffinity"):
+        pytest.skip("no CPU affinity on this platform")
+    cur = sorted(os.sched_getaffinity(0))
+    if len(cur) < 4:
+        pytest.skip("needs four cores")
+    half = len(cur) // 2
+    lo, hi = cur[:half], cur[half:]
+    root = str(tmp_path / "sys")
+    as_list = lambda cs: ",".join(str(c) for c in cs)
+    _fake_sysfs(root, [(0, as_list(hi)), (1, as_list(lo))])  # GPU 0 next to the UPPER half: a contiguous split would get this wrong
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "2")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("SM_RANK_CORES_PINNED", raising=False)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    try:
+        assert D.pin_rank_cores(root) == hi and sorted(os.sched_getaffinity(0)) == hi
+    finally:
+        os.sched_setaffinity(0, cur)
+        os.environ.pop("SM_RANK_CORES_PINNED", None)

@@ -75,3 +75,27 @@ def test_batched_solve_equals_per_image_solves():
         assert torch.equal(soft[i], s1) and torch.equal(binary[i], b1) and torch.equal(info[i], i1), i
     rs, rb, _ = B.bilateral_solver_output(imgs[5], tgts[5])
     assert np.abs(soft[5].cpu().numpy() - rs).max() <= 1e-9 and np.array_equal(binary[5].cpu().numpy().astype(bool), rb)
+
+
+def test_refinement_at_the_bench_batch_384_x_32():
+    """BASELINE configs[2] at the size bench.py's refine_384 leg runs: 32 scenes of 384^2 in one batched solve.  Three of them equal
+    their own single solves bit for bit (vertex / iteration counts included), one is checked against the CPU oracle, a second call
+    reproduces the first."""
+    from selfmask_amd.bilateral_solver import bilateral_solver_batch_device
+    from selfmask_amd.datasets import synthetic_scene
+    S, n = 384, 32
+    rng = np.random.Generator(np.random.PCG64(77))
+    scenes = [synthetic_scene(rng, S, S) for _ in range(n)]
+    imgs = np.stack([im for im, _ in scenes])
+    tgts = np.stack([np.clip(0.15 + 0.7 * g + rng.standard_normal((S, S)) * 0.1, 0, 1) for _, g in scenes])
+    I, T = torch.from_numpy(imgs).to(DEV), torch.from_numpy(tgts).to(DEV)
+    soft, binary, info = bilateral_solver_batch_device(I, T, return_info=True)
+    soft2, binary2, info2 = bilateral_solver_batch_device(I, T, return_info=True)
+    assert torch.equal(soft, soft2) and torch.equal(binary, binary2) and torch.equal(info, info2)
+    for i in (0, 13, 31):
+        s1, b1, i1 = bilateral_solver_output_device(I[i], T[i], return_info=True)
+        assert torch.equal(soft[i], s1) and torch.equal(binary[i], b1) and torch.equal(info[i], i1), i
+    rs, rb, _ = B.bilateral_solver_output(imgs[13], tgts[13])
+    d = np.abs(soft[13].cpu().numpy() - rs).max()
+    print(f"\n384^2 x 32: V={int(info[13, 0])} cg_iters={int(info[13, 1])} max|soft-oracle|={d:.2e}")
+    assert d <= 1e-9 and np.array_equal(binary[13].cpu().numpy().astype(bool), rb)

@@ -206,6 +206,43 @@ def test_full_bench_batch_64_properties(mode):
     assert (out["objectness"][pick].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
 
 
+@pytest.mark.parametrize("patch,size,B", [(8, 224, 16), (16, 384, 32)], ids=["vit_s8_224_b16", "vit_s16_384_b32"])
+def test_other_bench_shapes_at_full_size(patch, size, B):
+    """The two other shapes bench.py times, AT the batch it times them with: ViT-S/8 224^2 x 16 (N = 785: the shipped
+    checkpoint's patch size, M = 12 560 token rows) and ViT-S/16 384^2 x 32 (N = 577: BASELINE configs[2], M = 18 464) - the 256 x 256
+    / 256 x 128 tiles at those M and attention_f16x2 at those N.  Same properties as the batch-64 test: a second call gives the
+    same bits, twin images give twin outputs, three picked images alone give the bits they have inside the batch, and those three
+    meet the strict 1e-4 gate against the CPU oracle (calib weights)."""
+    sd = synthetic_state_dict(12, "calib", patch_size=patch)
+    xs = synthetic_images(778, (B, 3, size, size))
+    xs[B - 3] = xs[2]
+    x = torch.from_numpy(xs)
+    m = _model(patch, 12, "calib")
+    # the large-batch kernel set, pinned as the Evaluator pins it ("fused": LayerNorm launches, no folded pre-norms; with more than 208
+    # tokens the attention is the GEMM + attention_f16x2 pair in both sets) - what "auto" picks at these batch sizes
+    m.attention_path = "fused"
+    out = m(x.to(DEV), return_logits=True)
+    again = m(x.to(DEV), return_logits=True)
+    assert torch.equal(out["mask_logits"], again["mask_logits"]) and torch.equal(out["objectness"], again["objectness"])
+    assert torch.equal(out["mask_logits"][B - 3], out["mask_logits"][2]) and torch.equal(out["features"][B - 3], out["features"][2])
+    pick = [0, B // 2 - 1, B - 1]
+    for i in pick:
+        one = m(x[i:i + 1].to(DEV), return_logits=True)
+        assert torch.equal(one["mask_logits"][0], out["mask_logits"][i]), i
+        assert torch.equal(one["objectness"][0], out["objectness"][i]), i
+    m.attention_path = "auto"  # one image on the automatic path: the small-batch set (folded pre-norms) - the same result to rounding
+    auto_b = m(x.to(DEV), return_logits=True)
+    assert torch.equal(auto_b["mask_logits"], out["mask_logits"])  # and at the bench batch "auto" IS the pinned set
+    one = m(x[pick[1]:pick[1] + 1].to(DEV), return_logits=True)
+    assert (one["mask_logits"][0] - out["mask_logits"][pick[1]]).abs().max().item() <= 5e-5
+    o32 = O.forward(x[pick], sd, patch)
+    d = (out["mask_logits"][pick].cpu() - o32["mask_logits"]).abs().max().item()
+    print(f"\n[w16] ViT-S/{patch} {size}^2 B={B} calib, images {pick}: hip-oracle32={d:.2e}")
+    ledger.record(f"forward_vit_s{patch}_{size}_b{B}_calib_images", "w16", {"hip_minus_ref32": d, "rule": "hip-ref32 <= 1e-4", "images": pick})
+    assert d <= ABS_TOL
+    assert (out["objectness"][pick].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
+
+
 def test_hip_graph_replay_gives_the_eager_bits():
     """graphs.GraphedForward: the first two calls are eager, the third captures + replays, later ones replay; a new
     batch through the captured graph equals the eager forward bit for bit, on the default stream and on a side stream."""

@@ -118,3 +118,55 @@ def test_decode_pool_processes_write_the_same_bytes_as_decode_item(tmp_path):
         pool.close()
         slots.close()
     assert set(glob.glob("/dev/shm/sm_decode_*")) == before
+
+
+def test_workers_keep_no_mapping_of_a_finished_loader_and_paths_may_hold_any_character(tmp_path):
+    """every PrefetchingLoader makes its own ring of /dev/shm slots and unlinks it at the end; the shared
+    workers used to keep those unlinked segments mapped for good (tmpfs pages + address space, +7.5 MB per loader).  Now the
+    loader tells them to drop the ring (DecodePool.drop), and a worker also unmaps vanished segments when it meets a new one.
+    Requests are JSON lines: a path with a tab and a newline decodes like any other.  ``list(loader)`` holds owned arrays."""
+    import shutil
+    from selfmask_amd import datasets as DS
+    from selfmask_amd.decode_pool import shared_pool
+    from selfmask_amd.pipeline import PrefetchingLoader, decode_item
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 9, seed=5, size_range=(40, 70))
+    ds = DS.get_dataset(str(tmp_path), "ecssd")
+    odd = str(tmp_path / "odd\tname\nwith breaks.jpg")
+    shutil.copy(ds.p_imgs[0], odd)
+    ds.p_imgs[0] = odd
+    pool = shared_pool(2)
+
+    def deleted_maps():
+        n = 0
+        for p in pool._procs:
+            with open(f"/proc/{p.pid}/maps") as f:
+                n += sum(1 for line in f if "sm_decode_" in line and "(deleted)" in line)
+        return n
+
+    for _ in range(3):
+        got = list(PrefetchingLoader(ds, range(len(ds)), 4, workers=2, depth=1))
+        assert deleted_maps() == 0
+    # batches of a finished iteration are still intact (slot k % 2 was reused twice since batch 0 was yielded)
+    for rgbs, gts, idx in got:
+        for r, g, i in zip(rgbs, gts, idx):
+            rr, gg = decode_item(ds.p_imgs[i], ds.p_gts[i])
+            assert np.array_equal(r, rr) and np.array_equal(g, gg) and r.flags.owndata
+    assert pool.drop(["/dev/shm/never_mapped"]) == 0
+
+
+def test_loader_falls_back_to_threads_without_shared_memory(tmp_path, monkeypatch):
+    import warnings
+    from selfmask_amd import datasets as DS
+    from selfmask_amd import decode_pool
+    from selfmask_amd.pipeline import PrefetchingLoader, decode_item
+    DS.write_synthetic_dataset(str(tmp_path), "ecssd", 5, seed=6, size_range=(40, 60))
+    ds = DS.get_dataset(str(tmp_path), "ecssd")
+
+    def no_shm(*a, **k):
+        raise OSError(28, "No space left on device")
+    monkeypatch.setattr(decode_pool.BatchSlots, "__init__", no_shm)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = list(PrefetchingLoader(ds, range(len(ds)), 2, workers=2, depth=1))
+    assert any("decoding on threads" in str(x.message) for x in w)
+    assert sum(len(b[0]) for b in out) == 5 and np.array_equal(out[0][0][0], decode_item(ds.p_imgs[0], ds.p_gts[0])[0])
