@@ -491,7 +491,7 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=16, steps=10, warmup=3, cpu=Tr
 
     def chain():
         cands = VT.extract_candidate_masks(model, x)  # (B, 9, S, S)
-        return [VT.vote_mask(cands[b])[1] for b in range(B)]
+        return [r[1] for r in VT.vote_mask_batch(cands)]
 
     for _ in range(warmup):
         chain()
@@ -771,19 +771,21 @@ def main():
         flops_img = forward_flops_per_image(P, S)
         dom_name, dom = next(iter(kern.items()))
         # HBM bytes per launch from the PMC passes of this same command (scripts/pmc_traffic.sh writes
-        # profiles/r03_pmc_traffic.json with the hash of the kernel sources it ran on).  A profiler cannot run inside the
+        # profiles/r04_pmc_traffic.json with the hash of the kernel sources it ran on).  A profiler cannot run inside the
         # timed process, so the committed measurement is quoted - only if it was taken on exactly these sources, else null.
         traffic, traffic_note = None, "no PMC file for these kernel sources"
-        try:
-            with open(os.path.join(REPO, "profiles", "r03_pmc_traffic.json")) as f:
-                pmc = json.load(f)
+        for rnd in ("r04", "r03"):  # the newest PMC passes whose kernel-source hash matches
+            pf = f"profiles/{rnd}_pmc_traffic.json"
+            try:
+                with open(os.path.join(REPO, pf)) as f:
+                    pmc = json.load(f)
+            except (OSError, ValueError):
+                continue
             if pmc.get("source_hash") == source_hash():
-                traffic = pmc["kernels"].get(dom_name, {}).get("hbm_bytes_per_launch")
-                traffic_note = "profiles/r03_pmc_traffic.json (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950)"
-            else:
-                traffic_note = "profiles/r03_pmc_traffic.json was taken on other kernel sources (hash mismatch): not quoted"
-        except (OSError, ValueError, KeyError):
-            pass
+                traffic = pmc.get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
+                traffic_note = f"{pf} (separate FETCH_SIZE / WRITE_SIZE passes, FETCH x2 on gfx950)"
+                break
+            traffic_note = f"{pf} was taken on other kernel sources (hash mismatch): not quoted"
         peak = F32_MFMA_PEAK_TFLOPS if model.gemm_mode == "fp32" else F16_MFMA_PEAK_TFLOPS
         issue = 3.0 if model.gemm_mode in ("w16", "f16x2") else 1.0  # MFMA FLOPs issued per algorithmic FLOP (hi*hi, hi*lo, lo*hi)
 

@@ -161,6 +161,15 @@ typedef struct sm_ln_args {
     float* raw;                  /* NULL, or (rows,384) fp32 with x's row map / stride: the value BEFORE normalisation (with
                                     n_partials > 0 the reduced sum + pre_bias + residual: a pre-norm block's new residual
                                     stream; may alias `residual`)                                                       */
+    /* optional SECOND LayerNorm chained onto the first, in the same launch: chain_y[map(r)] = LN(y[r]; chain_gamma, chain_beta,
+     * chain_eps) (+ its F16X2 copy chain_ys) - the decoder's shared final norm applied to every layer's output
+     * (transformer_decoder.py:138-139 `self.norm(output)` right after norm3, :295), same bits as a launch of its own on y */
+    const float *chain_gamma, *chain_beta; /* NULL = no chained norm */
+    float* chain_y;              /* row stride chain_ldy, rows scattered by chain_map; may be NULL when only chain_ys is wanted */
+    float* chain_ys;
+    int64_t chain_ldy;
+    sm_row_map chain_map;
+    float chain_eps;
 } sm_ln_args;
 int sm_layernorm_rows_f32(const sm_ln_args* args, void* stream);
 
@@ -332,6 +341,15 @@ size_t sm_vote_workspace_bytes(int32_t M, int32_t H, int32_t W);
 int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int32_t remove_long, int32_t remove_small_large,
                      int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* B images of one size in one launch sequence: masks (B, M, H, W), keep (B, M), iou (B, M, M), row_sums (B, M), best (B),
+ * workspace >= B * sm_vote_workspace_bytes(M, H, W).  Image b's results are those of its own sm_vote_masks_u8 call. */
+int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, int32_t remove_long,
+                           int32_t remove_small_large, int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* labels (B, n_sizes, lh * lw) int32 of sm_spectral_cluster_f32 (or any clusterer) -> masks (B, sum of cluster_sizes, H, W) uint8 in one
+ * launch: sm_labels_to_masks_u8 for every (image, cluster size).  cluster_sizes: HOST array of n_sizes <= 8 entries. */
+int sm_labels_to_masks_batch_u8(const int32_t* labels, int32_t B, int32_t n_sizes, const int32_t* cluster_sizes, int32_t lh, int32_t lw,
+                                int32_t scale, int32_t H, int32_t W, uint8_t* masks, void* stream);
 
 /* ---- candidate masks of the pseudo-mask generator, DINO branch (mask_generator.pyc@L136-200) --------------------
  * features = F.interpolate(tokens, scale_factor=2, mode="bilinear", align_corners=True): tok (B, gh*gw, 384) with batch stride

@@ -173,7 +173,41 @@ __global__ __launch_bounds__(256) void labels_to_masks_kernel(const int* __restr
     }
 }
 
+struct LmSizes { int k[8], first[9]; };
+// every (image, cluster size) in one launch: mask plane c of image b belongs to cluster size s = the one with first[s] <= c < first[s + 1]
+__global__ __launch_bounds__(256) void labels_to_masks_batch_kernel(const int* __restrict__ labels, int n_sizes, LmSizes sz, int lh, int lw, int s,
+                                                                   int H, int W, unsigned char* __restrict__ masks) {
+    const int total_k = sz.first[n_sizes], plane = blockIdx.y, b = blockIdx.z;
+    int si = 0;
+    while (si + 1 < n_sizes && plane >= sz.first[si + 1]) ++si;
+    const int c = plane - sz.first[si];
+    const int* lab = labels + ((int64_t)b * n_sizes + si) * lh * lw;
+    unsigned char* out = masks + ((int64_t)b * total_k + plane) * H * W;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < H * W; t += gridDim.x * 256) {
+        const int x = t % W, y = t / W;
+        out[t] = lab[min(y / s, lh - 1) * lw + min(x / s, lw - 1)] == c ? 1 : 0;
+    }
+}
+
 }  // namespace sm
+
+extern "C" int sm_labels_to_masks_batch_u8(const int32_t* labels, int32_t B, int32_t n_sizes, const int32_t* cluster_sizes, int32_t lh,
+                                           int32_t lw, int32_t scale, int32_t H, int32_t W, uint8_t* masks, void* stream) {
+    SM_REQUIRE(labels && masks && cluster_sizes && B > 0 && B <= 65535 && n_sizes >= 1 && n_sizes <= 8 && lh > 0 && lw > 0 && scale >= 1 &&
+                   H > 0 && W > 0 && H <= lh * scale && W <= lw * scale,
+               "sm_labels_to_masks_batch_u8: bad arguments (1..8 cluster sizes, H <= lh * scale, W <= lw * scale)");
+    sm::LmSizes sz = {};
+    for (int i = 0; i < n_sizes; ++i) {
+        SM_REQUIRE(cluster_sizes[i] >= 1 && cluster_sizes[i] <= 64, "sm_labels_to_masks_batch_u8: cluster size %d", cluster_sizes[i]);
+        sz.k[i] = cluster_sizes[i];
+        sz.first[i + 1] = sz.first[i] + cluster_sizes[i];
+    }
+    int gx = (H * W + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(sm::labels_to_masks_batch_kernel, dim3(gx, sz.first[n_sizes], B), dim3(256), 0, (hipStream_t)stream, labels, n_sizes, sz,
+                       lh, lw, scale, H, W, masks);
+    return sm::check_launch("sm_labels_to_masks_batch_u8");
+}
 
 extern "C" int sm_upsample_tokens_aligned_f32(const float* tok, int64_t strideb, float* up, int32_t B, int32_t gh, int32_t gw,
                                               int32_t scale, void* stream) {

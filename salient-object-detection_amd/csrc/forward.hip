@@ -200,6 +200,11 @@ struct LnOpt {
     const float* pre_bias = nullptr;
     const float* residual = nullptr;
     float* raw = nullptr;       // the value before normalisation (sm_ln_args.raw)
+    // a second norm chained onto this one in the same launch (sm_ln_args.chain_*): the decoder's shared final norm
+    const float *chain_w = nullptr, *chain_b = nullptr;
+    float *chain_y = nullptr, *chain_ys = nullptr;
+    sm_row_map chain_map = {0, 0, 0};
+    float chain_eps = 0.f;
 };
 static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, float* y, int64_t rows, float eps,
               const LnOpt& o = LnOpt()) {
@@ -209,6 +214,8 @@ static int ln(const Ctx& c, const float* x, const float* gw, const float* gb, fl
     a.rows = (int)rows; a.eps = eps;
     a.n_partials = o.n_partials; a.partial_stride = o.partial_stride; a.pre_bias = o.pre_bias; a.residual = o.residual;
     a.ys = o.ys; a.y2_f16x2 = o.y2_s ? 1 : 0; a.raw = o.raw;
+    a.chain_gamma = o.chain_w; a.chain_beta = o.chain_b; a.chain_y = o.chain_y; a.chain_ys = o.chain_ys; a.chain_ldy = SM_EMBED;
+    a.chain_map = o.chain_map; a.chain_eps = o.chain_eps;
     TapScope tap(c.st, "layernorm384_kernel", 0.0, 2.0 * rows * SM_EMBED * 4);
     return sm_layernorm_rows_f32(&a, c.st);
 }
@@ -493,15 +500,13 @@ static int forward(const sm_weights* w, const sm_forward_io* io, float* wsbase, 
             o.ys = S ? ws.TGTs : nullptr;
             o.y2 = ws.TGTQ; o.y2_s = S; o.add = qpos; o.add_rows = s.nq;
             o.n_partials = 4; o.partial_stride = s.Md * D; o.pre_bias = d.lin2_b; o.residual = ws.TGT;
+            // ... and, chained in the same launch, the shared final norm on this layer's output, scattered into (B, L, nq, 384)
+            // (+ F16X2 copy): transformer_decoder.py:138-139.  Six launches fewer on the critical chain of a forward (serving).
+            o.chain_w = w->dec_norm_w; o.chain_b = w->dec_norm_b; o.chain_y = QD; o.chain_ys = S ? ws.QDs : nullptr;
+            o.chain_map = {s.nq, s.L * s.nq, l * s.nq}; o.chain_eps = 1e-5f;
             TRY(ln(c, ws.PART, d.norm3_w, d.norm3_b, ws.T2, s.Md, 1e-5f, o));
         }
         { float* t = ws.TGT; ws.TGT = ws.T2; ws.T2 = t; }  // norm3 wrote the new tgt into T2
-        {
-            LnOpt o;  // shared final norm on every layer's output, scattered into (B, L, nq, 384) (+ F16X2 copy)
-            o.out_map = {s.nq, s.L * s.nq, l * s.nq};
-            o.ys = S ? ws.QDs : nullptr;
-            TRY(ln(c, ws.TGT, w->dec_norm_w, w->dec_norm_b, QD, s.Md, 1e-5f, o));
-        }
     }
     const float* qd_a = S ? ws.QDs : QD;
 

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
     float* ysr = a.ys ? a.ys + orow * a.ldy : nullptr;
     float* y2r = a.y2 ? a.y2 + (int64_t)row * a.ldy2 : nullptr;
     const float* ar = a.y2 ? a.add + (int64_t)(row % a.add_rows) * SM_EMBED : nullptr;
+    const bool chain = a.chain_gamma != nullptr;  // (kernel-uniform)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int k = (l16 + 16 * i) * 8;
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
             const float4 bt = *reinterpret_cast<const float4*>(a.beta + k + 4 * h);
             o[4 * h + 0] = v[i][4 * h + 0] * rstd * gm.x + bt.x; o[4 * h + 1] = v[i][4 * h + 1] * rstd * gm.y + bt.y;
             o[4 * h + 2] = v[i][4 * h + 2] * rstd * gm.z + bt.z; o[4 * h + 3] = v[i][4 * h + 3] * rstd * gm.w + bt.w;
+        }
+        if (chain) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[i][e] = o[e];  // the chained norm's input: y as stored
         }
         const float (&o0)[4] = *reinterpret_cast<const float (*)[4]>(&o[0]);
         const float (&o1)[4] = *reinterpret_cast<const float (*)[4]>(&o[4]);
@@ -114,6 +119,43 @@ __global__ __launch_bounds__(256) void layernorm384_kernel(sm_ln_args a) {
                 *reinterpret_cast<float4*>(y2r + k + 4) = make_float4(o[4], o[5], o[6], o[7]);
             }
         }
+    }
+    if (!chain) return;
+    // chained norm: the same arithmetic, in the same order, as a launch of its own reading y (every lane of a live row's group is live)
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s2 += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+    const float mean2 = group16_sum(s2) * (1.0f / 384.0f);
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] -= mean2;
+            q2 += v[i][e] * v[i][e];
+        }
+    const float rstd2 = 1.0f / sqrtf(group16_sum(q2) * (1.0f / 384.0f) + a.chain_eps);
+    const int64_t crow = map_row(row, a.chain_map);
+    float* cyr = a.chain_y ? a.chain_y + crow * a.chain_ldy : nullptr;
+    float* cysr = a.chain_ys ? a.chain_ys + crow * a.chain_ldy : nullptr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = (l16 + 16 * i) * 8;
+        float o[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 gm = *reinterpret_cast<const float4*>(a.chain_gamma + k + 4 * h);
+            const float4 bt = *reinterpret_cast<const float4*>(a.chain_beta + k + 4 * h);
+            o[4 * h + 0] = v[i][4 * h + 0] * rstd2 * gm.x + bt.x; o[4 * h + 1] = v[i][4 * h + 1] * rstd2 * gm.y + bt.y;
+            o[4 * h + 2] = v[i][4 * h + 2] * rstd2 * gm.z + bt.z; o[4 * h + 3] = v[i][4 * h + 3] * rstd2 * gm.w + bt.w;
+        }
+        const float (&o0)[4] = *reinterpret_cast<const float (*)[4]>(&o[0]);
+        const float (&o1)[4] = *reinterpret_cast<const float (*)[4]>(&o[4]);
+        if (cyr) {
+            *reinterpret_cast<float4*>(cyr + k) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(cyr + k + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (cysr) store_f16x2_8(cysr, k, o0, o1);
     }
 }
 
@@ -138,6 +180,10 @@ extern "C" int sm_layernorm_rows_f32(const sm_ln_args* a, void* stream) {
     if (a->n_partials > 0)
         SM_REQUIRE(a->pre_bias && a->residual && a->partial_stride > 0 && a->partial_stride % 4 == 0, "sm_layernorm_f32: bad partials");
     if (a->y2) SM_REQUIRE(a->add && a->add_rows > 0 && a->ldy2 >= SM_EMBED && a->ldy2 % 4 == 0, "sm_layernorm_f32: bad y2/add");
+    if (a->chain_gamma)
+        SM_REQUIRE(a->chain_beta && (a->chain_y || a->chain_ys) && a->chain_ldy >= SM_EMBED && a->chain_ldy % 8 == 0 && a->chain_map.group >= 0 &&
+                       ((uintptr_t)a->chain_gamma | (uintptr_t)a->chain_beta | (uintptr_t)a->chain_y | (uintptr_t)a->chain_ys) % 16 == 0,
+                   "sm_layernorm_f32: bad chained norm (gamma, beta, an output, ld %% 8 == 0, 16-B aligned)");
     if (a->rows == 0) return SM_OK;
     hipLaunchKernelGGL(sm::layernorm384_kernel, dim3((a->rows + 15) / 16), dim3(256), 0, (hipStream_t)stream, *a);
     return sm::check_launch("sm_layernorm_f32");

@@ -19,9 +19,12 @@ namespace sm {
 struct VoteBox { int ymin, ymax, xmin, xmax; unsigned area; };
 
 __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __restrict__ masks, unsigned long long* __restrict__ bits,
-                                                       VoteBox* __restrict__ box, int H, int W, int words) {
+                                                       VoteBox* __restrict__ box, int H, int W, int words, int M) {
     const int m = blockIdx.y;
     const int64_t npx = (int64_t)H * W;
+    masks += (int64_t)blockIdx.z * M * npx;  // blockIdx.z: image of a batch (every per-image array is laid end to end)
+    bits += (int64_t)blockIdx.z * M * words;
+    box += (int64_t)blockIdx.z * M;
     const unsigned char* src = masks + (int64_t)m * npx;
     const int lane = threadIdx.x & 63;
     int ymin = 1 << 30, ymax = -1, xmin = 1 << 30, xmax = -1;
@@ -51,6 +54,8 @@ __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __r
 }
 
 __global__ __launch_bounds__(256) void vote_init_kernel(VoteBox* box, unsigned* inter, int M) {
+    box += (int64_t)blockIdx.z * M;
+    inter += (int64_t)blockIdx.z * M * M;
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < M) { box[t].ymin = 1 << 30; box[t].ymax = -1; box[t].xmin = 1 << 30; box[t].xmax = -1; box[t].area = 0; }
     if (t < M * M) inter[t] = 0;
@@ -59,6 +64,8 @@ __global__ __launch_bounds__(256) void vote_init_kernel(VoteBox* box, unsigned* 
 // one workgroup per (pair (i, j >= i), word chunk)
 __global__ __launch_bounds__(256) void vote_pairs_kernel(const unsigned long long* __restrict__ bits, unsigned* __restrict__ inter, int M,
                                                         int words) {
+    bits += (int64_t)blockIdx.z * M * words;
+    inter += (int64_t)blockIdx.z * M * M;
     int i = 0, rem = blockIdx.y;  // pair index -> (i, j): row i holds M - i pairs
     while (rem >= M - i) { rem -= M - i; ++i; }
     const int j = i + rem;
@@ -75,6 +82,8 @@ __global__ __launch_bounds__(64) void vote_finalize_kernel(const VoteBox* __rest
                                                           int W, int remove_long, int remove_small_large, int* __restrict__ keep,
                                                           float* __restrict__ iou, float* __restrict__ row_sums, int* __restrict__ best) {
     const int t = threadIdx.x;
+    box += (int64_t)blockIdx.z * M; inter += (int64_t)blockIdx.z * M * M; keep += (int64_t)blockIdx.z * M;
+    iou += (int64_t)blockIdx.z * M * M; row_sums += (int64_t)blockIdx.z * M; best += blockIdx.z;
     __shared__ int skeep[64];
     if (t < M) {
         const VoteBox b = box[t];
@@ -134,27 +143,34 @@ extern "C" size_t sm_vote_workspace_bytes(int32_t M, int32_t H, int32_t W) {
            (((size_t)M * M * 4 + 255) & ~(size_t)255);
 }
 
-extern "C" int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int32_t remove_long, int32_t remove_small_large,
-                                int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace, size_t workspace_bytes,
-                                void* stream) {
+extern "C" int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, int32_t remove_long,
+                                      int32_t remove_small_large, int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
     SM_REQUIRE(masks && keep && iou && row_sums && best && workspace, "sm_vote_masks_u8: null pointer");
-    SM_REQUIRE(M > 0 && M <= 64 && H > 0 && W > 0, "sm_vote_masks_u8: M=%d candidates (1..64), %dx%d", M, H, W);
-    SM_REQUIRE(workspace_bytes >= sm_vote_workspace_bytes(M, H, W) && ((uintptr_t)workspace % 256) == 0,
+    SM_REQUIRE(B > 0 && B <= 65535 && M > 0 && M <= 64 && H > 0 && W > 0, "sm_vote_masks_u8: %d images, M=%d candidates (1..64), %dx%d", B, M, H, W);
+    SM_REQUIRE(workspace_bytes >= (size_t)B * sm_vote_workspace_bytes(M, H, W) && ((uintptr_t)workspace % 256) == 0,
                "sm_vote_masks_u8: workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;
     const int words = (int)(((size_t)H * W + 63) / 64);
-    char* w = (char*)workspace;
+    char* w = (char*)workspace;  // [bitmaps of all images | boxes of all images | intersections of all images]
     auto* bits = (unsigned long long*)w;
-    w += ((size_t)M * words * 8 + 255) & ~(size_t)255;
+    w += ((size_t)B * M * words * 8 + 255) & ~(size_t)255;
     auto* box = (sm::VoteBox*)w;
-    w += ((size_t)M * sizeof(sm::VoteBox) + 255) & ~(size_t)255;
+    w += ((size_t)B * M * sizeof(sm::VoteBox) + 255) & ~(size_t)255;
     auto* inter = (unsigned*)w;
-    hipLaunchKernelGGL(sm::vote_init_kernel, dim3((M * M + 255) / 256), dim3(256), 0, st, box, inter, M);
+    hipLaunchKernelGGL(sm::vote_init_kernel, dim3((M * M + 255) / 256, 1, B), dim3(256), 0, st, box, inter, M);
     const int gx = (words + 3) / 4 < 256 ? (words + 3) / 4 : 256;
-    hipLaunchKernelGGL(sm::vote_pack_kernel, dim3(gx, M), dim3(256), 0, st, masks, bits, box, H, W, words);
-    hipLaunchKernelGGL(sm::vote_pairs_kernel, dim3((words + 255) / 256 < 16 ? (words + 255) / 256 : 16, M * (M + 1) / 2), dim3(256), 0, st,
+    hipLaunchKernelGGL(sm::vote_pack_kernel, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M);
+    hipLaunchKernelGGL(sm::vote_pairs_kernel, dim3((words + 255) / 256 < 16 ? (words + 255) / 256 : 16, M * (M + 1) / 2, B), dim3(256), 0, st,
                        bits, inter, M, words);
-    hipLaunchKernelGGL(sm::vote_finalize_kernel, dim3(1), dim3(64), 0, st, box, inter, M, H, W, remove_long, remove_small_large, keep, iou,
+    hipLaunchKernelGGL(sm::vote_finalize_kernel, dim3(1, 1, B), dim3(64), 0, st, box, inter, M, H, W, remove_long, remove_small_large, keep, iou,
                        row_sums, best);
     return sm::check_launch("sm_vote_masks_u8");
+}
+
+extern "C" int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int32_t remove_long, int32_t remove_small_large,
+                                int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+    return sm_vote_masks_batch_u8(masks, 1, M, H, W, remove_long, remove_small_large, keep, iou, row_sums, best, workspace, workspace_bytes,
+                                  stream);
 }

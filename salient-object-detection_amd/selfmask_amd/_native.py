@@ -35,7 +35,8 @@ class LnArgs(C.Structure):
                 ("y", fp), ("ldy", C.c_int64), ("out_map", RowMap), ("y2", fp), ("ldy2", C.c_int64),
                 ("add", fp), ("add_rows", C.c_int32), ("rows", C.c_int32), ("eps", C.c_float), ("n_partials", C.c_int32),
                 ("partial_stride", C.c_int64), ("pre_bias", fp), ("residual", fp), ("ys", fp), ("y2_f16x2", C.c_int32),
-                ("raw", fp)]
+                ("raw", fp), ("chain_gamma", fp), ("chain_beta", fp), ("chain_y", fp), ("chain_ys", fp), ("chain_ldy", C.c_int64),
+                ("chain_map", RowMap), ("chain_eps", C.c_float)]
 
 
 class AttnArgs(C.Structure):
@@ -165,6 +166,9 @@ SYMBOLS = {
     "sm_pick_mask_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_vote_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sm_vote_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "sm_vote_masks_batch_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "sm_labels_to_masks_batch_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                              C.c_int32, fp, fp]),
     "sm_upsample_tokens_aligned_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_kmeans_f32": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp]),
     "sm_labels_to_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp]),

@@ -60,6 +60,41 @@ def vote_mask(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, re
     return batch_pred_masks[best_h], prev_to_new[best_h], new_to_prev
 
 
+def vote_mask_batch(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False):
+    """``vote_mask`` for B images of one size in one launch sequence and ONE device-to-host copy: (B, M, H, W) 0/1 -> list of B
+    tuples (best mask (H, W), best index among the survivors, new_index_to_prev_index), each what ``vote_mask`` returns for that image."""
+    if not batch_pred_masks.is_cuda:
+        raise RuntimeError("vote_mask_batch (MI355X) needs its candidates on a HIP device; there is no CPU fallback")
+    m = batch_pred_masks.to(torch.uint8).contiguous()
+    B, M, H, W = m.shape
+    lib = N.load()
+    dev = m.device
+    nbytes = lib.sm_vote_workspace_bytes(M, H, W)
+    if nbytes == 0:
+        raise ValueError(f"vote_mask_batch: {M} candidates of {H}x{W} (1..64 candidates)")
+    ws = torch.empty(nbytes * B, dtype=torch.uint8, device=dev)
+    keep = torch.empty((B, M), dtype=torch.int32, device=dev)
+    iou = torch.empty((B, M, M), dtype=torch.float32, device=dev)
+    sums = torch.empty((B, M), dtype=torch.float32, device=dev)
+    best = torch.empty(B, dtype=torch.int32, device=dev)
+    N.check(lib.sm_vote_masks_batch_u8(m.data_ptr(), B, M, H, W, int(remove_long_masks), int(remove_small_large_masks), keep.data_ptr(),
+                                       iou.data_ptr(), sums.data_ptr(), best.data_ptr(), ws.data_ptr(), nbytes * B,
+                                       torch.cuda.current_stream(dev).cuda_stream), "sm_vote_masks_batch_u8")
+    host = torch.cat([keep, best[:, None]], dim=1).cpu().tolist()  # one copy for the whole batch
+    vote_mask_batch.last = {"keep": keep, "iou": iou, "row_sums": sums, "best": best}
+    out = []
+    for b, row in enumerate(host):
+        keep_h, best_h = row[:M], row[M]
+        if best_h < 0:
+            raise RuntimeError("sm_vote_masks_batch_u8 returned no winner")
+        new_to_prev = {}
+        for prev, k in enumerate(keep_h):
+            if k:
+                new_to_prev[len(new_to_prev)] = prev
+        out.append((batch_pred_masks[b, best_h], {v: k for k, v in new_to_prev.items()}[best_h], new_to_prev))
+    return out
+
+
 def kmeans(features: torch.Tensor, k: int, iters: int = 20):
     """features (B, n, 384) fp32 on a HIP device -> labels (B, n) int32: Lloyd's k-means with farthest-point initial centres,
     deterministic (csrc/cluster.hip).  Also returns the centres (B, k, 384)."""
@@ -137,6 +172,21 @@ def labels_to_masks(labels: torch.Tensor, k: int, scale: int, H: int, W: int) ->
     return masks
 
 
+def labels_to_masks_batch(labels: torch.Tensor, cluster_sizes: Sequence[int], lh: int, lw: int, scale: int, H: int, W: int) -> torch.Tensor:
+    """labels (B, len(cluster_sizes), lh * lw) int32 -> (B, sum(cluster_sizes), H, W) uint8: ``labels_to_masks`` for every (image,
+    cluster size) in one launch."""
+    lab = labels.contiguous().to(torch.int32)
+    B, ns = lab.shape[:2]
+    sizes = [int(k) for k in cluster_sizes]
+    assert ns == len(sizes) and lab.shape[2] == lh * lw
+    masks = torch.empty((B, sum(sizes), H, W), dtype=torch.uint8, device=lab.device)
+    host_sizes = (C.c_int32 * ns)(*sizes)
+    N.check(N.load().sm_labels_to_masks_batch_u8(lab.data_ptr(), B, ns, C.cast(host_sizes, C.POINTER(C.c_int32)), lh, lw, scale, H, W,
+                                                 masks.data_ptr(), torch.cuda.current_stream(lab.device).cuda_stream),
+            "sm_labels_to_masks_batch_u8")
+    return masks
+
+
 @torch.no_grad()
 def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clusterer=None, iters: int = 20,
                             cluster_type: str = "spectral", n_neighbors: int = 10) -> torch.Tensor:
@@ -157,11 +207,10 @@ def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clu
     feats = upsample_tokens_aligned(tok.reshape(B, gh * gw, N.EMBED), gh, gw, 2)  # (B, 2gh, 2gw, 384)
     flat = feats.reshape(B, 4 * gh * gw, N.EMBED)
     if clusterer is not None:
-        per_k = [clusterer(flat, k).reshape(B, 2 * gh, 2 * gw) for k in cluster_sizes]
+        lab = torch.stack([clusterer(flat, k).reshape(B, 4 * gh * gw).to(torch.int32) for k in cluster_sizes], dim=1)
     elif cluster_type == "spectral":  # mask_generator.pyc@L30-38: "k-means" -> KMeansClustering, anything else -> SpectralClustering
         lab = spectral_cluster(flat, cluster_sizes, n_neighbors)
-        per_k = [lab[:, i].reshape(B, 2 * gh, 2 * gw) for i in range(len(cluster_sizes))]
     else:
-        per_k = [kmeans(flat, k, iters)[0].reshape(B, 2 * gh, 2 * gw) for k in cluster_sizes]
-    out = [torch.cat([labels_to_masks(per_k[i][b], k, p // 2, H, W) for i, k in enumerate(cluster_sizes)], dim=0) for b in range(B)]
-    return out[0] if B == 1 else torch.stack(out)
+        lab = torch.stack([kmeans(flat, k, iters)[0] for k in cluster_sizes], dim=1)
+    out = labels_to_masks_batch(lab, cluster_sizes, 2 * gh, 2 * gw, p // 2, H, W)  # (B, sum k, H, W): one launch
+    return out[0] if B == 1 else out

@@ -36,7 +36,7 @@ def test_struct_sizes_match_header_layout(tmp_path):
              "sm_bilateral_args": N.BilateralArgs, "sm_enc_layer": N.EncLayer, "sm_dec_layer": N.DecLayer,
              "sm_row_map": N.RowMap, "sm_kernel_time": N.KernelTime, "sm_qkv_attn_args": N.QkvAttnArgs, "sm_pre_image": N.PreImage,
              "sm_spectral_args": N.SpectralArgs}
-    last = {"sm_gemm_args": "mfma_terms", "sm_ln_args": "residual", "sm_attn_args": "scale", "sm_weights": "no_objectness",
+    last = {"sm_gemm_args": "mfma_terms", "sm_ln_args": "chain_eps", "sm_attn_args": "scale", "sm_weights": "no_objectness",
             "sm_forward_io": "last_layer_only", "sm_eval_args": "scale", "sm_bilateral_args": "W", "sm_qkv_attn_args": "mfma_terms", "sm_pre_image": "ksy",
             "sm_spectral_args": "kmeans_max_iter"}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{os.path.join(REPO, "include", "selfmask_hip.h")}"',

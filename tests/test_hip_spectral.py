@@ -125,3 +125,12 @@ def test_extract_candidates_spectral_then_vote(patch, size):
     assert km.shape == (9, H, W)
     two = VT.extract_candidate_masks(m, torch.cat([x, x]))
     assert two.shape == (2, 9, H, W) and torch.equal(two[0], cands) and torch.equal(two[1], cands)
+    # the batched forms (one launch per stage for all images) against the per-image ones
+    mixed = torch.stack([cands, km])
+    for (bm, bi, bmap), one in zip(VT.vote_mask_batch(mixed), (VT.vote_mask(cands), VT.vote_mask(km))):
+        assert bi == one[1] and bmap == one[2] and torch.equal(bm, one[0])
+    lab = torch.randint(0, 2, (3, 2, gh * gw * 4), generator=torch.Generator().manual_seed(1), dtype=torch.int32).to(DEV)
+    got = VT.labels_to_masks_batch(lab, (2, 3), 2 * gh, 2 * gw, patch // 2, H, W)
+    for b in range(3):
+        ref_b = torch.cat([VT.labels_to_masks(lab[b, i].reshape(2 * gh, 2 * gw), k, patch // 2, H, W) for i, k in enumerate((2, 3))])
+        assert torch.equal(got[b], ref_b)
