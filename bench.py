@@ -823,7 +823,9 @@ def main():
                 res["throughput_mode"] = throughput_mode_leg(dev, wl)
             if (P, S) == (16, 224) and not a.no_other_shapes:
                 # the shapes the shipped checkpoint (ViT-S/8, configs/duts-...yaml:39) and configs[2] (384^2) run at
-                res["other_shapes"] = {"vit_s8_224": shape_leg(dev, 8, 224, 16, len(ring.streams), cpu=not a.no_cpu_baseline),
+                # ViT-S/8 at batch 32 since round 4: its attention launch is 7 groups x 6 heads x B workgroups on 512 slots - 1.31 rounds of
+                # work in 2 at batch 16 (4.89 k images/s; 5.07 k at 24, 5.10 k at 32: profiles/r04_vit_s8_by_batch.log)
+                res["other_shapes"] = {"vit_s8_224": shape_leg(dev, 8, 224, 32, len(ring.streams), cpu=not a.no_cpu_baseline),
                                        "vit_s16_384": shape_leg(dev, 16, 384, 32, len(ring.streams), cpu=not a.no_cpu_baseline)}
                 res["refine_384"] = refine_leg(dev, len(ring.streams), cpu=not a.no_cpu_baseline)       # configs[2]
                 res["pseudo_masks"] = pseudo_masks_leg(dev, len(ring.streams), cpu=not a.no_cpu_baseline)  # configs[4]

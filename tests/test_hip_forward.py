@@ -206,10 +206,10 @@ def test_full_bench_batch_64_properties(mode):
     assert (out["objectness"][pick].cpu() - o32["objectness"]).abs().max().item() <= 2e-5
 
 
-@pytest.mark.parametrize("patch,size,B", [(8, 224, 16), (16, 384, 32)], ids=["vit_s8_224_b16", "vit_s16_384_b32"])
+@pytest.mark.parametrize("patch,size,B", [(8, 224, 16), (8, 224, 32), (16, 384, 32)], ids=["vit_s8_224_b16", "vit_s8_224_b32", "vit_s16_384_b32"])
 def test_other_bench_shapes_at_full_size(patch, size, B):
-    """The two other shapes bench.py times, AT the batch it times them with: ViT-S/8 224^2 x 16 (N = 785: the shipped
-    checkpoint's patch size, M = 12 560 token rows) and ViT-S/16 384^2 x 32 (N = 577: BASELINE configs[2], M = 18 464) - the 256 x 256
+    """The two other shapes bench.py times, AT the batch it times them with: ViT-S/8 224^2 x 16 and x 32 (N = 785: the
+    shipped checkpoint's patch size, M = 12 560 / 25 120 token rows; round 3 benched 16, round 4 benches 32) and ViT-S/16 384^2 x 32 (N = 577: BASELINE configs[2], M = 18 464) - the 256 x 256
     / 256 x 128 tiles at those M and attention_f16x2 at those N.  Same properties as the batch-64 test: a second call gives the
     same bits, twin images give twin outputs, three picked images alone give the bits they have inside the batch, and those three
     meet the strict 1e-4 gate against the CPU oracle (calib weights)."""
