@@ -1118,6 +1118,7 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // 4 waves of 64x32
         case 47: return sm::launch_gemm_m16<256, 128, 3, 4, 4, 4>(a, st);   // 16 waves of 64x32, ring of three (proj, fc2, qkv, patch)
 #ifdef SM_TUNING  // measured-and-rejected shapes, kept as comparisons (scripts/gemm_w16_sweep.py, scripts/gemm_stamps.py)
+        case 49: return sm::launch_gemm_m16<64, 64, 6, 2, 2, 1>(a, st);     // 64 x 64 behind a ring of six (96 KiB), round 4: batch-1 forward 1.209 -> 1.256 ms
         case 41: return sm::launch_gemm_m16<256, 128, 3, 4, 2, 2>(a, st);   // 8 waves of 64x64, ring of three
         case 46: return sm::launch_gemm_m16<128, 384, 2, 2, 4, 2>(a, st);   // full 384-wide rows: 8 waves of 64x96 (N = 384 GEMMs on 99 CUs)
         case 48: return sm::launch_gemm_m16<256, 128, 2, 4, 4, 4>(a, st);   // as 47 with a ring of two (96 KiB)
@@ -1163,6 +1164,7 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
         case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3, 3>";
         case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4, 3>";
 #ifdef SM_TUNING
+        case 49: return "gemm_w16m16_kernel<64, 64, 6, 2, 2, 1, 3>";
         case 41: return "gemm_w16m16_kernel<256, 128, 3, 4, 2, 2, 3>";
         case 46: return "gemm_w16m16_kernel<128, 384, 2, 2, 4, 2, 3>";
         case 48: return "gemm_w16m16_kernel<256, 128, 2, 4, 4, 4, 3>";
@@ -1215,6 +1217,10 @@ extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     const long wg128 = (long)((g->M + 127) / 128) * ((g->N + 127) / 128) * nb;
     const long wg256x128 = (long)((g->M + 255) / 256) * ((g->N + 127) / 128) * nb;
     const long wg256 = (long)((g->M + 255) / 256) * ((g->N + 255) / 256) * nb;
+    // (Small launches are latency chains - a 64 x 64 tile walks 12 K-tiles behind a ring of three - but a ring of six, five stages in
+    // flight before the first MFMA, is SLOWER: the batch-1 forward 1.209 -> 1.256 ms, serving p50 1.20 -> 1.25 ms: issuing 80 KiB of
+    // LDS-DMA per workgroup up front costs more address-unit time than the waits it removes.  profiles/r04_deep_ring_ab.log; variant
+    // 49 lives in the tuning build.)
     if (wg128x64 < 512) return m32 ? 4 : 44;
     const bool narrow = g->N <= 384;
     if (narrow && forced_n >= 0) return forced_n;
