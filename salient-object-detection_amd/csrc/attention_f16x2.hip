@@ -38,8 +38,11 @@ __device__ __forceinline__ f16x4 tr_read4(unsigned addr) {
 // slot permutation of row r: bits (r0, r1, r2, r3) -> XOR mask bits (0, 3, 1, 2)
 __device__ __forceinline__ int hat_swz(int r) { return (r & 1) | ((r & 2) << 2) | ((r & 4) >> 1) | ((r & 8) >> 1); }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_args a, int groups, int ablate) {
+// ALL (tuning build only; measured slower, see sm_attention_f16x2): every chunk of the keys has its own ring slot (at most four: n_k
+// <= 256) and all of them are requested before the first MFMA - meant for launches of at most one workgroup per CU (batch-1 serving, the
+// decoder's 20 queries), where a wave has one chunk of compute (~1 us) to hide the next chunk's DMA round trip behind.
+template <int NW, bool ALL = false>
+__global__ __launch_bounds__(NW * 64, ALL ? 1 : 2) void attention_f16x2_kernel(sm_attn_args a, int groups, int ablate) {
 #ifndef SM_TUNING
     ablate = 0;  // the timing-only ablations exist only in the tuning build (build.py --tuning)
 #endif
@@ -91,7 +94,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
         }
     };
     const int nch = (n_k + HAT_CH - 1) / HAT_CH;
-    issue(0, 0);
+    if constexpr (ALL) {
+        for (int c = 0; c < nch; ++c) issue(c, c);
+    } else {
+        issue(0, 0);
+    }
 
     // Q fragments (B operand of S^T = K Q^T): lane (r,h), 16-dim step t -> k-group 2t+h: hi chunk, lo chunk
     int qrow = q0 + r;
@@ -126,15 +133,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
     const int vpiece = 4 * cb + 2 * (trp >> 1), vsub = (trp & 1) * 8;
 
     for (int c = 0; c < nch; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // chunk c has landed for every wave, and every wave is done with chunk c-1
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch && (ablate != 2)) issue(c + 1, (c + 1) & 1);
+        if (!ALL || c == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // chunk c has landed for every wave, and every wave is done with chunk c-1
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (!ALL) {
+            if (c + 1 < nch && (ablate != 2)) issue(c + 1, (c + 1) & 1);
+        }
         if (!active || ablate == 1) continue;
         const int ck = min(HAT_CH, n_k - c * HAT_CH);
         const int nb2 = (ck + 31) >> 5;
-        const char* Ks = smema + (c & 1) * HAT_SLOT;
-        const unsigned vs_lds = lds0 + (c & 1) * HAT_SLOT + HAT_TENSOR;
+        const int slot = ALL ? c : (c & 1);
+        const char* Ks = smema + slot * HAT_SLOT;
+        const unsigned vs_lds = lds0 + slot * HAT_SLOT + HAT_TENSOR;
 
         // raw scores t = main + cross / 2048 (the softmax scale cs > 0 is applied inside the exponent's fma)
         f32x16 s[2];
@@ -256,12 +268,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attention_f16x2_kernel(sm_attn_arg
     }
 }
 
-template <int NW>
+template <int NW, bool ALL>
 static int launch_attn_h(const sm_attn_args& a, int groups, hipStream_t st) {
+    constexpr int SLOTS = ALL ? 4 : 2;
     static std::once_flag attr_once;
     std::call_once(attr_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<NW>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HAT_SLOT);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f16x2_kernel<NW, ALL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, SLOTS * HAT_SLOT);
         (void)hipGetLastError();
     });
 #ifdef SM_TUNING
@@ -270,7 +283,7 @@ static int launch_attn_h(const sm_attn_args& a, int groups, hipStream_t st) {
     constexpr int ablate = 0;
 #endif
     dim3 grid(groups * a.heads * a.batch);
-    hipLaunchKernelGGL((attention_f16x2_kernel<NW>), grid, dim3(NW * 64), 2 * HAT_SLOT, st, a, groups, ablate);
+    hipLaunchKernelGGL((attention_f16x2_kernel<NW, ALL>), grid, dim3(NW * 64), SLOTS * HAT_SLOT, st, a, groups, ablate);
     return check_launch("sm_attention_f16x2");
 }
 
@@ -291,5 +304,12 @@ extern "C" int sm_attention_f16x2(const sm_attn_args* a, void* stream) {
     const int nw = (nqb + groups - 1) / groups;
     // always four waves: those past the last query block (decoder: a single block) issue their share of the ring's DMA
     (void)nw;
-    return sm::launch_attn_h<4>(*a, groups, st);
+#ifdef SM_TUNING
+    // Round 4, measured and rejected: at most one workgroup per CU and at most four key chunks -> all chunks staged at once (128 KiB of
+    // LDS), no per-chunk barrier.  Batch-1 forward 1.209 -> 1.250 ms, batch 8 1.43 -> 1.48 ms (profiles/r04_attn_all_ab.log): the first
+    // MFMA now waits for 128 KiB of LDS-DMA instead of 32.  Tuning build only (SM_ATTN_ALL=1).
+    static const bool all_env = getenv("SM_ATTN_ALL") && atoi(getenv("SM_ATTN_ALL")) == 1;
+    if (all_env && (long)groups * a->heads * a->batch <= 256 && a->n_k <= 4 * sm::HAT_CH) return sm::launch_attn_h<4, true>(*a, groups, st);
+#endif
+    return sm::launch_attn_h<4, false>(*a, groups, st);
 }
