@@ -182,7 +182,7 @@ static int linear_residual_ln(const Ctx& c, const float* A, int lda, const float
 }
 // in split mode Q, K and V are F16X2 (written so by the projection GEMMs) and the f16 matrix cores do the work
 static int attn(const Ctx& c, sm_attn_args& a) {
-    TapScope tap(c.st, c.S ? "attention_f16x2_kernel<4>" : "attention_f32_kernel", 4.0 * a.batch * a.heads * a.n_q * (double)a.n_k * SM_HEAD_DIM,
+    TapScope tap(c.st, c.S ? "attention_f16x2_kernel<4, false>" : "attention_f32_kernel", 4.0 * a.batch * a.heads * a.n_q * (double)a.n_k * SM_HEAD_DIM,
                  8.0 * a.batch * a.heads * SM_HEAD_DIM * ((double)a.n_q + a.n_k));  // Q, O and K, V once, 4 B per element
     a.out_f16x2 = c.S;
     return c.S ? sm_attention_f16x2(&a, c.st) : sm_attention_f32(&a, c.st);

@@ -391,7 +391,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, WPS) void gemm_w16m16_kernel(sm_gem
     constexpr int NW = NWM * NWN, WTM = BM / NWM, WTN = BN / NWN;
     constexpr int TM = WTM / 16, TN = WTN / 16;       // 16x16 tiles per wave
     constexpr int ROWB = 128;
-    constexpr int NL = (SM_GEMM_LOADH && NW >= 8) ? NW / 2 : NW;   // waves that feed the ring
+    // waves that feed the ring: all of them, or the first half where a stage's 8-row pieces do not divide among all (the 256 x 192 tile)
+    constexpr int NL = ((SM_GEMM_LOADH && NW >= 8) || (BN / 8) % NW != 0 || (BM / 8) % NW != 0) ? NW / 2 : NW;
     constexpr int A_INST = BM / 8 / NL, W_INST = BN / 8 / NL;
     static_assert(A_INST * 8 * NL == BM && W_INST * 8 * NL == BN && TM * 16 * NWM == BM && TN * 16 * NWN == BN && (TM % 2) == 0, "tile split");
     constexpr int NI = A_INST + W_INST;
@@ -1084,7 +1085,7 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
     SM_REQUIRE((uint64_t)g->M * (uint64_t)g->lda * 4 < (1ull << 32) && (uint64_t)g->N * (uint64_t)g->ldw * 4 < (1ull << 32),
                "sm_gemm_w16: operands beyond 4 GiB (the ring's source addresses are 32-bit offsets from A / W)");
     if (g->ln_stats || g->ln_stats_out || g->C2) {
-        SM_REQUIRE(variant >= 40 && variant < 50 && variant != 46, "sm_gemm_w16: the LayerNorm fold needs the 16x16x32 kernels with 32-column wave tiles");
+        SM_REQUIRE(variant >= 40 && variant < 50 && variant != 46 && (variant != 43 || !(g->ln_stats_out || g->C2)), "sm_gemm_w16: the LayerNorm fold needs the 16x16x32 kernels with 32-column wave tiles");
         if (g->ln_stats)
             SM_REQUIRE(g->K == SM_EMBED && g->ln_c && ((uintptr_t)g->ln_c % 16) == 0 && ((uintptr_t)g->ln_stats % 16) == 0 && g->ln_eps > 0.f &&
                            g->epilogue != SM_EPI_RESIDUAL && g->epilogue != SM_EPI_PATCH && !(g->split_k > 1) && g->alt_from_n == 0,
@@ -1094,7 +1095,7 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
                            (!g->C2 || ((uintptr_t)g->C2 % 32) == 0) && (!g->ln_stats_out || ((uintptr_t)g->ln_stats_out % 8) == 0),
                        "sm_gemm_w16: the F16X2 copy / row statistics come from a RESIDUAL epilogue with N = 384");
     }
-    SM_REQUIRE(sm_gemm_w16_variant_name(variant) != nullptr, "sm_gemm_w16_tile: variant %d is not in this build (shipped: 40, 42, 44, 45, 47; "
+    SM_REQUIRE(sm_gemm_w16_variant_name(variant) != nullptr, "sm_gemm_w16_tile: variant %d is not in this build (shipped: 40, 42, 43, 44, 45, 47; "
                "the rejected shapes are in the tuning build)", variant);
     SM_REQUIRE(g->mfma_terms == 0 || g->mfma_terms == 3 || (g->mfma_terms == 1 && variant >= 40 && variant < 50),
                "sm_gemm_w16: mfma_terms must be 0/3 (fp32-grade) or 1 (throughput mode, 16x16x32 kernels only)");
@@ -1114,6 +1115,7 @@ extern "C" int sm_gemm_w16_tile(const sm_gemm_args* g, int out_f16x2, int varian
         // the shipped v_mfma_f32_16x16x32_f16 kernels
         case 40: return sm::launch_gemm_m16<256, 256, 2, 2, 8, 4>(a, st);   // 16 waves of 128x32 (fc1, all-layer K/V)
         case 42: return sm::launch_gemm_m16<128, 128, 2, 2, 4, 4>(a, st);   // 8 waves of 64x32
+        case 43: return sm::launch_gemm_m16<256, 192, 2, 4, 4, 4>(a, st);   // 16 waves of 64x48: N = 1536 / 4608 in 400 / 1200 tiles
         case 44: return sm::launch_gemm_m16<64, 64, 3, 2, 2, 3>(a, st);     // 4 waves of 32x32 (decoder, batch 1)
         case 45: return sm::launch_gemm_m16<128, 64, 2, 2, 2, 3>(a, st);    // 4 waves of 64x32
         case 47: return sm::launch_gemm_m16<256, 128, 3, 4, 4, 4>(a, st);   // 16 waves of 64x32, ring of three (proj, fc2, qkv, patch)
@@ -1160,6 +1162,7 @@ extern "C" const char* sm_gemm_w16_variant_name(int variant) {
     switch (variant) {
         case 40: return "gemm_w16m16_kernel<256, 256, 2, 2, 8, 4, 3>";
         case 42: return "gemm_w16m16_kernel<128, 128, 2, 2, 4, 4, 3>";
+        case 43: return "gemm_w16m16_kernel<256, 192, 2, 4, 4, 4, 3>";
         case 44: return "gemm_w16m16_kernel<64, 64, 3, 2, 2, 3, 3>";
         case 45: return "gemm_w16m16_kernel<128, 64, 2, 2, 2, 3, 3>";
         case 47: return "gemm_w16m16_kernel<256, 128, 3, 4, 4, 4, 3>";
@@ -1226,6 +1229,13 @@ extern "C" int sm_gemm_w16_pick(const sm_gemm_args* g) {
     if (narrow && forced_n >= 0) return forced_n;
     if (!narrow && forced_w >= 0) return forced_w;
     if (g->alt_from_n == 0 || g->alt_from_n % 256 == 0) {
+        // (256 x 192, variant 43: fc1 in 400 tiles = 1.56 rounds of 0.75-size tiles instead of 1.17 rounds in 2.  Measured, three
+        // alternations, profiles/r04_tile_256x192_ab.log: the lone launch 79.9 -> 70.7 us (0.086 -> 0.097 of the f16 roof), ONE stream
+        // 16.1 k -> 16.7 k images/s (+3.8 %), the three-stream pipeline the metric is quoted on 22.43 k -> 22.20 k (-1.0 %: 17 % more
+        // staged bytes per MFMA).  The pick follows the pipeline; an experiment build (-DSM_GEMM_TILE_192) or sm_gemm_w16_tile selects 43.)
+#ifdef SM_GEMM_TILE_192
+        if (g->N % 192 == 0 && g->N >= 1024 && wg256 >= 128 && !m32) return 43;
+#endif
         if (g->N % 256 == 0 && g->N >= 1024 && wg256 >= 128) return m32 ? 32 : 40;  // 256 x 256
         if (wg256x128 >= 128) return m32 ? 31 : 47;                                  // 256 x 128, ring of three, 16 waves
     }

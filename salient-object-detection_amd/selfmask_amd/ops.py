@@ -228,7 +228,8 @@ def fold_layernorm(weight: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor
     rows, K = weight.shape
     h = w16.view(torch.float16).reshape(rows, K // 8, 2, 8).double()
     c = ((h[:, :, 0, :] + h[:, :, 1, :]).reshape(rows, K).sum(1) * ws).float().contiguous()
-    b2 = (bias.double() + weight.double() @ beta.double()).float().contiguous()
+    # (an elementwise product + row sum, not `@`: weight packing stays off the vendor BLAS - one-time per checkpoint, not timed)
+    b2 = (bias.double() + (weight.double() * beta.double()[None, :]).sum(1)).float().contiguous()
     return w16, ws, b2, c
 
 
