@@ -8,7 +8,7 @@ ground truths inside the slot - exactly what ``pipeline.pack_images`` / ``pack_g
 
 A sample larger than its window (``max_side``) is decoded in-process instead (same function, same bytes - but on the GIL-holding
 consumer thread and after the worker has decoded it once for nothing: a warning says so once; size ``max_side`` for the dataset).
-Requests and replies are JSON lines, so a path may hold tabs or newlines.  When a ring of slots is closed its files are unlinked
+A request travels as a JSON line whenever a path holds a tab, a newline or a backslash (tab-separated otherwise: 0.5 us against 2.9).  When a ring of slots is closed its files are unlinked
 and the workers are told to unmap them (``DecodePool.drop``): a worker keeps no mapping of a finished loader.
 """
 import importlib.util
@@ -43,6 +43,11 @@ def decode_item(p_img, p_gt=None):
 
 
 _WARNED_BIG = False
+
+
+def _PLAIN(path: str) -> bool:
+    """may travel tab-separated: no tab, newline or backslash, and not something the worker would take for a JSON line"""
+    return not ("\t" in path or "\n" in path or "\\" in path or "\r" in path) and not path.startswith("J[")
 
 
 def _cgroup_cpus() -> Optional[float]:
@@ -148,7 +153,7 @@ class DecodePool:
                         reply = p.stdout.readline()
                         if not reply:
                             raise RuntimeError("decode worker exited")
-                        replies.append(json.loads(reply))
+                        replies.append(reply.rstrip("\n").split("\t"))
                 fut.set_result(replies)
             except Exception as e:  # noqa: BLE001
                 fut.set_exception(e)
@@ -159,7 +164,7 @@ class DecodePool:
         released = 0
         if self._closed:
             return 0
-        msg = json.dumps(["drop"] + list(files)) + "\n"
+        msg = "J" + json.dumps(["drop"] + list(files)) + "\n"
         for p, lock in zip(self._procs, self._locks):
             try:
                 with lock:
@@ -167,7 +172,7 @@ class DecodePool:
                     p.stdin.flush()
                     reply = p.stdout.readline()
                 if reply:
-                    released += int(json.loads(reply)[1])
+                    released += int(reply.split("\t")[1])
             except (OSError, ValueError, IndexError):
                 pass
         return released
@@ -185,7 +190,10 @@ class DecodePool:
             for i in range(c0, min(c0 + chunk, len(paths))):
                 pi, pg = paths[i]
                 ro = i * slots.stride
-                lines.append(json.dumps([pi, pg, slots.files[slot], ro, slots.rgb_cap, ro + slots.rgb_cap, slots.gt_cap]) + "\n")
+                if _PLAIN(pi) and (pg is None or (_PLAIN(pg) and pg != "-")):
+                    lines.append(f"{pi}\t{pg or '-'}\t{slots.files[slot]}\t{ro}\t{slots.rgb_cap}\t{ro + slots.rgb_cap}\t{slots.gt_cap}\n")
+                else:
+                    lines.append("J" + json.dumps([pi, pg, slots.files[slot], ro, slots.rgb_cap, ro + slots.rgb_cap, slots.gt_cap]) + "\n")
             f: Future = Future()
             self._q.put((lines, f))
             futs.append(f)

@@ -125,6 +125,7 @@ def test_workers_keep_no_mapping_of_a_finished_loader_and_paths_may_hold_any_cha
     workers used to keep those unlinked segments mapped for good (tmpfs pages + address space, +7.5 MB per loader).  Now the
     loader tells them to drop the ring (DecodePool.drop), and a worker also unmaps vanished segments when it meets a new one.
     Requests are JSON lines: a path with a tab and a newline decodes like any other.  ``list(loader)`` holds owned arrays."""
+    import os
     import shutil
     from selfmask_amd import datasets as DS
     from selfmask_amd.decode_pool import shared_pool
@@ -134,6 +135,10 @@ def test_workers_keep_no_mapping_of_a_finished_loader_and_paths_may_hold_any_cha
     odd = str(tmp_path / "odd\tname\nwith breaks.jpg")
     shutil.copy(ds.p_imgs[0], odd)
     ds.p_imgs[0] = odd
+    os.makedirs(tmp_path / "J[x", exist_ok=True)
+    for i, name in ((1, str(tmp_path / "Jpeg_like_name.jpg")), (2, str(tmp_path / "J[x" / "y.jpg"))):  # names that start like a JSON request
+        shutil.copy(ds.p_imgs[i], name)
+        ds.p_imgs[i] = name
     pool = shared_pool(2)
 
     def deleted_maps():
