@@ -19,6 +19,9 @@ def __getattr__(name):  # lazy: `python -m selfmask_amd.evaluator` must not find
     if name == "Evaluator":
         from .evaluator import Evaluator
         return Evaluator
+    if name == "MaskGenerator":
+        from .mask_generator import MaskGenerator
+        return MaskGenerator
     if name == "SelfMaskInference":
         from .inference import SelfMaskInference
         return SelfMaskInference

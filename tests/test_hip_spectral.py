@@ -134,3 +134,41 @@ def test_extract_candidates_spectral_then_vote(patch, size):
     for b in range(3):
         ref_b = torch.cat([VT.labels_to_masks(lab[b, i].reshape(2 * gh, 2 * gw), k, patch // 2, H, W) for i, k in enumerate((2, 3))])
         assert torch.equal(got[b], ref_b)
+
+
+def test_mask_generator_files_to_encoded_masks(tmp_path):
+    """MaskGenerator(...)(p_images) (mask_generator.pyc@L232-252): JPEG files of two sizes -> {file name: RLE of the voted mask}; every
+    file's result equals the oracle chain (CPU decode + normalise, device tokens, restated clustering / one-hot / vote) on that file."""
+    from PIL import Image
+    from selfmask_amd.datasets import MEAN, STD, synthetic_scene
+    from selfmask_amd.mask_generator import MaskGenerator, rle_decode
+    patch = 16
+    m = MaskFormer(n_queries=20, patch_size=patch, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(31, "soft", patch_size=patch), strict=True)
+    m = m.to(DEV)
+    rng = np.random.Generator(np.random.PCG64(4))
+    paths = []
+    for i, (h, w) in enumerate([(96, 128), (100, 120), (96, 128), (96, 128)]):
+        img, _ = synthetic_scene(rng, h, w)
+        p = str(tmp_path / f"img_{i}.png")  # PNG: the file holds exactly these pixels
+        Image.fromarray(img).save(p)
+        paths.append(p)
+    gen = MaskGenerator(network=m, device=DEV, batch_size=2)
+    out = gen(paths)
+    assert sorted(out) == [f"img_{i}.png" for i in range(4)]
+    for p in paths:
+        name = p.split("/")[-1]
+        got = rle_decode(out[name])
+        rgb = np.asarray(Image.open(p).convert("RGB"), np.float32) / np.float32(255.0)
+        x = torch.from_numpy(np.ascontiguousarray(((rgb - np.asarray(MEAN, np.float32)) / np.asarray(STD, np.float32)).transpose(2, 0, 1)))[None]
+        H, W = x.shape[-2:]
+        assert got.shape == (H, W)
+        tok = m(x.to(DEV), encoder_only=True)["patch_tokens"].cpu()
+        gh, gw = tok.shape[1:3]
+        feats = CO.upsample_aligned(tok.reshape(1, gh * gw, 384), gh, gw, 2)[0].reshape(-1, 384).numpy()
+        ref_labels, _, _, _ = CO.spectral_cluster(feats, (2, 3, 4), 10)
+        ref = torch.cat([CO.to_one_hot_masks(torch.from_numpy(ref_labels[k]).reshape(2 * gh, 2 * gw), k, patch // 2, H, W) for k in (2, 3, 4)])
+        ref_mask = V.vote_mask(ref)[0].numpy()
+        assert (got != ref_mask).mean() <= 5e-3, name
+    raw = gen(paths[:1], encode=False)
+    assert np.array_equal(raw["img_0.png"], rle_decode(out["img_0.png"]))
