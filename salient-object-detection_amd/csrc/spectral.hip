@@ -112,16 +112,21 @@ __global__ __launch_bounds__(256) void knn_select_kernel(const float* __restrict
 // lists t (integer atomics: the RESULT does not depend on their order), then one wave per row turns the set bits into a list.
 // A pair listed from both ends appears twice, once per direction: W_ij = (C_ij + C_ji) / 2 is "every entry weighs 1/2", and
 // d_t = (m + in_degree_t) / 2.
+constexpr int SP_COL_SLACK = 32;  // ints readable past the last list (the gathers fetch 24 entries of a list whatever its length)
+__host__ __device__ inline int64_t sp_col_capacity(int n, int m) { return (int64_t)2 * n * m + 4 * (int64_t)n + SP_COL_SLACK; }
+
 __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __restrict__ idx_all, int n, int m,
                                                                unsigned long long* __restrict__ bits_all, int* __restrict__ ptr_all,
-                                                               int* __restrict__ col_all, double* __restrict__ isd_all) {
+                                                               int* __restrict__ len_all, int* __restrict__ col_all,
+                                                               double* __restrict__ isd_all) {
     __shared__ int part[SP_THREADS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img = blockIdx.x;
     const int nw = (n + 63) / 64;
     const int* idx = idx_all + (int64_t)img * n * m;
     unsigned long long* bits = bits_all + (int64_t)img * n * nw;
     int* ptr = ptr_all + (int64_t)img * (n + 1);
-    int* col = col_all + (int64_t)img * 2 * n * m;
+    int* len = len_all + (int64_t)img * n;
+    int* col = col_all + (int64_t)img * sp_col_capacity(n, m);
     double* isd = isd_all + (int64_t)img * n;
     for (int64_t e = tid; e < (int64_t)n * m; e += SP_THREADS) {
         const int i = (int)(e / m), t = idx[e];
@@ -129,15 +134,15 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
     }
     __threadfence();
     __syncthreads();
-    // list length (m + in-degree) of this thread's contiguous chunk of rows, exclusive scan over the workgroup
+    // list length (m + in-degree, rounded up to 4 entries) of this thread's contiguous chunk of rows, exclusive scan over the workgroup
     const int per = (n + SP_THREADS - 1) / SP_THREADS, r0 = tid * per, r1 = min(n, r0 + per);
     int mine = 0;
     for (int r = r0; r < r1; ++r) {
         int c = 0;
         for (int w = 0; w < nw; ++w) c += __popcll(__hip_atomic_load(&bits[(int64_t)r * nw + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        ptr[r + 1] = m + c;  // length for now
+        len[r] = m + c;
         isd[r] = 1.0 / sqrt(0.5 * (double)(m + c));
-        mine += m + c;
+        mine += (m + c + 3) & ~3;  // every list starts on a 16-B boundary: the gathers fetch four indices per load
     }
     part[tid] = mine;
     __syncthreads();
@@ -159,9 +164,8 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
     {
         int run = part[tid];
         for (int r = r0; r < r1; ++r) {
-            const int c = ptr[r + 1];
             ptr[r] = run;
-            run += c;
+            run += (len[r] + 3) & ~3;
         }
         if (r1 == n && r0 < n) ptr[n] = run;
     }
@@ -193,48 +197,71 @@ __global__ __launch_bounds__(SP_THREADS) void knn_graph_kernel(const int* __rest
 // ---------------------------------------------------------------------------------------------------------------------------
 // 4. eigen-solver
 struct SpGraph {
-    const int* ptr;     // (n + 1) adjacency list starts
-    const int* col;     // 2 n m entries, each of weight 1/2
+    const int* ptr;     // (n + 1) adjacency list starts, multiples of 4
+    const int* len;     // (n) list lengths (m + in-degree)
+    const int* col;     // the lists, each entry of weight 1/2
     const double* isd;  // 1 / sqrt(d)
     int n;
 };
 
-// sum over the adjacency list [s, t) of ylds[nb * CG + jj], in list order.  The neighbour indices are the only global loads left
-// on this path: the first 24 of a list are requested together from clamped addresses (a list is m + in-degree >= m long; the
-// padding re-reads its last entry and adds 0), longer lists (hubs) finish in a plain loop.
-template <int CG>
-__device__ __forceinline__ double sp_gather_lds(const int* __restrict__ col, int s, int t, const double* ylds, int jj) {
-    const int cnt = t - s;
-    int nb[24];
-#pragma unroll
-    for (int u = 0; u < 24; ++u) nb[u] = col[s + min(u, cnt - 1)];
-    double acc = 0.0;
-#pragma unroll
-    for (int u = 0; u < 24; ++u) {
-        const double y = ylds[nb[u] * CG + jj];
-        acc += u < cnt ? y : 0.0;
-    }
-    for (int e = s + 24; e < t; ++e) acc += ylds[col[e] * CG + jj];
-    return acc;
-}
-
 // One step of the Chebyshev recurrence on the scaled variables (see the kernel): Xw <- ((I - D^-1 W) Yr - c0 Yr) f1 - f2 Xw, the
-// gathered block Yr staged through the LDS in groups of CG columns (n * CG doubles fit the workgroup's share of the 160 KB)
-template <int CG>
+// gathered block Yr staged through the LDS in groups of CG columns (n * CG doubles fit the workgroup's share of the 160 KB).
+// An item = (row i, column jj): sum over the row's adjacency list (start: a multiple of 4, cnt entries) of ylds[nb * CG + jj] in list
+// order.  The neighbour indices are the only global loads on this path and the loop is software-pipelined by hand around them: the
+// list start / length / scale of the item after next and the first 24 indices of the next item (six 16-B loads) are in flight while
+// the current item reads the LDS - all 24 reads first, ONE wait, then the sum.  (Left to the compiler every neighbour was a read ->
+// s_waitcnt lgkmcnt(0) -> add round trip, and an item began with two dependent global latencies: 80 k cycles per step at n = 784,
+// scripts/spectral_stamps.py.)  Entries past cnt are read but add 0; longer lists (hubs) finish in a plain loop.
+template <int CG, bool LAST>
 __device__ __forceinline__ void sp_filter_step(const SpGraph& g, const double* __restrict__ Yr, double* __restrict__ Xw, double* ylds,
-                                               double c0, double f1, double f2, bool last) {
-    const int n = g.n;
+                                               double c0, double f1, double f2) {
+    const int total = g.n * CG, zero_row = g.n;  // ylds holds n + 1 rows: the last one is zeros, the target of a list's padding
+    struct Meta { int s, cnt; double w; };
+    auto meta = [&](int t) {
+        Meta m = {0, 0, 1.0};
+        if (t < total) { const int i = t / CG; m.s = g.ptr[i]; m.cnt = g.len[i]; m.w = g.isd[i]; }
+        return m;
+    };
+    struct Idx { int4 v[6]; };
+    auto indices = [&](const Meta& m) {
+        Idx x;
+        const int4* p = reinterpret_cast<const int4*>(g.col + m.s);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x.v[k] = p[k];  // (an item past the end reads the first list: valid memory, never used)
+        return x;
+    };
 #pragma unroll 1
     for (int c = 0; c < SP_B; c += CG) {
-        for (int t = threadIdx.x; t < n * CG; t += SP_THREADS) ylds[t] = Yr[(t / CG) * SP_B + c + t % CG];
+        for (int t = threadIdx.x; t < total; t += SP_THREADS) ylds[t] = Yr[(t / CG) * SP_B + c + t % CG];
+        if (threadIdx.x < CG) ylds[total + threadIdx.x] = 0.0;
+        int t = threadIdx.x;
+        Meta m_cur = meta(t), m_next = meta(t + SP_THREADS);
+        Idx x_cur = indices(m_cur);
         __syncthreads();
-#pragma unroll 2
-        for (int t = threadIdx.x; t < n * CG; t += SP_THREADS) {
-            const int i = t / CG, jj = t % CG;
-            const double w = g.isd[i], y = ylds[t];
-            const double ly = y - (0.5 * w * w) * sp_gather_lds<CG>(g.col, g.ptr[i], g.ptr[i + 1], ylds, jj);
-            const double xn = (ly - c0 * y) * f1 - f2 * Xw[i * SP_B + c + jj];
-            Xw[i * SP_B + c + jj] = last ? xn / w : xn;  // back to the symmetric variables on the way out
+#pragma unroll 1
+        for (; t < total; t += SP_THREADS) {
+            const Idx x_next = indices(m_next);                 // next item's indices: its list start arrived an iteration ago
+            const Meta m_after = meta(t + 2 * SP_THREADS);      // and the list start of the one after
+            const int i = t / CG, jj = t % CG, cnt = m_cur.cnt;
+            int nb[24];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { nb[4 * k] = x_cur.v[k].x; nb[4 * k + 1] = x_cur.v[k].y; nb[4 * k + 2] = x_cur.v[k].z; nb[4 * k + 3] = x_cur.v[k].w; }
+            double y[24];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) y[u] = ylds[(u < cnt ? nb[u] : zero_row) * CG + jj];  // past the list: + 0.0 (exact)
+            const double yo = ylds[t], xo = Xw[i * SP_B + c + jj];
+            asm volatile("" ::: "memory");  // every load above is issued before the first add below
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < 24; ++u) acc += y[u];
+            for (int e = 24; e < cnt; ++e) acc += ylds[g.col[m_cur.s + e] * CG + jj];
+            const double w = m_cur.w;
+            const double ly = yo - (0.5 * w * w) * acc;
+            const double xn = (ly - c0 * yo) * f1 - f2 * xo;
+            Xw[i * SP_B + c + jj] = LAST ? xn / w : xn;  // back to the symmetric variables on the way out (last step only)
+            m_cur = m_next;
+            m_next = m_after;
+            x_cur = x_next;
         }
         __syncthreads();
     }
@@ -264,7 +291,7 @@ __device__ __forceinline__ void sp_apply_sym(const SpGraph& g, const double* __r
 #pragma unroll 2
     for (int t = threadIdx.x; t < g.n * SP_B; t += SP_THREADS) {
         const int i = t / SP_B, j = t % SP_B;
-        Out[t] = In[t] - 0.5 * g.isd[i] * sp_gather2(g.col, g.ptr[i], g.ptr[i + 1], g.isd, In, j);
+        Out[t] = In[t] - 0.5 * g.isd[i] * sp_gather2(g.col, g.ptr[i], g.ptr[i] + g.len[i], g.isd, In, j);
     }
 }
 
@@ -490,22 +517,32 @@ __device__ __forceinline__ double sp_init_value(int i, int j) {  // splitmix64 o
 }
 
 template <int CG>
-__global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ ptr_all, const int* __restrict__ col_all,
+__global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ ptr_all, const int* __restrict__ len_all,
+                                                                    const int* __restrict__ col_all,
                                                                     const double* __restrict__ isd_all, int n, int m, int kw, int degree,
                                                                     int max_outer, double tol, double* __restrict__ blocks_all,
                                                                     double* __restrict__ eig_all, double* __restrict__ emb_all,
                                                                     double* __restrict__ res_all, int* __restrict__ info_all) {
     __shared__ SpShared sh;
-    extern __shared__ __attribute__((aligned(16))) double ylds[];  // n * CG doubles: the gathered block of a filter step
+    extern __shared__ __attribute__((aligned(16))) double ylds[];  // (n + 1) * CG doubles: the gathered block of a filter step + a zero row
     const int tid = threadIdx.x, img = blockIdx.x;
     SpGraph g;
     g.ptr = ptr_all + (int64_t)img * (n + 1);
-    g.col = col_all + (int64_t)img * 2 * n * m;
+    g.len = len_all + (int64_t)img * n;
+    g.col = col_all + (int64_t)img * sp_col_capacity(n, m);
     g.isd = isd_all + (int64_t)img * n;
     g.n = n;
     double* U = blocks_all + (int64_t)img * 2 * n * SP_B;  // the Ritz vectors
     double* V = U + (int64_t)n * SP_B;                     // L U
     int guard = 0, matvecs = 0, outer = 0, converged = 0;
+#ifdef SM_SPECTRAL_STAMPS  // experiment build: shader-clock cycles per phase instead of the residuals (scripts/spectral_stamps.py)
+    unsigned long long t_filter = 0, t_chol = 0, t_apply = 0, t_rr = 0, t0 = 0;
+#define SP_T0 t0 = __builtin_readcyclecounter()
+#define SP_T(acc) acc += __builtin_readcyclecounter() - t0
+#else
+#define SP_T0
+#define SP_T(acc)
+#endif
 
     for (int t = tid; t < n * SP_B; t += SP_THREADS) {
         const int i = t / SP_B, j = t % SP_B;
@@ -514,12 +551,18 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
     __syncthreads();
     for (outer = 0;; ++outer) {
         // U holds the block to work on (the start block, then the filtered one): orthonormalise, V = L U, Rayleigh-Ritz
+        SP_T0;
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) chol_qr_pass(U, n, pass == 0 ? 1e-11 : 0.0, sh, &guard);  // shifted Cholesky QR, three passes
+        SP_T(t_chol);
+        SP_T0;
         sp_apply_sym(g, U, V);
         ++matvecs;
         __syncthreads();
+        SP_T(t_apply);
+        SP_T0;
         rayleigh_ritz(U, V, n, sh);
+        SP_T(t_rr);
         double worst = 0.0;
         for (int j = 0; j < kw; ++j) worst = fmax(worst, sh.res[j]);
         if (worst <= tol) { converged = 1; break; }
@@ -534,6 +577,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         double sig = e / (0.0 - c0);
         const double tau = 2.0 / sig;
         __syncthreads();  // everyone has read sh.res / sh.th
+        SP_T0;
         double* X = U;
         double* Y = V;
         {
@@ -548,7 +592,8 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         for (int it = 2; it <= degree; ++it) {
             const double sn = 1.0 / (tau - sig);
             const double f1 = 2.0 * sn / e, f2 = sig * sn;
-            sp_filter_step<CG>(g, Y, X, ylds, c0, f1, f2, it == degree);
+            if (it == degree) sp_filter_step<CG, true>(g, Y, X, ylds, c0, f1, f2);
+            else sp_filter_step<CG, false>(g, Y, X, ylds, c0, f1, f2);
             ++matvecs;
             double* sw = X;
             X = Y;
@@ -557,6 +602,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         }
         U = Y;  // the filtered block
         V = X;
+        SP_T(t_filter);
     }
     // results: eigenvalues ascending, embedding rows v_i / sqrt(d_i), first kw columns
     double* emb = emb_all + (int64_t)img * n * kw;
@@ -568,6 +614,12 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         if (eig_all) eig_all[(int64_t)img * kw + tid] = sh.th[tid];
         if (res_all) res_all[(int64_t)img * kw + tid] = sh.res[tid];
     }
+#ifdef SM_SPECTRAL_STAMPS
+    if (tid == 0 && res_all && kw >= 4) {
+        double* r = res_all + (int64_t)img * kw;
+        r[0] = (double)t_filter; r[1] = (double)t_chol; r[2] = (double)t_apply; r[3] = (double)t_rr;
+    }
+#endif
     if (tid == 0 && info_all) {
         int* info = info_all + (int64_t)img * 4;
         info[0] = outer;
@@ -715,7 +767,7 @@ __global__ __launch_bounds__(256) void gram_diag_kernel(const float* __restrict_
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct SpLayout {
-    size_t fs, gram, sq, idx, bits, inptr, incol, isd, blocks, emb, total;
+    size_t fs, gram, sq, idx, bits, inptr, inlen, incol, isd, blocks, emb, total;
 };
 static SpLayout sp_layout(int B, int n, int m, int kw) {
     SpLayout l;
@@ -727,7 +779,8 @@ static SpLayout sp_layout(int B, int n, int m, int kw) {
     l.idx = o;    o += al256((size_t)B * n * m * 4);
     l.bits = o;   o += al256((size_t)B * n * nw * 8);
     l.inptr = o;  o += al256((size_t)B * (n + 1) * 4);
-    l.incol = o;  o += al256((size_t)B * 2 * n * m * 4);
+    l.inlen = o;  o += al256((size_t)B * n * 4);
+    l.incol = o;  o += al256((size_t)B * sp_col_capacity(n, m) * 4);
     l.isd = o;    o += al256((size_t)B * n * 8);
     l.blocks = o; o += al256((size_t)B * 2 * n * SP_B * 8);
     l.emb = o;    o += al256((size_t)B * n * kw * 8);
@@ -794,20 +847,22 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
         return SM_ELAUNCH;
     }
     hipLaunchKernelGGL(sm::knn_graph_kernel, dim3(B), dim3(sm::SP_THREADS), 0, st, idx, n, m, (unsigned long long*)(ws + l.bits),
-                       (int*)(ws + l.inptr), (int*)(ws + l.incol), (double*)(ws + l.isd));
+                       (int*)(ws + l.inptr), (int*)(ws + l.inlen), (int*)(ws + l.incol), (double*)(ws + l.isd));
     const int degree = a->degree > 1 ? a->degree : 24, max_outer = a->max_outer > 0 ? a->max_outer : 60;
     const double tol = a->tol > 0.0 ? a->tol : 1e-9;
     {
-        // columns staged per filter pass: as many as fit 144 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950)
-        const int cg = (size_t)n * 8 * 8 <= 147456 ? 8 : (size_t)n * 4 * 8 <= 147456 ? 4 : 2;
-        const size_t lds = (size_t)n * cg * 8;
+        // columns staged per filter pass: as many as fit 150 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950)
+        constexpr size_t LDS_MAX = 153600;
+        const int cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
+        const size_t lds = (size_t)(n + 1) * cg * 8;
         auto launch = [&](auto kern) {
             static bool once = false;  // per instantiation (the lambda is instantiated per kernel type)
             if (!once) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
                 once = true;
             }
-            hipLaunchKernelGGL(kern, dim3(B), dim3(sm::SP_THREADS), lds, st, (const int*)(ws + l.inptr), (const int*)(ws + l.incol),
+            hipLaunchKernelGGL(kern, dim3(B), dim3(sm::SP_THREADS), lds, st, (const int*)(ws + l.inptr), (const int*)(ws + l.inlen),
+                               (const int*)(ws + l.incol),
                                (const double*)(ws + l.isd), n, m, kw, degree, max_outer, tol, (double*)(ws + l.blocks), a->eigenvalues, emb,
                                a->residuals, a->info);
         };
