@@ -274,14 +274,22 @@ __global__ void bs_splat_kernel(const double* __restrict__ target, double conf, 
 }
 
 // ---- bistochastize + PCG: one launch per sweep / per phase, BS_SOLVE_BLOCKS workgroups per image -----------------------------
+// (Both gathers below fetch ALL neighbour indices, then ALL neighbour values from clamped addresses, and only then add - with the
+// reference's skip of an absent neighbour as a select.  Written as `if (j >= 0) t += x[j]` every neighbour was its own basic block with a
+// full s_waitcnt: ten dependent memory round trips per vertex.)
 __device__ __forceinline__ double bs_blur(const double* __restrict__ x, const int* __restrict__ nbr, int maxV, int v) {
+    int j[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) j[k] = nbr[(size_t)k * maxV + v];
+    double xv[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) xv[k] = x[j[k] >= 0 ? j[k] : v];
     double out = 10.0 * x[v];  // 2 * dim * x  (:97)
 #pragma unroll
     for (int k = 0; k < 5; ++k) {  // out = out + blur_k.dot(x): row entries in ascending column order
         double t = 0.0;
-        const int lo = nbr[(size_t)(2 * k) * maxV + v], hi = nbr[(size_t)(2 * k + 1) * maxV + v];
-        if (lo >= 0) t = t + x[lo];
-        if (hi >= 0) t = t + x[hi];
+        t = j[2 * k] >= 0 ? t + xv[2 * k] : t;
+        t = j[2 * k + 1] >= 0 ? t + xv[2 * k + 1] : t;
         out = out + t;
     }
     return out;
@@ -293,18 +301,19 @@ __device__ __forceinline__ double bs_blur(const double* __restrict__ x, const in
 // per product) so that a mat-vec gathers p[j] only.
 __device__ __forceinline__ double bs_matvec(const double* __restrict__ p, const double* __restrict__ coef,
                                             const double* __restrict__ diag, const int* __restrict__ nbr, int maxV, int v) {
+    int j[10];
+    double c[10], pj[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { j[k] = nbr[(size_t)k * maxV + v]; c[k] = coef[(size_t)k * maxV + v]; }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) pj[k] = p[j[k] >= 0 ? j[k] : v];
+    const double dv = diag[v] * p[v];
     double out = 0.0;
 #pragma unroll
-    for (int k = 4; k >= 0; --k) {
-        const int j = nbr[(size_t)(2 * k) * maxV + v];
-        if (j >= 0) out = out + coef[(size_t)(2 * k) * maxV + v] * p[j];
-    }
-    out = out + diag[v] * p[v];
+    for (int k = 4; k >= 0; --k) out = j[2 * k] >= 0 ? out + c[2 * k] * pj[2 * k] : out;
+    out = out + dv;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int j = nbr[(size_t)(2 * k + 1) * maxV + v];
-        if (j >= 0) out = out + coef[(size_t)(2 * k + 1) * maxV + v] * p[j];
-    }
+    for (int k = 0; k < 5; ++k) out = j[2 * k + 1] >= 0 ? out + c[2 * k + 1] * pj[2 * k + 1] : out;
     return out;
 }
 
@@ -371,7 +380,8 @@ __global__ __launch_bounds__(BS_SOLVE_THREADS) void bs_pcg_setup_kernel(BsWs w, 
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
             const int j = w.nbr[(size_t)k * maxV + v];
-            w.coef[(size_t)k * maxV + v] = j >= 0 ? -(lam * (nv * n[j])) : 0.0;
+            const double nj = n[j >= 0 ? j : v];
+            w.coef[(size_t)k * maxV + v] = j >= 0 ? -(lam * (nv * nj)) : 0.0;
         }
     }
     bs_store_partial(bb, w.part, BS_P_BB);

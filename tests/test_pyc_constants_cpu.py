@@ -85,3 +85,32 @@ def test_mask_generator_defaults_thresholds_and_kwargs(pins):
     assert "0.05 * H * W" in hip and "0.95 * H * W" in hip and "1e-7f" in hip  # the literals the kernels compile in
     main = fn(pins, "mask_generator", "<module>")["consts"]
     assert "spectral" in main and "k-means" in main and [2, 3, 4] in main and 16 in main
+
+
+def _in_order(names, *wanted):
+    pos = [names.index(w) for w in wanted]
+    return pos == sorted(pos)
+
+
+def test_first_use_order_of_the_callers_names(pins):
+    """`co_names` lists a function's global / attribute names in order of FIRST USE: a static trace of the order of work.  The mirror's
+    order of work (evaluator.py, voting.py, mask_generator.py) is asserted against it."""
+    call = fn(pins, "evaluator", "<module>.Evaluator.__call__")["names"]
+    assert _in_order(call, "_init_meters", "get_dataset", "get_dataloader", "next", "_forward", "interpolate", "_get_upper_bound_mask",
+                     "argsort", "_update_meters", "set_description", "makedirs", "einsum", "_visualize", "open", "write", "close")
+    upd = fn(pins, "evaluator", "<module>.Evaluator._update_meters")["names"]
+    # metrics computed first, meters updated in the order iou, f_score, f_max, f_mean, s_measure, mae, pixel_acc - then the same for *_ub
+    assert _in_order(upd, "compute_iou", "FMeasure", "compute_mae", "compute_pixel_accuracy", "iou", "update", "f_score", "f_max", "f_mean",
+                     "s_measure", "SMeasure", "mae", "pixel_acc", "iou_ub", "f_score_ub", "f_max_ub", "f_mean_ub", "s_measure_ub", "mae_ub",
+                     "pixel_acc_ub")
+    ext = fn(pins, "mask_generator", "<module>.MaskGenerator.extract_candidate_masks")["names"]
+    assert _in_order(ext, "feature_types", "get_model", "DataLoader", "CustomDataset", "pad_input_image", "encoder", "interpolate",
+                     "cluster_sizes", "clusterer", "to_one_hot", "concatenate")
+    vote = fn(pins, "mask_generator", "<module>.MaskGenerator.vote_mask")["names"]
+    assert _in_order(vote, "mask_to_bbox", "filter_masks", "logical_and", "sum", "logical_or", "argsort", "item")
+    gen = fn(pins, "mask_generator", "<module>.MaskGenerator.__call__")["names"]
+    assert _in_order(gen, "extract_candidate_masks", "vote_mask", "encode", "asfortranarray")
+    # the written line follows the header's column order: the avg values of the seven meters, then the seven *_ub ones
+    tail = call[call.index("f_score"):]
+    for k in ("f_score", "f_max", "mae", "s_measure", "iou", "pixel_acc"):
+        assert k in tail and k + "_ub" in tail
