@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4: 64 x 64 tiles behind a ring of six for launches of at most one round (variant 49) against the ring of three (variant 44)
+# round 4: A/B harness for the two small-launch experiments (ring-of-six 64 x 64 GEMM, then attention with all key chunks staged at once): the product library against an experiment build that disables the change; both changes lost and live in the tuning build now (profiles/r04_deep_ring_ab.log, r04_attn_all_ab.log)
 set -o pipefail
 mkdir -p gpurun_out/r4
 timeout -k 10 900 python -m pytest tests/test_hip_ops.py tests/test_hip_forward.py tests/test_hip_inference.py -x -q 2>&1 | tee gpurun_out/r4/attn_all_tests.log | tail -5
