@@ -80,6 +80,34 @@ def time_forward_kernels(model, x, forwards=3):
     return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ms_per_forward"]))
 
 
+def time_taps(fn, reps=3):
+    """The same event taps around the launch sequences of the clusterer / the bilateral solver (per phase; one-launch phases carry
+    their kernel's name): {name: {"ms_per_call", "launch_pairs_per_call", "algorithmic_gbs" (when the phase states its bytes)}}."""
+    from selfmask_amd import _native as Nn
+    lib = Nn.load()
+    fn()
+    torch.cuda.synchronize()
+    Nn.check(lib.sm_forward_timing(1), "sm_forward_timing")
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    buf = (Nn.KernelTime * 32)()
+    n = lib.sm_forward_timing_read(buf, 32)
+    lib.sm_forward_timing(0)
+    if n < 0:
+        raise RuntimeError(lib.sm_last_error().decode())
+    out = {}
+    for e in buf[:n]:
+        d = {"ms_per_call": round(e.total_us / reps * 1e-3, 4), "event_pairs_per_call": e.launches / reps}
+        if e.bytes > 0 and e.total_us > 0:
+            d["algorithmic_bytes_per_call"] = round(e.bytes / reps)
+            d["algorithmic_gbs"] = round(e.bytes / (e.total_us * 1e-6) / 1e9, 2)
+        if e.flops > 0 and e.total_us > 0:
+            d["achieved_tflops"] = round(e.flops / (e.total_us * 1e-6) / 1e12, 2)
+        out[e.name.decode()] = d
+    return dict(sorted(out.items(), key=lambda kv: -kv[1]["ms_per_call"]))
+
+
 def source_hash() -> str:
     """Hash of the kernel sources: PMC measurements are only quoted for exactly the code they were taken on."""
     import glob
@@ -446,6 +474,7 @@ def refine_leg(dev, streams, P=16, S=384, B=32, steps=12, warmup=3, cpu=True):
     w.step = plain
     target, info = state["target"], state["info"].cpu().numpy()
     ms_solver = _event_ms(lambda: bilateral_solver_batch_device(u8, target), 5, dev)
+    phases = time_taps(lambda: bilateral_solver_batch_device(u8, target))
     V, iters = info[:, 0].astype(np.float64), info[:, 1].astype(np.float64)
     npx = float(S * S)
     nnz = 6.0 * V  # nnz ~ V + sum of the blur matrices' entries ~ 6 V
@@ -459,6 +488,7 @@ def refine_leg(dev, streams, P=16, S=384, B=32, steps=12, warmup=3, cpu=True):
                             "images_per_sec": round(B / ms_solver * 1e3, 1), "vertices_mean": round(float(V.mean()), 1),
                             "pcg_iterations_mean": round(float(iters.mean()), 2),
                             "algorithmic_bytes_per_image": round(float(alg.mean())),
+                            "phases_ms_per_batch": phases,
                             "roofline": {"bound": "hbm", "achieved": round(float(alg.sum()) / (ms_solver * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                                          "unit": "GB/s", "frac": round(float(alg.sum()) / (ms_solver * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                          "note": "latency / irregularity-bound by design (SURVEY.md 8d): a few thousand lattice vertices per "
@@ -480,27 +510,41 @@ def refine_leg(dev, streams, P=16, S=384, B=32, steps=12, warmup=3, cpu=True):
     return res
 
 
-def pseudo_masks_leg(dev, streams, P=16, S=224, B=16, steps=10, warmup=3, cpu=True):
+def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=True):
     """BASELINE.json configs[4], DINO branch: encoder -> bilinear x2 -> spectral clustering for k = 2, 3, 4 (ONE eigen-solve per
-    image) -> 9 candidate masks -> vote (mask_generator.pyc@L136-230).  images/s of the whole chain, the clusterer alone, and the
-    CPU restatement (oracle/cluster_oracle.py: dense eigh) beside it.  The clusterer is parity UNPINNED (absent from the reference)."""
+    image) -> 9 candidate masks -> vote (mask_generator.pyc@L136-230), as MaskGenerator.__call__ runs it: `streams` batches in flight,
+    each batch's votes read back (one copy) `streams` batches later.  images/s of the whole chain, the same on one stream, the
+    clusterer alone, and the CPU restatement (oracle/cluster_oracle.py: dense eigh) beside it.  The clusterer is parity UNPINNED
+    (absent from the reference)."""
     import numpy as np
+    from collections import deque
     from selfmask_amd import voting as VT
-    w = Workload(dev, P, S, B, streams=1, forward_only=True)
+    w = Workload(dev, P, S, B, streams=streams, forward_only=True, graph=False)
     model, x = w.model, w.x
 
-    def chain():
-        cands = VT.extract_candidate_masks(model, x)  # (B, 9, S, S)
-        return [r[1] for r in VT.vote_mask_batch(cands)]
+    def run(n_steps, ring):
+        pending = deque()
+        ring.fork()
+        for _ in range(n_steps):
+            with ring.next():
+                pending.append(VT.vote_mask_batch_async(VT.extract_candidate_masks(model, x), winners=True))  # (B, 9, S, S) -> votes
+            if len(pending) >= len(ring.streams):
+                pending.popleft().winners_host()
+        while pending:
+            pending.popleft().winners_host()
+        ring.join()
 
-    for _ in range(warmup):
-        chain()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        chain()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def timed(ring):
+        run(warmup + len(ring.streams), ring)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps, ring)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    from selfmask_amd.streams import StreamRing
+    dt1 = timed(StreamRing(dev, 1))
+    dt = timed(w.ring) if len(w.ring.streams) > 1 else dt1
     tok = model(x, encoder_only=True)["patch_tokens"]
     gh, gw = tok.shape[1:3]
     feats = VT.upsample_tokens_aligned(tok.reshape(B, gh * gw, 384), gh, gw, 2).reshape(B, 4 * gh * gw, 384)
@@ -510,14 +554,29 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=16, steps=10, warmup=3, cpu=Tr
     _, det = VT.spectral_cluster(feats, (2, 3, 4), return_details=True)
     info = det["info"].cpu().numpy()
     n = 4 * gh * gw
+    phases = time_taps(lambda: VT.spectral_cluster(feats, (2, 3, 4)))
+    dom_name = next(iter(phases))
+    dom = dict(phases[dom_name])
+    if dom_name.startswith("spectral_embed_kernel"):
+        # one launch = B workgroups (one per image), each running its image's whole eigen-solve out of LDS; algorithmic bytes of ONE
+        # block mat-vec = the (n x 8) fp64 block read + written + the 2 n m adjacency entries (index + weight folded: 4 B)
+        mv = float(info[:, 1].sum())
+        per_mv = 2.0 * n * 8 * 8 + 2.0 * n * 10 * 4
+        dom.update({"kernel": dom_name, "bound": "latency: one workgroup (8 waves) per image, dependent sparse mat-vecs served from LDS - not an "
+                                                 "HBM or MFMA roofline kernel",
+                    "block_matvecs_per_launch": mv, "lds_bytes_per_block_matvec": per_mv,
+                    "achieved_lds_gbs": round(mv * per_mv / (dom["ms_per_call"] * 1e-3) / 1e9, 1),
+                    "us_per_block_matvec_per_image": round(dom["ms_per_call"] * 1e3 / (mv / B), 3)})
     res = {"workload": f"ViT-S/{P} {S}x{S}, batch={B}: encoder -> bilinear x2 ({n} points x 384) -> spectral clustering k=2,3,4 (10-NN graph, "
                        f"normalised Laplacian, 4 eigenvectors, k-means) -> 9 candidates -> vote",
            "value": round(steps * B / dt, 1), "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 3),
+           "batches_in_flight": len(w.ring.streams), "one_stream_images_per_sec": round(steps * B / dt1, 1),
            "encoder_ms_per_batch": round(ms_enc, 3), "spectral_cluster_ms_per_batch": round(ms_spec, 3),
            "spectral_cluster_images_per_sec": round(B / ms_spec * 1e3, 1),
            "kmeans_option_ms_per_batch": round(ms_km, 3),
            "eigensolver": {"outer_iterations_mean": round(float(info[:, 0].mean()), 2), "block_matvecs_mean": round(float(info[:, 1].mean()), 1),
                            "converged": int(info[:, 2].sum()), "of": B, "max_residual": float(det["residuals"].max())},
+           "clusterer_phases_ms_per_batch": phases, "dominant_kernel": dom,
            "parity": "UNPINNED: the reference's `clusterings` module is absent in every form; scikit-learn is the witness (tests)"}
     if cpu:
         from oracle import cluster_oracle as CO

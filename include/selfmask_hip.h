@@ -520,7 +520,9 @@ int sm_maskformer_forward(const sm_weights* w, const sm_forward_io* io, void* wo
  * While enabled, every GEMM / attention / LayerNorm launch of a forward is bracketed by two HIP events recorded on the
  * forward's own stream; sm_forward_timing_read waits for them and returns one entry per kernel family (GEMMs by their
  * workgroup tile, i.e. by kernel instantiation) summed over all forwards issued since the enable.  Diagnostic mode:
- * single caller thread, one stream at a time. */
+ * single caller thread, one stream at a time.  sm_spectral_cluster_f32 and sm_bilateral_solver_f64 are tapped too, per PHASE (several
+ * kernels between one event pair: names "spectral: ..." / "bilateral: ..."), except the eigen-solver and the embedding k-means,
+ * which are one launch each and carry their kernel names. */
 typedef struct {
     char name[64];     /* kernel (template instantiation) name as rocprofv3 prints it, without the argument list */
     int32_t launches;

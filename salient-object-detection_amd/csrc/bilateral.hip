@@ -657,6 +657,8 @@ extern "C" int sm_bilateral_solver_batch_f64(const sm_bilateral_args* a, int32_t
         return SM_ELAUNCH;
     }
     const int pb = (d.npx + 255) / 256;
+    const double npxd = (double)d.npx * n_images;
+    int tap = sm::tap_begin(stream, "bilateral: lattice build (bs_cells .. bs_splat)", 0.0, npxd * (3 + 5 * 4 + 8 + 8 + 4 * 16 + 2 * (8 + 4)));
     hipLaunchKernelGGL(sm::bs_cells_kernel, dim3(pb, 1, nz), dim3(256), 0, st, a->img, d, w, bb);
     const int nscan = (d.nwords + sm::BS_SCAN_WORDS - 1) / sm::BS_SCAN_WORDS;
     hipLaunchKernelGGL(sm::bs_scan_partial_kernel, dim3(nscan, 1, nz), dim3(256), 0, st, d, w, bb);
@@ -670,9 +672,13 @@ extern "C" int sm_bilateral_solver_batch_f64(const sm_bilateral_args* a, int32_t
     while (table < 2 * n) table *= 2;
     const size_t lds = ((n * 4 + 15) & ~15) + (size_t)n * 8 + (size_t)table * 8;
     hipLaunchKernelGGL(sm::bs_splat_kernel, dim3(d.NX, d.NY, nz), dim3(threads), lds, st, a->target, a->confidence, d, w, table, bb);
+    sm::tap_end(tap);
+    tap = sm::tap_begin(stream, "bilateral: bs_bisto_kernel x 11", 0.0, 0.0);
     {
         const dim3 sg(sm::BS_SOLVE_BLOCKS * 8, (nz + 7) / 8, 1), sb(sm::BS_SOLVE_THREADS);
         for (int it = -1; it < 10; ++it) hipLaunchKernelGGL(sm::bs_bisto_kernel, sg, sb, 0, st, w, maxV, it, bb);
+        sm::tap_end(tap);
+        tap = sm::tap_begin(stream, "bilateral: bs_pcg_* (setup, r0, maxiter x (p, q, x))", 0.0, 0.0);
         hipLaunchKernelGGL(sm::bs_pcg_setup_kernel, sg, sb, 0, st, w, maxV, a->lam, a->a_diag_min, bb);
         hipLaunchKernelGGL(sm::bs_pcg_r0_kernel, sg, sb, 0, st, w, maxV, a->lam, bb);
         for (int it = 0; it < a->cg_maxiter; ++it) {
@@ -681,6 +687,8 @@ extern "C" int sm_bilateral_solver_batch_f64(const sm_bilateral_args* a, int32_t
             hipLaunchKernelGGL(sm::bs_pcg_x_kernel, sg, sb, 0, st, w, it, a->cg_tol, bb);
         }
     }
+    sm::tap_end(tap);
+    tap = sm::tap_begin(stream, "bilateral: bs_slice + bs_post_*", 0.0, npxd * (8 + 8 + 1 + 2 * 4 * 6));
     hipLaunchKernelGGL(sm::bs_slice_kernel, dim3(pb, 1, nz), dim3(256), 0, st, d, w, a->soft, bb);
     {
         const dim3 pg(pb, 1, nz), pt(256);
@@ -698,6 +706,7 @@ extern "C" int sm_bilateral_solver_batch_f64(const sm_bilateral_args* a, int32_t
         hipLaunchKernelGGL(sm::bs_post_second_kernel, pg, pt, 0, st, d, w, bb);
         hipLaunchKernelGGL(sm::bs_post_out_kernel, pg, pt, 0, st, d, w, a->binary, bb);
     }
+    sm::tap_end(tap);
     if (a->info) hipLaunchKernelGGL(sm::bs_info_kernel, dim3(1, 1, nz), dim3(64), 0, st, w, a->info, bb);
     return sm::check_launch("sm_bilateral_solver_f64");
 }

@@ -287,6 +287,16 @@ __device__ __forceinline__ int m16_chunk_of_slot(int row, int p) { return p ^ m1
 // row of a 32x32 MFMA accumulator held in register v by lane-half h  (cdna_hip_programming.md section 3)
 __device__ __forceinline__ int acc_row(int v, int h) { return (v & 3) + 8 * (v >> 2) + 4 * h; }
 
+// timing taps of sm_forward_timing (forward.hip) for the library's other launch sequences: an event pair on `stream` around what runs
+// between tap_begin and tap_end while timing is on (handle -1 otherwise); read back, summed by name, with sm_forward_timing_read
+int tap_begin(void* stream, const char* name, double flops, double bytes);
+void tap_end(int handle);
+struct TapGuard {
+    int h;
+    TapGuard(void* stream, const char* name, double flops = 0.0, double bytes = 0.0) : h(tap_begin(stream, name, flops, bytes)) {}
+    ~TapGuard() { tap_end(h); }
+};
+
 }  // namespace sm
 
 const char* sm_qkv_attention_kernel_name(int mfma_terms);  // qkv_attention.hip: rocprofv3 name of the fused kernel that is launched

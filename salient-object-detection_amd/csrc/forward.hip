@@ -42,6 +42,20 @@ struct TapScope {
     }
 };
 
+// the same taps for the other launch sequences of the library (spectral.hip, bilateral.hip): begin returns a handle (-1 when timing is off)
+int tap_begin(void* stream, const char* name, double flops, double bytes) {
+    if (!g_timing) return -1;
+    Tap t;
+    t.st = (hipStream_t)stream; t.name = name; t.flops = flops; t.bytes = bytes;
+    if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return -1;
+    (void)hipEventRecord(t.e0, t.st);
+    g_taps.push_back(t);
+    return (int)g_taps.size() - 1;
+}
+void tap_end(int handle) {
+    if (handle >= 0 && handle < (int)g_taps.size()) (void)hipEventRecord(g_taps[handle].e1, g_taps[handle].st);
+}
+
 // Forwards this small (batch 1-2 at 224^2: serving) run the encoder's fc2 - K = 1536 on M/64 x 6 workgroups, a 48-step serial K
 // loop of ~20 us - split four ways along K; the LayerNorm launch that follows sums the slices (as the decoder's does).  Only on
 // the automatic path (sm_forward_io.attn_path = 0): the Evaluator pins a path so that rows do not depend on the batch size.

@@ -820,8 +820,12 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
     float* gram = (float*)(ws + l.gram);
     int* idx = a->knn ? a->knn : (int*)(ws + l.idx);
     double* emb = a->embedding ? a->embedding : (double*)(ws + l.emb);
-    int rc = sm_split_f16x2(a->features, SM_EMBED, fs, SM_EMBED, (int64_t)B * n, SM_EMBED, stream);
-    if (rc) return rc;
+    const double nd = (double)n, Bd = (double)B;
+    int rc;
+    {
+        sm::TapGuard tap(stream, "spectral: split_f16x2 + Gram gemm_f16x2", 2.0 * Bd * nd * nd * SM_EMBED, Bd * (nd * SM_EMBED * 8 + nd * nd * 4));
+        rc = sm_split_f16x2(a->features, SM_EMBED, fs, SM_EMBED, (int64_t)B * n, SM_EMBED, stream);
+        if (rc) return rc;
     sm_gemm_args g = {};
     g.A = fs;
     g.W = fs;
@@ -834,9 +838,11 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
     g.ldc = n;
     g.batch = B;
     g.epilogue = SM_EPI_BIAS;
-    rc = sm_gemm_f16x2(&g, 0, stream);
-    if (rc) return rc;
+        rc = sm_gemm_f16x2(&g, 0, stream);
+        if (rc) return rc;
+    }
     float* sq = (float*)(ws + l.sq);
+    int tap = sm::tap_begin(stream, "spectral: knn_select + knn_graph", 0.0, Bd * (nd * nd * 4 + 3.0 * nd * m * 4));
     hipLaunchKernelGGL(sm::gram_diag_kernel, dim3((unsigned)(((int64_t)B * n + 255) / 256)), dim3(256), 0, st, gram, n, (int64_t)B * n, sq);
     if (m <= 16)
         hipLaunchKernelGGL(sm::knn_select_kernel<16>, dim3((n + 3) / 4, B), dim3(256), 0, st, gram, sq, n, m, idx);
@@ -848,6 +854,7 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
     }
     hipLaunchKernelGGL(sm::knn_graph_kernel, dim3(B), dim3(sm::SP_THREADS), 0, st, idx, n, m, (unsigned long long*)(ws + l.bits),
                        (int*)(ws + l.inptr), (int*)(ws + l.inlen), (int*)(ws + l.incol), (double*)(ws + l.isd));
+    sm::tap_end(tap);
     const int degree = a->degree > 1 ? a->degree : 24, max_outer = a->max_outer > 0 ? a->max_outer : 60;
     const double tol = a->tol > 0.0 ? a->tol : 1e-9;
     {
@@ -866,10 +873,14 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
                                (const double*)(ws + l.isd), n, m, kw, degree, max_outer, tol, (double*)(ws + l.blocks), a->eigenvalues, emb,
                                a->residuals, a->info);
         };
+        // (bytes: what ONE block mat-vec moves - the block read and written + the adjacency lists; the count of mat-vecs is data-dependent)
+        sm::TapGuard tap2(stream, cg == 8 ? "spectral_embed_kernel<8>" : cg == 4 ? "spectral_embed_kernel<4>" : "spectral_embed_kernel<2>", 0.0,
+                          Bd * (2.0 * nd * 8 * 8 + 2.0 * nd * m * 4));
         if (cg == 8) launch(&sm::spectral_embed_kernel<8>);
         else if (cg == 4) launch(&sm::spectral_embed_kernel<4>);
         else launch(&sm::spectral_embed_kernel<2>);
     }
+    sm::TapGuard tap3(stream, "kmeans_embed_kernel", 0.0, Bd * nd * kw * 8 * a->n_sizes);
     hipLaunchKernelGGL(sm::kmeans_embed_kernel, dim3(a->n_sizes, B), dim3(sm::SP_THREADS), 0, st, emb, n, kw, sizes, a->n_sizes,
                        a->kmeans_max_iter > 0 ? a->kmeans_max_iter : 100, a->labels);
     return sm::check_launch("sm_spectral_cluster_f32");

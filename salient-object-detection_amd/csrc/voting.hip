@@ -7,7 +7,7 @@
 // The clustering that PRODUCES the candidates (faiss k-NN affinity + eigen-decomposition) is absent from the reference in
 // any form and stays out of scope.
 //
-// Byte / integer work, HBM-bound on reading the masks once: each mask becomes a bitmap (64 pixels per wave ballot), its
+// Byte / integer work, HBM-bound on reading the masks once: each mask becomes a bitmap (16 pixels per lane, four lanes per word), its
 // bounding box and area come from integer atomics (deterministic), and the pairwise intersections are popcounts of ANDed
 // bitmap words - M (M+1) / 2 pairs x H W / 64 words, nothing next to the first pass.
 #include "common.h"
@@ -18,6 +18,10 @@ namespace sm {
 
 struct VoteBox { int ymin, ymax, xmin, xmax; unsigned area; };
 
+// 16 pixels per lane: four lanes assemble one 64-pixel bitmap word, a workgroup covers 4096 pixels and issues ONE set of box atomics
+// (a wave per word and five atomics per wave made 784 x 5 atomics per 224^2 mask on five addresses: 1.5 ms per 128 images x 9 masks;
+// this form: see profiles/r04_kernel_stats_pseudo_masks.csv).  VEC: one 16-byte load per lane (every mask starts 16-byte aligned).
+template <bool VEC>
 __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __restrict__ masks, unsigned long long* __restrict__ bits,
                                                        VoteBox* __restrict__ box, int H, int W, int words, int M) {
     const int m = blockIdx.y;
@@ -26,18 +30,43 @@ __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __r
     bits += (int64_t)blockIdx.z * M * words;
     box += (int64_t)blockIdx.z * M;
     const unsigned char* src = masks + (int64_t)m * npx;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int ymin = 1 << 30, ymax = -1, xmin = 1 << 30, xmax = -1;
     unsigned area = 0;
-    for (int wd = blockIdx.x * 4 + (threadIdx.x >> 6); wd < words; wd += gridDim.x * 4) {
-        const int64_t p = (int64_t)wd * 64 + lane;
-        const bool on = p < npx && src[p] != 0;
-        const unsigned long long word = __ballot(on);
-        if (lane == 0) bits[(int64_t)m * words + wd] = word;
-        if (on) {
-            const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
-            ymin = min(ymin, y); ymax = max(ymax, y); xmin = min(xmin, x); xmax = max(xmax, x);
-            area += 1;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < (int64_t)words * 4; g += (int64_t)gridDim.x * 256) {  // quads stay together
+        const int64_t p0 = g * 16;
+        unsigned b16 = 0;
+        if (VEC && p0 + 16 <= npx) {
+            const uint4 v = *reinterpret_cast<const uint4*>(src + p0);
+            const unsigned q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // 0x80 in every non-zero byte, then the four flags gathered into bits 24..27 by one multiply (no two products collide)
+                const unsigned t = ((q[k] | ((q[k] & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+                b16 |= ((t * 0x01020408u) >> 24 & 0xfu) << (4 * k);
+            }
+        } else {
+            for (int k = 0; k < 16; ++k)
+                if (p0 + k < npx && src[p0 + k] != 0) b16 |= 1u << k;
+        }
+        unsigned long long part = (unsigned long long)b16 << (16 * (lane & 3));
+        part |= __shfl_xor(part, 1, 64);
+        part |= __shfl_xor(part, 2, 64);
+        if ((lane & 3) == 0) bits[(int64_t)m * words + (g >> 2)] = part;
+        if (b16) {
+            const int64_t pf = p0 + __ffs(b16) - 1, pl = p0 + 31 - __clz(b16);
+            const int yf = (int)(pf / W), yl = (int)(pl / W);
+            ymin = min(ymin, yf); ymax = max(ymax, yl);
+            if (yf == yl) {
+                xmin = min(xmin, (int)(pf - (int64_t)yf * W)); xmax = max(xmax, (int)(pl - (int64_t)yf * W));
+            } else {  // the 16 pixels cross a row end
+                for (unsigned r = b16; r; r &= r - 1) {
+                    const int64_t p = p0 + __ffs(r) - 1;
+                    const int x = (int)(p - (p / W) * W);
+                    xmin = min(xmin, x); xmax = max(xmax, x);
+                }
+            }
+            area += __popc(b16);
         }
     }
 #pragma unroll
@@ -46,10 +75,19 @@ __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __r
         xmin = min(xmin, __shfl_xor(xmin, o, 64)); xmax = max(xmax, __shfl_xor(xmax, o, 64));
         area += __shfl_xor(area, o, 64);
     }
-    if (lane == 0 && area) {
-        atomicMin(&box[m].ymin, ymin); atomicMax(&box[m].ymax, ymax);
-        atomicMin(&box[m].xmin, xmin); atomicMax(&box[m].xmax, xmax);
-        atomicAdd(&box[m].area, area);
+    __shared__ int red[4][5];
+    if (lane == 0) { red[wave][0] = ymin; red[wave][1] = ymax; red[wave][2] = xmin; red[wave][3] = xmax; red[wave][4] = (int)area; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            ymin = min(ymin, red[k][0]); ymax = max(ymax, red[k][1]); xmin = min(xmin, red[k][2]); xmax = max(xmax, red[k][3]);
+            area += (unsigned)red[k][4];
+        }
+        if (area) {
+            atomicMin(&box[m].ymin, ymin); atomicMax(&box[m].ymax, ymax);
+            atomicMin(&box[m].xmin, xmin); atomicMax(&box[m].xmax, xmax);
+            atomicAdd(&box[m].area, area);
+        }
     }
 }
 
@@ -159,8 +197,11 @@ extern "C" int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M
     w += ((size_t)B * M * sizeof(sm::VoteBox) + 255) & ~(size_t)255;
     auto* inter = (unsigned*)w;
     hipLaunchKernelGGL(sm::vote_init_kernel, dim3((M * M + 255) / 256, 1, B), dim3(256), 0, st, box, inter, M);
-    const int gx = (words + 3) / 4 < 256 ? (words + 3) / 4 : 256;
-    hipLaunchKernelGGL(sm::vote_pack_kernel, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M);
+    const int gx = (words + 63) / 64 < 64 ? (words + 63) / 64 : 64;  // 64 words (4096 pixels) per workgroup and pass
+    if (((uintptr_t)masks % 16) == 0 && ((int64_t)H * W) % 16 == 0)
+        hipLaunchKernelGGL(sm::vote_pack_kernel<true>, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M);
+    else
+        hipLaunchKernelGGL(sm::vote_pack_kernel<false>, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M);
     hipLaunchKernelGGL(sm::vote_pairs_kernel, dim3((words + 255) / 256 < 16 ? (words + 255) / 256 : 16, M * (M + 1) / 2, B), dim3(256), 0, st,
                        bits, inter, M, words);
     hipLaunchKernelGGL(sm::vote_finalize_kernel, dim3(1, 1, B), dim3(64), 0, st, box, inter, M, H, W, remove_long, remove_small_large, keep, iou,

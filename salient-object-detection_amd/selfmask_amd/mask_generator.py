@@ -47,10 +47,21 @@ def rle_decode(rle: dict) -> np.ndarray:
     return np.repeat(vals, rle["counts"]).reshape((h, w), order="F").astype(np.uint8)
 
 
+class _Files:
+    """what PrefetchingLoader needs of a dataset: image paths, no ground truth"""
+
+    def __init__(self, p_imgs):
+        self.p_imgs, self.p_gts = list(p_imgs), [None] * len(p_imgs)
+
+
 class MaskGenerator:
     def __init__(self, cluster_sizes: Sequence[int] = VT.DEFAULT_CLUSTER_SIZES, cluster_type: str = VT.DEFAULT_CLUSTER_TYPE,
                  feature_types: Sequence[str] = ("dino",), use_gpu: bool = True, device: torch.device = torch.device("cuda:0"),
-                 network=None, batch_size: int = 16, n_neighbors: int = 10):
+                 network=None, batch_size: int = 128, n_neighbors: int = 10, streams: int = 3, workers: Optional[int] = None):
+        """``batch_size``: the most images of ONE size clustered together - the eigen-solver runs one workgroup per image, so a launch
+        takes about as long for 128 images as for 8 (profiles/r04_pseudo_masks_by_batch.log); ``streams``: batches in flight (one's
+        eigen-solve, half of the CUs at 128 images, runs beside the next one's encoder); ``workers``: decode processes
+        (default: this rank's share of the host cores)."""
         assert cluster_type in VT.CLUSTER_TYPES + ("kmeans",), cluster_type  # mask_generator.pyc@L30: ('k-means', 'spectral')
         unsupported = [f for f in feature_types if f != "dino"]
         if unsupported:
@@ -63,34 +74,48 @@ class MaskGenerator:
             raise RuntimeError("the MI355X build has no CPU path")
         self.cluster_sizes, self.cluster_type, self.feature_types = tuple(int(k) for k in cluster_sizes), cluster_type, list(feature_types)
         self.device, self.network, self.batch_size, self.n_neighbors = torch.device(device), network, int(batch_size), int(n_neighbors)
+        self.streams, self.workers = max(1, int(streams)), workers
 
     # ---- mask_generator.pyc@L136-200 --------------------------------------------------------------------------------------------
     def _load(self, p_image: str) -> torch.Tensor:
+        """one file as ``CustomDataset`` prepares it on the host (custom_dataset.py:26-32) - what the batches below hold, per image
+        (tests compare the two)"""
         from PIL import Image
         rgb = np.asarray(Image.open(p_image).convert("RGB"), np.float32) / np.float32(255.0)  # to_tensor
         x = (rgb - np.asarray(MEAN, np.float32)) / np.asarray(STD, np.float32)               # normalize
         return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
 
+    def _batches(self, p_images: Sequence[str]):
+        """-> (file names, decoded uint8 RGB arrays) per batch of images of ONE size, at most ``batch_size``: the headers give the
+        sizes, the decode processes of the input pipeline (decode_pool.py) the pixels, a few batches ahead of the device."""
+        from PIL import Image
+        from .pipeline import PrefetchingLoader
+        p_images = list(p_images)
+        by_size = defaultdict(list)
+        for i, p in enumerate(p_images):
+            with Image.open(p) as im:  # header only
+                by_size[im.size].append(i)
+        batches = [idx[s:s + self.batch_size] for idx in by_size.values() for s in range(0, len(idx), self.batch_size)]
+        loader = PrefetchingLoader(_Files(p_images), range(len(p_images)), self.batch_size, workers=self.workers, batches=batches)
+        for rgbs, _gts, idx in loader:
+            yield [p_images[i].split("/")[-1] for i in idx], rgbs
+
+    def _candidates(self, rgbs) -> torch.Tensor:
+        """decoded images of one size -> (B, sum(cluster_sizes), H, W) uint8 candidates, queued on the current stream"""
+        from .pipeline import preprocess_on_device
+        H, W = rgbs[0].shape[:2]
+        x = preprocess_on_device(rgbs, None, self.device, pinned=True, pad_to=(H, W))  # (B, 3, H, W): to_tensor + normalize on the device
+        cands = VT.extract_candidate_masks(self.network, x, self.cluster_sizes, cluster_type=self.cluster_type, n_neighbors=self.n_neighbors)
+        return cands[None] if cands.dim() == 3 else cands
+
     @torch.no_grad()
     def extract_candidate_masks(self, p_images: Sequence[str]) -> Dict[str, torch.Tensor]:
         """file name -> (sum(cluster_sizes), H, W) uint8 on the device (the reference concatenates the candidates of its three
         feature types per file name; here there is one)."""
-        by_size = defaultdict(list)
-        tensors = {}
-        for p in p_images:
-            x = self._load(p)
-            tensors[p] = x
-            by_size[tuple(x.shape[-2:])].append(p)
         out: Dict[str, torch.Tensor] = {}
-        for (_h, _w), paths in by_size.items():
-            for s in range(0, len(paths), self.batch_size):
-                chunk = paths[s:s + self.batch_size]
-                x = torch.stack([tensors[p] for p in chunk]).to(self.device)
-                cands = VT.extract_candidate_masks(self.network, x, self.cluster_sizes, cluster_type=self.cluster_type,
-                                                   n_neighbors=self.n_neighbors)
-                cands = cands[None] if cands.dim() == 3 else cands
-                for p, c in zip(chunk, cands):
-                    out[p.split("/")[-1]] = c
+        for names, rgbs in self._batches(p_images):
+            for n, c in zip(names, self._candidates(rgbs)):
+                out[n] = c
         return out
 
     # ---- mask_generator.pyc@L202-230 --------------------------------------------------------------------------------------------
@@ -101,14 +126,26 @@ class MaskGenerator:
     @torch.no_grad()
     def __call__(self, p_images: Sequence[str], remove_long_masks: bool = True, remove_small_large_masks: bool = False,
                  encode: Optional[bool] = True) -> Dict[str, object]:
-        cands = self.extract_candidate_masks(p_images)
-        by_shape = defaultdict(list)
-        for name, c in cands.items():
-            by_shape[tuple(c.shape)].append(name)
+        """Candidates and vote of one batch are queued on one stream of a ring and read back ``streams`` batches later: images are
+        independent, so the result per file is what the reference's extract-everything-then-vote order gives."""
+        from collections import deque
+        from .streams import StreamRing
+        ring = StreamRing(self.device, self.streams)
+        pending = deque()
         result: Dict[str, object] = {}
-        for _shape, names in by_shape.items():  # one vote launch sequence and one device-to-host copy per group of one size
-            votes = VT.vote_mask_batch(torch.stack([cands[n] for n in names]), remove_long_masks, remove_small_large_masks)
-            for n, (best_mask, _best, _map) in zip(names, votes):
-                m = best_mask.cpu().numpy()
-                result[n] = rle_encode(m) if encode else m
+
+        def settle():
+            names, votes = pending.popleft()
+            for n, m in zip(names, votes.winners_host().numpy()):
+                result[n] = rle_encode(m) if encode else m.copy()
+
+        for names, rgbs in self._batches(p_images):
+            with ring.next():
+                pending.append((names, VT.vote_mask_batch_async(self._candidates(rgbs), remove_long_masks, remove_small_large_masks,
+                                                                winners=True)))
+            if len(pending) >= len(ring.streams):
+                settle()
+        while pending:
+            settle()
+        ring.join()
         return result

@@ -60,9 +60,52 @@ def vote_mask(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, re
     return batch_pred_masks[best_h], prev_to_new[best_h], new_to_prev
 
 
-def vote_mask_batch(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False):
-    """``vote_mask`` for B images of one size in one launch sequence and ONE device-to-host copy: (B, M, H, W) 0/1 -> list of B
-    tuples (best mask (H, W), best index among the survivors, new_index_to_prev_index), each what ``vote_mask`` returns for that image."""
+class PendingVotes:
+    """The votes of one batch, queued on a stream: ``result()`` waits for THAT batch's device-to-host copy only, so the caller can
+    queue the next batch (on another stream) before asking.  ``winners`` (B, H, W) uint8 is the voted mask of every image on the
+    device; ``winners_host()`` the same in page-locked host memory (one copy for the batch)."""
+
+    def __init__(self, source, masks, keep, iou, sums, best, want_winners: bool):
+        self.source, self.masks, self.keep, self.iou, self.row_sums, self.best = source, masks, keep, iou, sums, best
+        B, M = keep.shape
+        self._host = torch.empty((B, M + 1), dtype=torch.int32, pin_memory=True)
+        self._host.copy_(torch.cat([keep, best[:, None]], dim=1), non_blocking=True)
+        self.winners = self._winners_host = None
+        if want_winners:
+            self.winners = masks[torch.arange(B, device=masks.device), best.long().clamp_(min=0)]
+            self._winners_host = torch.empty(self.winners.shape, dtype=torch.uint8, pin_memory=True)
+            self._winners_host.copy_(self.winners, non_blocking=True)
+        self._done = torch.cuda.Event()
+        self._done.record(torch.cuda.current_stream(masks.device))
+
+    def _rows(self):
+        self._done.synchronize()
+        rows = self._host.tolist()
+        if any(r[-1] < 0 for r in rows):
+            raise RuntimeError("sm_vote_masks_batch_u8 returned no winner")
+        return rows
+
+    def winners_host(self) -> torch.Tensor:
+        assert self._winners_host is not None, "vote_mask_batch_async(..., winners=True)"
+        self._rows()
+        return self._winners_host
+
+    def result(self):
+        out = []
+        M = self.keep.shape[1]
+        for b, row in enumerate(self._rows()):
+            keep_h, best_h = row[:M], row[M]
+            new_to_prev = {}
+            for prev, k in enumerate(keep_h):
+                if k:
+                    new_to_prev[len(new_to_prev)] = prev
+            out.append((self.source[b, best_h], {v: k for k, v in new_to_prev.items()}[best_h], new_to_prev))
+        return out
+
+
+def vote_mask_batch_async(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False,
+                          winners: bool = False) -> PendingVotes:
+    """``vote_mask`` for B images of one size in one launch sequence on the current stream, without waiting for it."""
     if not batch_pred_masks.is_cuda:
         raise RuntimeError("vote_mask_batch (MI355X) needs its candidates on a HIP device; there is no CPU fallback")
     m = batch_pred_masks.to(torch.uint8).contiguous()
@@ -80,19 +123,15 @@ def vote_mask_batch(batch_pred_masks: torch.Tensor, remove_long_masks: bool = Tr
     N.check(lib.sm_vote_masks_batch_u8(m.data_ptr(), B, M, H, W, int(remove_long_masks), int(remove_small_large_masks), keep.data_ptr(),
                                        iou.data_ptr(), sums.data_ptr(), best.data_ptr(), ws.data_ptr(), nbytes * B,
                                        torch.cuda.current_stream(dev).cuda_stream), "sm_vote_masks_batch_u8")
-    host = torch.cat([keep, best[:, None]], dim=1).cpu().tolist()  # one copy for the whole batch
-    vote_mask_batch.last = {"keep": keep, "iou": iou, "row_sums": sums, "best": best}
-    out = []
-    for b, row in enumerate(host):
-        keep_h, best_h = row[:M], row[M]
-        if best_h < 0:
-            raise RuntimeError("sm_vote_masks_batch_u8 returned no winner")
-        new_to_prev = {}
-        for prev, k in enumerate(keep_h):
-            if k:
-                new_to_prev[len(new_to_prev)] = prev
-        out.append((batch_pred_masks[b, best_h], {v: k for k, v in new_to_prev.items()}[best_h], new_to_prev))
-    return out
+    return PendingVotes(batch_pred_masks, m, keep, iou, sums, best, winners)
+
+
+def vote_mask_batch(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False):
+    """``vote_mask`` for B images of one size in one launch sequence and ONE device-to-host copy: (B, M, H, W) 0/1 -> list of B
+    tuples (best mask (H, W), best index among the survivors, new_index_to_prev_index), each what ``vote_mask`` returns for that image."""
+    pend = vote_mask_batch_async(batch_pred_masks, remove_long_masks, remove_small_large_masks)
+    vote_mask_batch.last = {"keep": pend.keep, "iou": pend.iou, "row_sums": pend.row_sums, "best": pend.best}
+    return pend.result()
 
 
 def kmeans(features: torch.Tensor, k: int, iters: int = 20):

@@ -172,3 +172,16 @@ def test_mask_generator_files_to_encoded_masks(tmp_path):
         assert (got != ref_mask).mean() <= 5e-3, name
     raw = gen(paths[:1], encode=False)
     assert np.array_equal(raw["img_0.png"], rle_decode(out["img_0.png"]))
+    # the batches the generator feeds the encoder hold exactly what CustomDataset would (to_tensor + normalize), per file
+    from selfmask_amd.pipeline import preprocess_on_device
+    seen = {}
+    for names, rgbs in gen._batches(paths):
+        H, W = rgbs[0].shape[:2]
+        xb = preprocess_on_device(rgbs, None, DEV, pinned=True, pad_to=(H, W)).cpu()
+        seen.update(zip(names, xb))
+    for p in paths:
+        assert torch.equal(seen[p.split("/")[-1]], gen._load(p))
+    # neither the batch size nor the number of batches in flight changes a result
+    for bs, st in ((1, 1), (4, 2)):
+        again = MaskGenerator(network=m, device=DEV, batch_size=bs, streams=st)(paths)
+        assert again == out

@@ -70,3 +70,36 @@ def test_vote_known_answers(name):
     assert np.array_equal(best_mask.cpu().numpy(), masks[want_map[want_best]])
     kept = [new_to_prev[k] for k in range(len(new_to_prev))]
     assert np.array_equal(vote_mask.last["iou"].cpu().numpy()[kept][:, kept], np.asarray(want_table, np.float32))
+
+
+@pytest.mark.parametrize("h,w", [(224, 224), (48, 50), (37, 53), (300, 400), (16, 16), (5, 7)])
+def test_pack_shapes_bytes_and_batches(h, w):
+    """The bitmap / box pass in both its forms (16-byte loads when every mask starts 16-byte aligned, byte loads otherwise), rows that
+    end inside a lane's 16 pixels, any non-zero byte counting as set, single pixels in the corners, and the batch form."""
+    from selfmask_amd.voting import vote_mask_batch
+    rng = np.random.Generator(np.random.PCG64(h * 1000 + w))
+    yy, xx = np.mgrid[:h, :w]
+    batch = []
+    for b in range(3):
+        ms = []
+        for _ in range(5):
+            cy, cx, ry, rx = rng.uniform(0.2, 0.8) * h, rng.uniform(0.2, 0.8) * w, rng.uniform(0.15, 0.4) * h, rng.uniform(0.15, 0.4) * w
+            ms.append(((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1).astype(np.uint8) * rng.choice([1, 2, 128, 255]))
+        corner = np.zeros((h, w), np.uint8)
+        corner[[0, -1, 0, -1], [0, -1, -1, 0]] = 255
+        ms += [corner, (rng.random((h, w)) < 0.5).astype(np.uint8), np.zeros((h, w), np.uint8)]
+        batch.append(np.stack(ms))
+    masks = torch.from_numpy(np.stack(batch))
+    got = vote_mask_batch(masks.to(DEV), False, False)
+    tables = vote_mask_batch.last["iou"].cpu()
+    for b in range(3):
+        binary = (masks[b] != 0).to(torch.uint8)
+        ref_mask, ref_best, ref_map, table, _ = V.vote_mask(binary, False, False)
+        assert got[b][1] == ref_best and got[b][2] == ref_map
+        assert torch.equal((got[b][0].cpu() != 0).to(torch.uint8), ref_mask)
+        kept = [ref_map[k] for k in range(len(ref_map))]
+        assert torch.equal(tables[b][kept][:, kept], table)
+        for flags in ((True, False), (True, True)):  # the filters read the boxes and areas
+            one = vote_mask(masks[b].to(DEV), *flags)
+            ref = V.vote_mask(binary, *flags)
+            assert one[1] == ref[1] and one[2] == ref[2]
