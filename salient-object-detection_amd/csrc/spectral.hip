@@ -267,6 +267,138 @@ __device__ __forceinline__ void sp_filter_step(const SpGraph& g, const double* _
     }
 }
 
+// The same step with the GRAPH in the LDS as well (round 4, second pass): the first SP_PAD = 24 neighbours of every row as 16-bit
+// indices padded with the zero row (48 B per row), the list lengths and 1 / sqrt(d) - filled once per solve, the graph does not change.
+// The item loop then has no global load on its critical path (the hand-pipelined global index loads above still cost a memory round
+// trip per item - 4.5 k cycles per item and wave at n = 784): the next item's three 16-B index reads and its X value are in flight
+// while the current item's 24 gathers are summed.  Same sums in the same order as sp_filter_step: bit-identical results.
+constexpr int SP_PAD = 24;
+
+struct SpLdsGraph {
+    const unsigned short* nb;   // n x SP_PAD
+    const unsigned short* len;  // n
+    const double* isd;          // n
+};
+
+__host__ __device__ constexpr size_t sp_lds_graph_offset(int n, int cg) { return (((size_t)(n + 1) * cg * 8 + (size_t)n * 8) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t sp_lds_graph_bytes(int n, int cg) {
+    return ((sp_lds_graph_offset(n, cg) + (size_t)n * SP_PAD * 2 + (size_t)n * 2) + 15) & ~(size_t)15;
+}
+
+template <int CG, bool LAST>
+__device__ __forceinline__ void sp_filter_step_lds(const SpGraph& g, const SpLdsGraph& lg, const double* __restrict__ Yr, double* __restrict__ Xw,
+                                                   double* ylds, double c0, double f1, double f2) {
+    const int total = g.n * CG;
+    struct Idx { uint4 q[3]; };
+    auto indices = [&](int t) {
+        Idx x;
+        const uint4* p = reinterpret_cast<const uint4*>(lg.nb + (t < total ? t / CG : 0) * SP_PAD);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x.q[k] = p[k];
+        return x;
+    };
+#pragma unroll 1
+    for (int c = 0; c < SP_B; c += CG) {
+        for (int t = threadIdx.x; t < total; t += SP_THREADS) ylds[t] = Yr[(t / CG) * SP_B + c + t % CG];
+        if (threadIdx.x < CG) ylds[total + threadIdx.x] = 0.0;
+        int t = threadIdx.x;
+        double xo_next = t < total ? Xw[(t / CG) * SP_B + c + t % CG] : 0.0;
+        __syncthreads();
+        Idx x_cur = indices(t);
+#pragma unroll 1
+        for (; t < total; t += SP_THREADS) {
+            const int i = t / CG, jj = t % CG, tn = t + SP_THREADS;
+            const double xo = xo_next;
+            if (tn < total) xo_next = Xw[(tn / CG) * SP_B + c + tn % CG];
+            const Idx x_next = indices(tn);
+            const unsigned wq[12] = {x_cur.q[0].x, x_cur.q[0].y, x_cur.q[0].z, x_cur.q[0].w, x_cur.q[1].x, x_cur.q[1].y,
+                                     x_cur.q[1].z, x_cur.q[1].w, x_cur.q[2].x, x_cur.q[2].y, x_cur.q[2].z, x_cur.q[2].w};
+            double y[SP_PAD];
+#pragma unroll
+            for (int u = 0; u < SP_PAD; ++u) y[u] = ylds[(int)((wq[u >> 1] >> (16 * (u & 1))) & 0xffffu) * CG + jj];  // padding: the zero row
+            const double yo = ylds[t], w = lg.isd[i];
+            const int cnt = lg.len[i];
+            asm volatile("" ::: "memory");  // every load above is issued before the first add below
+            double acc = 0.0;
+#pragma unroll
+            for (int u = 0; u < SP_PAD; ++u) acc += y[u];
+            if (cnt > SP_PAD) {
+                const int s0 = g.ptr[i];
+                for (int e = SP_PAD; e < cnt; ++e) acc += ylds[g.col[s0 + e] * CG + jj];  // hubs: the rest of the list from memory
+            }
+            const double ly = yo - (0.5 * w * w) * acc;
+            const double xn = (ly - c0 * yo) * f1 - f2 * xo;
+            Xw[i * SP_B + c + jj] = LAST ? xn / w : xn;
+            x_cur = x_next;
+        }
+        __syncthreads();
+    }
+}
+
+// And with BOTH blocks of the recurrence in the LDS beside the graph (n <= 825: 2 (n + 1) x 8 doubles + 58 B per row within 150 KB -
+// the 28 x 28 x 4 = 784 points of a 224^2 image): a whole filter runs without touching memory - the step gathers from yl, rewrites
+// xl in place (each lane its own element), and the two exchange roles; only the last step writes, to the block in memory.  With two
+// waves per SIMD nothing hid the memory round trips of the staged forms (SQ counters: 69 % of the wave cycles waiting, 3 % of them on
+// the LDS; ~50 k cycles per step, profiles/r04_spectral_sq_counters.txt).  Same sums in the same order: bit-identical results.
+constexpr size_t sp_resident_offset(int n) { return (size_t)2 * (n + 1) * SP_B * 8; }  // then isd (n + 1, the last one 0) | nb | len
+__host__ __device__ constexpr size_t sp_resident_bytes(int n) {
+    return ((((sp_resident_offset(n) + (size_t)(n + 1) * 8 + 15) & ~(size_t)15) + (size_t)n * SP_PAD * 2 + (size_t)n * 2) + 15) & ~(size_t)15;
+}
+
+// (An item here = a row and TWO columns: one 16-B read per neighbour, and the lists hold BYTE offsets of the neighbours' rows - the
+// (row, column) form spent 2.5 address instructions per 8-byte gather and was issue-bound at 38 k cycles per step.)
+template <bool LAST>
+__device__ __forceinline__ void sp_filter_step_resident(const SpGraph& g, const SpLdsGraph& lg, const double* yl, double* xl, double c0,
+                                                        double f1, double f2) {
+    constexpr int TC = 2, PER_ROW = SP_B / TC;
+    const int total = g.n * PER_ROW;
+    struct Idx { uint4 q[3]; };
+    auto indices = [&](int t) {
+        Idx x;
+        const uint4* p = reinterpret_cast<const uint4*>(lg.nb + (t < total ? t / PER_ROW : 0) * SP_PAD);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x.q[k] = p[k];
+        return x;
+    };
+    int t = threadIdx.x;
+    Idx x_cur = indices(t);
+#pragma unroll 1
+    for (; t < total; t += SP_THREADS) {
+        const int i = t / PER_ROW, jj = (t % PER_ROW) * TC;
+        const Idx x_next = indices(t + SP_THREADS);
+        const unsigned wq[12] = {x_cur.q[0].x, x_cur.q[0].y, x_cur.q[0].z, x_cur.q[0].w, x_cur.q[1].x, x_cur.q[1].y,
+                                 x_cur.q[1].z, x_cur.q[1].w, x_cur.q[2].x, x_cur.q[2].y, x_cur.q[2].z, x_cur.q[2].w};
+        const char* ycol = reinterpret_cast<const char*>(yl + jj);
+        double2 y[SP_PAD];
+#pragma unroll
+        for (int u = 0; u < SP_PAD; ++u)  // the list entry IS the byte offset of the neighbour's row (padding: the zero row)
+            y[u] = *reinterpret_cast<const double2*>(ycol + ((wq[u >> 1] >> (16 * (u & 1))) & 0xffffu));
+        const double2 yo = *reinterpret_cast<const double2*>(yl + i * SP_B + jj);
+        const double2 xo = *reinterpret_cast<const double2*>(xl + i * SP_B + jj);
+        const double w = lg.isd[i];
+        const int cnt = lg.len[i];
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < SP_PAD; ++u) { a0 += y[u].x; a1 += y[u].y; }
+        if (cnt > SP_PAD) {
+            const int s0 = g.ptr[i];
+            for (int e = SP_PAD; e < cnt; ++e) {  // hubs: the rest of the list from memory
+                const double2 v = *reinterpret_cast<const double2*>(yl + g.col[s0 + e] * SP_B + jj);
+                a0 += v.x; a1 += v.y;
+            }
+        }
+        const double h = 0.5 * w * w;
+        const double l0 = yo.x - h * a0, l1 = yo.y - h * a1;
+        double2 xn;
+        xn.x = (l0 - c0 * yo.x) * f1 - f2 * xo.x;
+        xn.y = (l1 - c0 * yo.y) * f1 - f2 * xo.y;
+        if (LAST) { xn.x = xn.x / w; xn.y = xn.y / w; }  // back to the symmetric variables on the way out (last step only)
+        *reinterpret_cast<double2*>(xl + i * SP_B + jj) = xn;
+        x_cur = x_next;
+    }
+    __syncthreads();
+}
+
 // the same with every term scaled by isd[nb] (the symmetric form: two loads per neighbour; once per outer iteration)
 __device__ __forceinline__ double sp_gather2(const int* __restrict__ col, int s, int t, const double* __restrict__ isd,
                                              const double* __restrict__ Y, int j) {
@@ -292,6 +424,48 @@ __device__ __forceinline__ void sp_apply_sym(const SpGraph& g, const double* __r
     for (int t = threadIdx.x; t < g.n * SP_B; t += SP_THREADS) {
         const int i = t / SP_B, j = t % SP_B;
         Out[t] = In[t] - 0.5 * g.isd[i] * sp_gather2(g.col, g.ptr[i], g.ptr[i] + g.len[i], g.isd, In, j);
+    }
+}
+
+// Out = L In with both blocks and the graph in the LDS (MODE 2): the same products isd[nb] * In[nb] summed in list order (the padding
+// adds isd[n] * In[n] = 0 * 0), a row and two columns per lane
+__device__ __forceinline__ void sp_apply_sym_resident(const SpGraph& g, const SpLdsGraph& lg, const double* in, double* out) {
+    constexpr int TC = 2, PER_ROW = SP_B / TC;
+    const int total = g.n * PER_ROW;
+#pragma unroll 1
+    for (int t = threadIdx.x; t < total; t += SP_THREADS) {
+        const int i = t / PER_ROW, jj = (t % PER_ROW) * TC;
+        const uint4* p = reinterpret_cast<const uint4*>(lg.nb + i * SP_PAD);
+        const uint4 q0 = p[0], q1 = p[1], q2 = p[2];
+        const unsigned wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        const char* col = reinterpret_cast<const char*>(in + jj);
+        const char* isdb = reinterpret_cast<const char*>(lg.isd);
+        double2 y[SP_PAD];
+        double w[SP_PAD];
+#pragma unroll
+        for (int u = 0; u < SP_PAD; ++u) {
+            const unsigned off = (wq[u >> 1] >> (16 * (u & 1))) & 0xffffu;  // byte offset of the neighbour's row: 64 B per row, 8 per isd entry
+            y[u] = *reinterpret_cast<const double2*>(col + off);
+            w[u] = *reinterpret_cast<const double*>(isdb + (off >> 3));
+        }
+        const double2 self = *reinterpret_cast<const double2*>(in + i * SP_B + jj);
+        const double wi = lg.isd[i];
+        const int cnt = lg.len[i];
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int u = 0; u < SP_PAD; ++u) { a0 += w[u] * y[u].x; a1 += w[u] * y[u].y; }
+        if (cnt > SP_PAD) {
+            const int s0 = g.ptr[i];
+            for (int e = SP_PAD; e < cnt; ++e) {
+                const int nbr = g.col[s0 + e];
+                const double2 v = *reinterpret_cast<const double2*>(in + nbr * SP_B + jj);
+                a0 += lg.isd[nbr] * v.x; a1 += lg.isd[nbr] * v.y;
+            }
+        }
+        double2 o;
+        o.x = self.x - 0.5 * wi * a0;
+        o.y = self.y - 0.5 * wi * a1;
+        *reinterpret_cast<double2*>(out + i * SP_B + jj) = o;
     }
 }
 
@@ -516,7 +690,8 @@ __device__ __forceinline__ double sp_init_value(int i, int j) {  // splitmix64 o
     return (double)(long long)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
-template <int CG>
+// MODE 0: graph in memory, CG columns of the block staged per pass; 1: graph in the LDS too; 2: graph and both blocks in the LDS (CG = 8)
+template <int CG, int MODE>
 __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ ptr_all, const int* __restrict__ len_all,
                                                                     const int* __restrict__ col_all,
                                                                     const double* __restrict__ isd_all, int n, int m, int kw, int degree,
@@ -532,9 +707,25 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
     g.col = col_all + (int64_t)img * sp_col_capacity(n, m);
     g.isd = isd_all + (int64_t)img * n;
     g.n = n;
-    double* U = blocks_all + (int64_t)img * 2 * n * SP_B;  // the Ritz vectors
-    double* V = U + (int64_t)n * SP_B;                     // L U
+    // the Ritz vectors U and L U: in memory, or - MODE 2 - in the LDS for the whole solve (each with a zero row at index n)
+    double* U = MODE == 2 ? ylds : blocks_all + (int64_t)img * 2 * n * SP_B;
+    double* V = MODE == 2 ? ylds + (size_t)(n + 1) * SP_B : U + (int64_t)n * SP_B;
     int guard = 0, matvecs = 0, outer = 0, converged = 0;
+    SpLdsGraph lg = {nullptr, nullptr, nullptr};
+    if (MODE) {  // the graph beside the block(s): [ylds (n + 1) * CG (x 2: MODE 2) | isd n | (16-B aligned) nb n * SP_PAD u16 | len n u16]
+        const size_t blocks = MODE == 2 ? sp_resident_offset(n) : (size_t)(n + 1) * CG * 8;
+        double* isdl = reinterpret_cast<double*>(reinterpret_cast<char*>(ylds) + blocks);
+        unsigned short* nbl = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ylds) + ((blocks + (size_t)(n + (MODE == 2)) * 8 + 15) & ~(size_t)15));
+        unsigned short* lenl = nbl + (size_t)n * SP_PAD;
+        for (int t = tid; t < n * SP_PAD; t += SP_THREADS) {
+            const int i = t / SP_PAD, u = t % SP_PAD;
+            const int nbr = u < g.len[i] ? g.col[g.ptr[i] + u] : n;
+            nbl[t] = (unsigned short)(MODE == 2 ? nbr * (SP_B * 8) : nbr);  // MODE 2: the byte offset of the row ((n + 1) * 64 <= 65535 there)
+        }
+        for (int t = tid; t < n; t += SP_THREADS) { lenl[t] = (unsigned short)g.len[t]; isdl[t] = g.isd[t]; }
+        if (MODE == 2 && tid < SP_B) { U[n * SP_B + tid] = 0.0; V[n * SP_B + tid] = 0.0; isdl[n] = 0.0; }  // what a list's padding points at
+        lg.nb = nbl; lg.len = lenl; lg.isd = isdl;
+    }
 #ifdef SM_SPECTRAL_STAMPS  // experiment build: shader-clock cycles per phase instead of the residuals (scripts/spectral_stamps.py)
     unsigned long long t_filter = 0, t_chol = 0, t_apply = 0, t_rr = 0, t0 = 0;
 #define SP_T0 t0 = __builtin_readcyclecounter()
@@ -556,7 +747,8 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         for (int pass = 0; pass < 3; ++pass) chol_qr_pass(U, n, pass == 0 ? 1e-11 : 0.0, sh, &guard);  // shifted Cholesky QR, three passes
         SP_T(t_chol);
         SP_T0;
-        sp_apply_sym(g, U, V);
+        if (MODE == 2) sp_apply_sym_resident(g, lg, U, V);
+        else sp_apply_sym(g, U, V);
         ++matvecs;
         __syncthreads();
         SP_T(t_apply);
@@ -578,30 +770,60 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         const double tau = 2.0 / sig;
         __syncthreads();  // everyone has read sh.res / sh.th
         SP_T0;
-        double* X = U;
-        double* Y = V;
-        {
+        if (MODE == 2) {
+            double* xl = U;  // X_0 = D^-1/2 U, in place
+            double* yl = V;  // X_1
             const double f = sig / e;
             for (int t = tid; t < n * SP_B; t += SP_THREADS) {
-                const double w = g.isd[t / SP_B], x = X[t] * w;
-                X[t] = x;
-                Y[t] = (Y[t] * w - c0 * x) * f;
+                const double w = lg.isd[t / SP_B], x = xl[t] * w;
+                xl[t] = x;
+                yl[t] = (yl[t] * w - c0 * x) * f;
             }
+            __syncthreads();
+            for (int it = 2; it <= degree; ++it) {
+                const double sn = 1.0 / (tau - sig);
+                const double f1 = 2.0 * sn / e, f2 = sig * sn;
+                if (it == degree) sp_filter_step_resident<true>(g, lg, yl, xl, c0, f1, f2);
+                else sp_filter_step_resident<false>(g, lg, yl, xl, c0, f1, f2);
+                ++matvecs;
+                double* sw = xl;
+                xl = yl;
+                yl = sw;
+                sig = sn;
+            }
+            U = yl;  // the filtered block
+            V = xl;
+        } else {
+            double* X = U;
+            double* Y = V;
+            {
+                const double f = sig / e;
+                for (int t = tid; t < n * SP_B; t += SP_THREADS) {
+                    const double w = g.isd[t / SP_B], x = X[t] * w;
+                    X[t] = x;
+                    Y[t] = (Y[t] * w - c0 * x) * f;
+                }
+            }
+            __syncthreads();
+            for (int it = 2; it <= degree; ++it) {
+                const double sn = 1.0 / (tau - sig);
+                const double f1 = 2.0 * sn / e, f2 = sig * sn;
+                if (MODE == 1) {
+                    if (it == degree) sp_filter_step_lds<CG, true>(g, lg, Y, X, ylds, c0, f1, f2);
+                    else sp_filter_step_lds<CG, false>(g, lg, Y, X, ylds, c0, f1, f2);
+                } else {
+                    if (it == degree) sp_filter_step<CG, true>(g, Y, X, ylds, c0, f1, f2);
+                    else sp_filter_step<CG, false>(g, Y, X, ylds, c0, f1, f2);
+                }
+                ++matvecs;
+                double* sw = X;
+                X = Y;
+                Y = sw;
+                sig = sn;
+            }
+            U = Y;  // the filtered block
+            V = X;
         }
-        __syncthreads();
-        for (int it = 2; it <= degree; ++it) {
-            const double sn = 1.0 / (tau - sig);
-            const double f1 = 2.0 * sn / e, f2 = sig * sn;
-            if (it == degree) sp_filter_step<CG, true>(g, Y, X, ylds, c0, f1, f2);
-            else sp_filter_step<CG, false>(g, Y, X, ylds, c0, f1, f2);
-            ++matvecs;
-            double* sw = X;
-            X = Y;
-            Y = sw;
-            sig = sn;
-        }
-        U = Y;  // the filtered block
-        V = X;
         SP_T(t_filter);
     }
     // results: eigenvalues ascending, embedding rows v_i / sqrt(d_i), first kw columns
@@ -858,10 +1080,19 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
     const int degree = a->degree > 1 ? a->degree : 24, max_outer = a->max_outer > 0 ? a->max_outer : 60;
     const double tol = a->tol > 0.0 ? a->tol : 1e-9;
     {
-        // columns staged per filter pass: as many as fit 150 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950)
+        // columns staged per filter pass: as many as fit 150 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950);
+        // with the graph in the LDS too (58 B per row) when that fits with at least two columns, the block alone otherwise
         constexpr size_t LDS_MAX = 153600;
-        const int cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
-        const size_t lds = (size_t)(n + 1) * cg * 8;
+        int cg = 0, mode = 1;
+        if (sm::sp_resident_bytes(n) <= LDS_MAX && (size_t)n * 64 <= 65535) {  // (16-bit byte offsets of the rows)
+            cg = 8; mode = 2; }
+        for (int c : {8, 4, 2})
+            if (!cg && sm::sp_lds_graph_bytes(n, c) <= LDS_MAX) cg = c;
+        if (!cg) {
+            mode = 0;
+            cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
+        }
+        const size_t lds = mode == 2 ? sm::sp_resident_bytes(n) : mode == 1 ? sm::sp_lds_graph_bytes(n, cg) : (size_t)(n + 1) * cg * 8;
         auto launch = [&](auto kern) {
             static bool once = false;  // per instantiation (the lambda is instantiated per kernel type)
             if (!once) {
@@ -874,11 +1105,20 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
                                a->residuals, a->info);
         };
         // (bytes: what ONE block mat-vec moves - the block read and written + the adjacency lists; the count of mat-vecs is data-dependent)
-        sm::TapGuard tap2(stream, cg == 8 ? "spectral_embed_kernel<8>" : cg == 4 ? "spectral_embed_kernel<4>" : "spectral_embed_kernel<2>", 0.0,
-                          Bd * (2.0 * nd * 8 * 8 + 2.0 * nd * m * 4));
-        if (cg == 8) launch(&sm::spectral_embed_kernel<8>);
-        else if (cg == 4) launch(&sm::spectral_embed_kernel<4>);
-        else launch(&sm::spectral_embed_kernel<2>);
+        static const char* const names[3][3] = {{"spectral_embed_kernel<8, 0>", "spectral_embed_kernel<4, 0>", "spectral_embed_kernel<2, 0>"},
+                                                {"spectral_embed_kernel<8, 1>", "spectral_embed_kernel<4, 1>", "spectral_embed_kernel<2, 1>"},
+                                                {"spectral_embed_kernel<8, 2>", "", ""}};
+        sm::TapGuard tap2(stream, names[mode][cg == 8 ? 0 : cg == 4 ? 1 : 2], 0.0, Bd * (2.0 * nd * 8 * 8 + 2.0 * nd * m * 4));
+        if (mode == 2) launch(&sm::spectral_embed_kernel<8, 2>);
+        else if (mode == 1) {
+            if (cg == 8) launch(&sm::spectral_embed_kernel<8, 1>);
+            else if (cg == 4) launch(&sm::spectral_embed_kernel<4, 1>);
+            else launch(&sm::spectral_embed_kernel<2, 1>);
+        } else {
+            if (cg == 8) launch(&sm::spectral_embed_kernel<8, 0>);
+            else if (cg == 4) launch(&sm::spectral_embed_kernel<4, 0>);
+            else launch(&sm::spectral_embed_kernel<2, 0>);
+        }
     }
     sm::TapGuard tap3(stream, "kmeans_embed_kernel", 0.0, Bd * nd * kw * 8 * a->n_sizes);
     hipLaunchKernelGGL(sm::kmeans_embed_kernel, dim3(a->n_sizes, B), dim3(sm::SP_THREADS), 0, st, emb, n, kw, sizes, a->n_sizes,

@@ -152,6 +152,32 @@ def gather_rows(rows_local: torch.Tensor, idx_local: Sequence[int], n_total: int
     return out
 
 
+def gather_bytes(payload: bytes, comm, device="cpu") -> List[bytes]:
+    """One variable-length byte string per rank -> the list of all ranks' strings, in rank order, on every rank: an all-gather of the
+    lengths, then one of the payloads padded to the longest (device tensors under RCCL, host tensors under gloo)."""
+    n = torch.tensor([len(payload)], dtype=torch.int64, device=device)
+    lens = comm.all_gather(n).reshape(-1).tolist()
+    buf = torch.zeros(max(max(lens), 1), dtype=torch.uint8, device=device)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    allb = comm.all_gather(buf).cpu().numpy()
+    return [allb[r, :lens[r]].tobytes() for r in range(comm.world_size)]
+
+
+def gather_dicts(local: dict, comm, device="cpu") -> dict:
+    """{key: JSON-able value} of every rank's shard -> the union on every rank (pseudo-mask generation, BASELINE.json configs[4]: the
+    file list is sharded like the evaluator's images, the per-file run-length codes are the only thing exchanged).  A key two ranks
+    both hold is an error: shards are disjoint."""
+    import json
+    out: dict = {}
+    for r, b in enumerate(gather_bytes(json.dumps(local, separators=(",", ":")).encode(), comm, device)):
+        part = json.loads(b.decode()) if b else {}
+        dup = set(part) & set(out)
+        assert not dup, f"rank {r} repeats {sorted(dup)[:3]}"
+        out.update(part)
+    return out
+
+
 def average_rows(rows: np.ndarray) -> dict:
     """metrics/average_meter.py:12-16 over images in index order: float32 running sums for the tensor-derived
     values, Python-float (fp64) sums for the S-measure (SMeasure returns ``Q.item()``), evaluator.pyc@L55-99."""

@@ -125,9 +125,21 @@ class MaskGenerator:
     # ---- mask_generator.pyc@L232-252 --------------------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, p_images: Sequence[str], remove_long_masks: bool = True, remove_small_large_masks: bool = False,
-                 encode: Optional[bool] = True) -> Dict[str, object]:
+                 encode: Optional[bool] = True, comm=None) -> Dict[str, object]:
         """Candidates and vote of one batch are queued on one stream of a ring and read back ``streams`` batches later: images are
-        independent, so the result per file is what the reference's extract-everything-then-vote order gives."""
+        independent, so the result per file is what the reference's extract-everything-then-vote order gives.  ``comm`` (a
+        ``distributed.TorchDistComm``): this rank takes files rank, rank + W, ... of the list (``shard_indices``, as the evaluator
+        shards its images), and every rank returns the codes of ALL files (one all-gather of the encoded shards at the end)."""
+        if comm is not None and comm.world_size > 1:
+            from .distributed import gather_dicts, shard_indices
+            assert encode, "the gather exchanges run-length codes"
+            p_images = list(p_images)
+            names = [p.split("/")[-1] for p in p_images]
+            assert len(set(names)) == len(names), "file names must be unique (they key the result)"
+            mine = self([p_images[i] for i in shard_indices(len(p_images), comm.rank, comm.world_size)], remove_long_masks,
+                        remove_small_large_masks, True)
+            merged = gather_dicts(mine, comm, self.device)
+            return {n: merged[n] for n in names}  # the list's order, whatever the sharding
         from collections import deque
         from .streams import StreamRing
         ring = StreamRing(self.device, self.streams)

@@ -169,3 +169,36 @@ def test_pin_rank_cores_uses_the_topology(tmp_path, monkeypatch):
     finally:
         os.sched_setaffinity(0, cur)
         os.environ.pop("SM_RANK_CORES_PINNED", None)
+
+
+def _dict_worker(rank, world, port, n, outdir):
+    import json
+    import torch.distributed as dist
+    from selfmask_amd.mask_generator import rle_encode
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = D.TorchDistComm()
+    local = {f"img_{i}.png": rle_encode(_mask(i)) for i in D.shard_indices(n, rank, world)}
+    with open(os.path.join(outdir, f"merged_{rank}.json"), "w") as f:
+        json.dump(D.gather_dicts(local, comm), f, sort_keys=True)
+    dist.destroy_process_group()
+
+
+def _mask(i):
+    rng = np.random.Generator(np.random.PCG64(i))
+    return (rng.random((7 + i % 5, 9 + i % 3)) < 0.4).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [9, 2, 1, 0])
+def test_two_rank_gloo_gather_of_encoded_pseudo_masks(tmp_path, n):
+    """configs[4] across ranks: the file list sharded rank-strided, every rank ends with every file's run-length code - ragged payloads,
+    a rank with nothing (n < world), nothing at all."""
+    import json
+    from selfmask_amd.mask_generator import rle_decode
+    world = 2
+    mp.spawn(_dict_worker, args=(world, _free_port(), n, str(tmp_path)), nprocs=world, join=True)
+    merged = [json.load(open(tmp_path / f"merged_{r}.json")) for r in range(world)]
+    assert merged[0] == merged[1] and sorted(merged[0]) == sorted(f"img_{i}.png" for i in range(n))
+    for i in range(n):
+        assert np.array_equal(rle_decode(merged[0][f"img_{i}.png"]), _mask(i))
+    assert D.gather_dicts({"a": 1}, D.SingleComm()) == {"a": 1}
