@@ -22,24 +22,60 @@ constexpr int SP_WAVES = SP_THREADS / 64;
 constexpr int SP_MAXM = 32;      // neighbours kept per point (n_neighbors - 1)
 constexpr int SP_MAXN = 8192;    // points per image
 
+__device__ __forceinline__ double shfl_d(double v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __shfl((unsigned)u, src, 64), hi = __shfl((unsigned)(u >> 32), src, 64);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double shfl_xor_d(double v, int o) {
     const unsigned long long u = __double_as_longlong(v);
     const unsigned lo = __shfl_xor((unsigned)u, o, 64), hi = __shfl_xor((unsigned)(u >> 32), o, 64);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-// sum of NV values over the workgroup, in a fixed order (butterfly inside a wave, then the waves in index order);
+// Sum over the 64 lanes, every lane returning the same total: lane ^ 1, ^ 2 by DPP quad permutes, then the other quad of the eight
+// (row_half_mirror: the quads are uniform by then), the other half of the row (row_mirror), the neighbouring row and the other half of
+// the wave by v_permlane16_swap / v_permlane32_swap of the value with itself - no trip through the LDS (six ds_bpermute round trips
+// per value made a 36-value block sum 24 k cycles: 60 % of a Cholesky-QR pass).  Both operands of every add are the same two
+// numbers on the lanes that exchange them, so all lanes agree bit for bit.
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double sum8_d(double x) {  // over each aligned group of eight lanes
+    x += dpp_d<0xB1>(x);   // quad_perm [1, 0, 3, 2]
+    x += dpp_d<0x4E>(x);   // quad_perm [2, 3, 0, 1]
+    x += dpp_d<0x141>(x);  // row_half_mirror
+    return x;
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+    x = sum8_d(x);
+    x += dpp_d<0x140>(x);  // row_mirror
+    const unsigned long long u = __double_as_longlong(x);
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        x = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+    const unsigned long long w = __double_as_longlong(x);
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)w, (unsigned)w, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(w >> 32), (unsigned)(w >> 32), false, false);
+        x = __longlong_as_double(((unsigned long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((unsigned long long)hi[1] << 32) | lo[1]);
+    }
+    return x;
+}
+
+// sum of NV values over the workgroup, in a fixed order (the tree of wave_sum_d inside a wave, then the waves in index order);
 // every thread returns with the totals in v.  `scratch` holds (SP_WAVES + 1) * NV doubles.
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* scratch) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        double x = v[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += shfl_xor_d(x, o);
-        v[i] = x;
-    }
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_d(v[i]);
     __syncthreads();  // scratch may still be read from a previous call
     if (lane == 0)
 #pragma unroll
@@ -335,57 +371,73 @@ __device__ __forceinline__ void sp_filter_step_lds(const SpGraph& g, const SpLds
     }
 }
 
-// And with BOTH blocks of the recurrence in the LDS beside the graph (n <= 825: 2 (n + 1) x 8 doubles + 58 B per row within 150 KB -
-// the 28 x 28 x 4 = 784 points of a 224^2 image): a whole filter runs without touching memory - the step gathers from yl, rewrites
-// xl in place (each lane its own element), and the two exchange roles; only the last step writes, to the block in memory.  With two
-// waves per SIMD nothing hid the memory round trips of the staged forms (SQ counters: 69 % of the wave cycles waiting, 3 % of them on
-// the LDS; ~50 k cycles per step, profiles/r04_spectral_sq_counters.txt).  Same sums in the same order: bit-identical results.
-constexpr size_t sp_resident_offset(int n) { return (size_t)2 * (n + 1) * SP_B * 8; }  // then isd (n + 1, the last one 0) | nb | len
-__host__ __device__ constexpr size_t sp_resident_bytes(int n) {
-    return ((((sp_resident_offset(n) + (size_t)(n + 1) * 8 + 15) & ~(size_t)15) + (size_t)n * SP_PAD * 2 + (size_t)n * 2) + 15) & ~(size_t)15;
+// And with BOTH blocks of the recurrence in the LDS beside the graph (MODE 2; n = 784, the 28 x 28 x 4 points of a 224^2 image, with
+// 10 neighbours: 144 KB of the 150): the whole solve runs without touching memory - a filter step gathers from yl, rewrites xl in
+// place (each lane its own elements), and the two exchange roles.  With two waves per SIMD nothing hid the memory round trips of the
+// staged forms (SQ counters: 69 % of the wave cycles waiting, 3 % of them on the LDS; ~50 k cycles per step,
+// profiles/r04_spectral_sq_counters.txt).  Here the graph is a CSR of 16-bit BYTE offsets of the neighbours' rows, lists padded to a
+// multiple of four with the zero row, rows SORTED by list length (longest first): an item = a row and two columns (one 16-B read per
+// neighbour), a wave walks its 16 rows in chunks of four neighbours up to the length of its first (longest) row - k-NN graphs have a
+// long tail (mean 13, maximum 60-70 entries at n = 784), and both the padding of every list to 24 and the serial walk of the hubs'
+// tails through memory (33 k cycles for one 71-entry row: the step's critical path) are gone.  Every row's sum still runs in list
+// order (the padding adds + 0.0): the results are bit-identical to the other modes'.
+struct SpResGraph {
+    const unsigned short* ent;   // the lists: byte offsets (row * 64), each list a multiple of 4 entries
+    const unsigned short* ptr4;  // (n) list start / 4, by sorted position
+    const unsigned short* len;   // (n) list length, by sorted position (descending)
+    const unsigned short* row;   // (n) the row at a sorted position
+    const double* isd;           // (n + 1) 1 / sqrt(d) by row; isd[n] = 0
+    unsigned zoff;               // byte offset of the zero row: n * 64
+};
+
+__host__ __device__ constexpr size_t sp_resident_entries(int n, int m) { return (((size_t)(2 * m + 3) * n) + 7) & ~(size_t)7; }  // sum of cnt <= 2 n m
+__host__ __device__ constexpr size_t sp_resident_isd_offset(int n) { return (size_t)2 * (n + 1) * SP_B * 8; }
+__host__ __device__ constexpr size_t sp_resident_ent_offset(int n) { return (sp_resident_isd_offset(n) + (size_t)(n + 1) * 8 + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t sp_resident_bytes(int n, int m) {
+    return (sp_resident_ent_offset(n) + sp_resident_entries(n, m) * 2 + (size_t)3 * n * 2 + 15) & ~(size_t)15;
 }
 
-// (An item here = a row and TWO columns: one 16-B read per neighbour, and the lists hold BYTE offsets of the neighbours' rows - the
-// (row, column) form spent 2.5 address instructions per 8-byte gather and was issue-bound at 38 k cycles per step.)
+// the gathers of one chunk: four neighbours' (two-column) values
+struct SpChunk { double2 v[4]; };
+__device__ __forceinline__ SpChunk sp_gather_chunk(const char* col, uint2 q) {
+    SpChunk c;
+    c.v[0] = *reinterpret_cast<const double2*>(col + (q.x & 0xffffu));
+    c.v[1] = *reinterpret_cast<const double2*>(col + (q.x >> 16));
+    c.v[2] = *reinterpret_cast<const double2*>(col + (q.y & 0xffffu));
+    c.v[3] = *reinterpret_cast<const double2*>(col + (q.y >> 16));
+    return c;
+}
+
+// (Two items per lane at a time - two independent chains of LDS round trips per wave - changed nothing: 17.0 k against 16.7 k cycles
+// per step; the step is not bound by one chain's latency.)
 template <bool LAST>
-__device__ __forceinline__ void sp_filter_step_resident(const SpGraph& g, const SpLdsGraph& lg, const double* yl, double* xl, double c0,
-                                                        double f1, double f2) {
+__device__ __forceinline__ void sp_filter_step_resident(const SpResGraph& rg, int n, const double* yl, double* xl, double c0, double f1,
+                                                        double f2) {
     constexpr int TC = 2, PER_ROW = SP_B / TC;
-    const int total = g.n * PER_ROW;
-    struct Idx { uint4 q[3]; };
-    auto indices = [&](int t) {
-        Idx x;
-        const uint4* p = reinterpret_cast<const uint4*>(lg.nb + (t < total ? t / PER_ROW : 0) * SP_PAD);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) x.q[k] = p[k];
-        return x;
-    };
-    int t = threadIdx.x;
-    Idx x_cur = indices(t);
+    const int total = n * PER_ROW;
+    const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
 #pragma unroll 1
-    for (; t < total; t += SP_THREADS) {
-        const int i = t / PER_ROW, jj = (t % PER_ROW) * TC;
-        const Idx x_next = indices(t + SP_THREADS);
-        const unsigned wq[12] = {x_cur.q[0].x, x_cur.q[0].y, x_cur.q[0].z, x_cur.q[0].w, x_cur.q[1].x, x_cur.q[1].y,
-                                 x_cur.q[1].z, x_cur.q[1].w, x_cur.q[2].x, x_cur.q[2].y, x_cur.q[2].z, x_cur.q[2].w};
+    for (int t = threadIdx.x; t < total; t += SP_THREADS) {
+        const int pos = t / PER_ROW, jj = (t % PER_ROW) * TC;
+        const int i = rg.row[pos], my = (rg.len[pos] + 3) >> 2;
+        const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
+        const int nch = __builtin_amdgcn_readfirstlane(my);  // the wave's first row is its longest
         const char* ycol = reinterpret_cast<const char*>(yl + jj);
-        double2 y[SP_PAD];
-#pragma unroll
-        for (int u = 0; u < SP_PAD; ++u)  // the list entry IS the byte offset of the neighbour's row (padding: the zero row)
-            y[u] = *reinterpret_cast<const double2*>(ycol + ((wq[u >> 1] >> (16 * (u & 1))) & 0xffffu));
         const double2 yo = *reinterpret_cast<const double2*>(yl + i * SP_B + jj);
         const double2 xo = *reinterpret_cast<const double2*>(xl + i * SP_B + jj);
-        const double w = lg.isd[i];
-        const int cnt = lg.len[i];
+        const double w = rg.isd[i];
         double a0 = 0.0, a1 = 0.0;
+        SpChunk cur = sp_gather_chunk(ycol, 0 < my ? e[0] : zz);
+        uint2 qn = 1 < my ? e[1] : zz;
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            SpChunk nxt = cur;
+            if (c + 1 < nch) nxt = sp_gather_chunk(ycol, qn);       // the next chunk's gathers and the index pair after it are in flight
+            const uint2 qnn = c + 2 < my ? e[c + 2] : zz;           // while this chunk is summed
 #pragma unroll
-        for (int u = 0; u < SP_PAD; ++u) { a0 += y[u].x; a1 += y[u].y; }
-        if (cnt > SP_PAD) {
-            const int s0 = g.ptr[i];
-            for (int e = SP_PAD; e < cnt; ++e) {  // hubs: the rest of the list from memory
-                const double2 v = *reinterpret_cast<const double2*>(yl + g.col[s0 + e] * SP_B + jj);
-                a0 += v.x; a1 += v.y;
-            }
+            for (int u = 0; u < 4; ++u) { a0 += cur.v[u].x; a1 += cur.v[u].y; }
+            cur = nxt;
+            qn = qnn;
         }
         const double h = 0.5 * w * w;
         const double l0 = yo.x - h * a0, l1 = yo.y - h * a1;
@@ -394,7 +446,6 @@ __device__ __forceinline__ void sp_filter_step_resident(const SpGraph& g, const 
         xn.y = (l1 - c0 * yo.y) * f1 - f2 * xo.y;
         if (LAST) { xn.x = xn.x / w; xn.y = xn.y / w; }  // back to the symmetric variables on the way out (last step only)
         *reinterpret_cast<double2*>(xl + i * SP_B + jj) = xn;
-        x_cur = x_next;
     }
     __syncthreads();
 }
@@ -428,39 +479,35 @@ __device__ __forceinline__ void sp_apply_sym(const SpGraph& g, const double* __r
 }
 
 // Out = L In with both blocks and the graph in the LDS (MODE 2): the same products isd[nb] * In[nb] summed in list order (the padding
-// adds isd[n] * In[n] = 0 * 0), a row and two columns per lane
-__device__ __forceinline__ void sp_apply_sym_resident(const SpGraph& g, const SpLdsGraph& lg, const double* in, double* out) {
+// adds isd[n] * In[n] = 0 * 0)
+__device__ __forceinline__ void sp_apply_sym_resident(const SpResGraph& rg, int n, const double* in, double* out) {
     constexpr int TC = 2, PER_ROW = SP_B / TC;
-    const int total = g.n * PER_ROW;
+    const int total = n * PER_ROW;
+    const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
+    const char* isdb = reinterpret_cast<const char*>(rg.isd);
 #pragma unroll 1
     for (int t = threadIdx.x; t < total; t += SP_THREADS) {
-        const int i = t / PER_ROW, jj = (t % PER_ROW) * TC;
-        const uint4* p = reinterpret_cast<const uint4*>(lg.nb + i * SP_PAD);
-        const uint4 q0 = p[0], q1 = p[1], q2 = p[2];
-        const unsigned wq[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+        const int pos = t / PER_ROW, jj = (t % PER_ROW) * TC;
+        const int i = rg.row[pos], my = (rg.len[pos] + 3) >> 2;
+        const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
+        const int nch = __builtin_amdgcn_readfirstlane(my);
         const char* col = reinterpret_cast<const char*>(in + jj);
-        const char* isdb = reinterpret_cast<const char*>(lg.isd);
-        double2 y[SP_PAD];
-        double w[SP_PAD];
-#pragma unroll
-        for (int u = 0; u < SP_PAD; ++u) {
-            const unsigned off = (wq[u >> 1] >> (16 * (u & 1))) & 0xffffu;  // byte offset of the neighbour's row: 64 B per row, 8 per isd entry
-            y[u] = *reinterpret_cast<const double2*>(col + off);
-            w[u] = *reinterpret_cast<const double*>(isdb + (off >> 3));
-        }
         const double2 self = *reinterpret_cast<const double2*>(in + i * SP_B + jj);
-        const double wi = lg.isd[i];
-        const int cnt = lg.len[i];
+        const double wi = rg.isd[i];
         double a0 = 0.0, a1 = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const uint2 q = c < my ? e[c] : zz;
+            const unsigned off[4] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16};  // 64 B per row, 8 per isd entry
+            double2 y[4];
+            double w[4];
 #pragma unroll
-        for (int u = 0; u < SP_PAD; ++u) { a0 += w[u] * y[u].x; a1 += w[u] * y[u].y; }
-        if (cnt > SP_PAD) {
-            const int s0 = g.ptr[i];
-            for (int e = SP_PAD; e < cnt; ++e) {
-                const int nbr = g.col[s0 + e];
-                const double2 v = *reinterpret_cast<const double2*>(in + nbr * SP_B + jj);
-                a0 += lg.isd[nbr] * v.x; a1 += lg.isd[nbr] * v.y;
+            for (int u = 0; u < 4; ++u) {
+                y[u] = *reinterpret_cast<const double2*>(col + off[u]);
+                w[u] = *reinterpret_cast<const double*>(isdb + (off[u] >> 3));
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += w[u] * y[u].x; a1 += w[u] * y[u].y; }
         }
         double2 o;
         o.x = self.x - 0.5 * wi * a0;
@@ -475,7 +522,16 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
+#ifdef SM_SPECTRAL_STAMPS  // experiment build: finer marks inside the phases, thread 0 (SP_MARK(k): cycles since the previous mark -> dbg[k])
+#define SP_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_readcyclecounter(); sh.dbg[k] += now_ - sh.dbg_t; sh.dbg_t = now_; } } while (0)
+#else
+#define SP_MARK(k)
+#endif
+
 struct SpShared {
+#ifdef SM_SPECTRAL_STAMPS
+    unsigned long long dbg[16], dbg_t;
+#endif
     double red[(SP_WAVES + 1) * 36];
     double z[SP_B][SP_B];   // R^-1 or the Ritz rotation
     double th[SP_B];
@@ -491,60 +547,79 @@ constexpr int sp_tri(int a, int b) { return a * SP_B - a * (a - 1) / 2 + (b - a)
 // ascending to sh.th, eigenvectors to the columns of sh.z.  (A single thread walking the same matrices in LDS spent a millisecond per
 // call on dependent LDS round trips - three quarters of the eigen-solver's time.)
 __device__ __forceinline__ void jacobi_eig_wave(const double (&sym)[36], SpShared& sh) {
-    const int lane = threadIdx.x & 63;
+    // lane k (of every group of eight: the groups repeat each other) owns row k.  A sweep = the 7 rounds of a round-robin schedule,
+    // each rotating FOUR disjoint pairs at once: the lanes of a pair work out their rotation side by side (one chain of divisions and
+    // square roots per round instead of four - the row-cyclic order paid 28 per sweep, ~1 k cycles each: 105-125 k cycles per call),
+    // the column halves of the four rotations are register arithmetic with v_readlane broadcasts of (c, s), the row halves one lane
+    // exchange per column.  Rotations on disjoint pairs commute, so this is cyclic Jacobi in another order.
+    const int lane = threadIdx.x & 63, k = lane & 7, grp = lane & ~7;
     double a[SP_B], z[SP_B];
 #pragma unroll
     for (int j = 0; j < SP_B; ++j) {
         double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < SP_B; ++k) v = lane == k ? sym[k <= j ? sp_tri(k, j) : sp_tri(j, k)] : v;
+        for (int kk = 0; kk < SP_B; ++kk) v = k == kk ? sym[kk <= j ? sp_tri(kk, j) : sp_tri(j, kk)] : v;
         a[j] = v;
-        z[j] = lane == j ? 1.0 : 0.0;
+        z[j] = k == j ? 1.0 : 0.0;
     }
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0, dia = 0.0;
 #pragma unroll
         for (int j = 0; j < SP_B; ++j) {
-            const double sq = lane < SP_B ? a[j] * a[j] : 0.0;
-            if (lane == j) dia += sq; else off += sq;
+            const double sq = a[j] * a[j];
+            if (k == j) dia += sq; else off += sq;
         }
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) { off += shfl_xor_d(off, o); dia += shfl_xor_d(dia, o); }
+        off = sum8_d(off);
+        dia = sum8_d(dia);
         off = readlane_d(off, 0);
         dia = readlane_d(dia, 0);
         if (off <= 1e-32 * dia) break;
 #pragma unroll
-        for (int p = 0; p < SP_B - 1; ++p)
+        for (int r = 0; r < SP_B - 1; ++r) {
+            const int pk = k == 7 ? r : (k == r ? 7 : (2 * r - k + 7) % 7);  // this row's partner in round r
+            double dk = a[0], apk = a[0];
 #pragma unroll
-            for (int q = p + 1; q < SP_B; ++q) {
-                const double app = readlane_d(a[p], p), aqq = readlane_d(a[q], q), apq = readlane_d(a[q], p);
-                if (apq != 0.0) {  // wave-uniform
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    const double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
-                    const double akp = a[p], akq = a[q];  // columns p, q of every row
-                    a[p] = c * akp - s * akq;
-                    a[q] = s * akp + c * akq;
-#pragma unroll
-                    for (int j = 0; j < SP_B; ++j) {  // rows p, q
-                        const double rp = readlane_d(a[j], p), rq = readlane_d(a[j], q);
-                        if (lane == p) a[j] = c * rp - s * rq;
-                        if (lane == q) a[j] = s * rp + c * rq;
-                    }
-                    const double zkp = z[p], zkq = z[q];
-                    z[p] = c * zkp - s * zkq;
-                    z[q] = s * zkp + c * zkq;
-                }
+            for (int j = 1; j < SP_B; ++j) { dk = k == j ? a[j] : dk; apk = pk == j ? a[j] : apk; }
+            const double dpar = shfl_d(dk, grp | pk);
+            const bool pside = k < pk;
+            const double app = pside ? dk : dpar, aqq = pside ? dpar : dk;
+            double c = 1.0, sn = 0.0;
+            if (apk != 0.0) {
+                const double tau = (aqq - app) / (2.0 * apk);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                c = 1.0 / sqrt(1.0 + t * t);
+                sn = t * c;
             }
+            const int psrc = grp | (pside ? k : pk);  // both lanes of a pair use the rotation its lower row worked out (from A[p][q])
+            c = shfl_d(c, psrc);
+            sn = shfl_d(sn, psrc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // the column halves
+                const int u = i == 0 ? r : (r + i) % 7, v = i == 0 ? 7 : (r - i + 7) % 7;
+                const int p = u < v ? u : v, q = u < v ? v : u;
+                const double ci = readlane_d(c, p), si = readlane_d(sn, p);
+                const double akp = a[p], akq = a[q];
+                a[p] = ci * akp - si * akq;
+                a[q] = si * akp + ci * akq;
+                const double zkp = z[p], zkq = z[q];
+                z[p] = ci * zkp - si * zkq;
+                z[q] = si * zkp + ci * zkq;
+            }
+#pragma unroll
+            for (int j = 0; j < SP_B; ++j) {  // the row halves
+                const double par = shfl_d(a[j], grp | pk);
+                a[j] = pside ? c * a[j] - sn * par : sn * par + c * a[j];
+            }
+        }
     }
     double mine = 0.0;  // the eigenvalue this lane's diagonal entry became
 #pragma unroll
     for (int j = 0; j < SP_B; ++j) mine = lane == j ? a[j] : mine;
     int rank = 0;  // ascending order, ties by index
 #pragma unroll
-    for (int k = 0; k < SP_B; ++k) {
-        const double other = readlane_d(mine, k);
-        rank += (other < mine || (other == mine && k < lane)) ? 1 : 0;
+    for (int kk = 0; kk < SP_B; ++kk) {
+        const double other = readlane_d(mine, kk);
+        rank += (other < mine || (other == mine && kk < lane)) ? 1 : 0;
     }
     if (lane < SP_B) sh.th[rank] = mine;
 #pragma unroll
@@ -571,47 +646,59 @@ __device__ __forceinline__ void chol_qr_pass(double* __restrict__ X, int n, doub
 #pragma unroll
             for (int b = a; b < SP_B; ++b) acc[t++] += x[a] * x[b];
     }
+    SP_MARK(0);
     block_sum<36>(acc, sh.red);
-    if (tid == 0) {  // everything below indexes with compile-time constants: the factor and its inverse live in registers
+    SP_MARK(1);
+    if (tid < 64) {
+        // The factor and its inverse, one COLUMN per lane (lane b = column b; lanes 8.. repeat them): step a of the factorisation needs
+        // column a's finished entries - v_readlane broadcasts - and every entry is the same expression, evaluated in the same order, as
+        // in a serial walk (which had cost ~30 k of a pass's 42 k cycles on one lane: 64 dependent fp64 divisions and square roots).
+        const int b = tid & 7;
         double tr = 0.0;
 #pragma unroll
         for (int a = 0; a < SP_B; ++a) tr += acc[sp_tri(a, a)];
-#pragma unroll
-        for (int a = 0; a < SP_B; ++a) acc[sp_tri(a, a)] += shift * tr;
-        // upper Cholesky factor R (R^T R = G), in place in the packed upper triangle
+        double r[SP_B];  // r[a] = G[a][b], then R[a][b] (a <= b)
 #pragma unroll
         for (int a = 0; a < SP_B; ++a) {
-            double d = acc[sp_tri(a, a)];
+            double v = 0.0;
 #pragma unroll
-            for (int k = 0; k < a; ++k) d -= acc[sp_tri(k, a)] * acc[sp_tri(k, a)];
-            if (!(d > 1e-300 * tr)) { d = fmax(1e-30 * tr, 1e-300); *guard = 1; }
+            for (int bb = a; bb < SP_B; ++bb) v = b == bb ? acc[sp_tri(a, bb)] : v;
+            r[a] = a == b ? v + shift * tr : v;
+        }
+        int bad = 0;
+#pragma unroll
+        for (int a = 0; a < SP_B; ++a) {
+            double sacc = r[a];
+#pragma unroll
+            for (int k = 0; k < a; ++k) sacc -= readlane_d(r[k], a) * r[k];  // R[k][a] R[k][b]
+            double d = readlane_d(sacc, a);
+            if (!(d > 1e-300 * tr)) { d = fmax(1e-30 * tr, 1e-300); bad = 1; }
             const double raa = sqrt(d);
-            acc[sp_tri(a, a)] = raa;
-#pragma unroll
-            for (int b = a + 1; b < SP_B; ++b) {
-                double sacc = acc[sp_tri(a, b)];
-#pragma unroll
-                for (int k = 0; k < a; ++k) sacc -= acc[sp_tri(k, a)] * acc[sp_tri(k, b)];
-                acc[sp_tri(a, b)] = sacc / raa;
-            }
+            r[a] = b == a ? raa : sacc / raa;
         }
-        double inv[36];  // R^-1, upper triangular
+        if (bad && tid == 0) *guard = 1;
+        double iv[SP_B];  // iv[a] = (R^-1)[a][b], zero below the diagonal
+        {
+            double rbb = r[0];
 #pragma unroll
-        for (int b = 0; b < SP_B; ++b) {
-            inv[sp_tri(b, b)] = 1.0 / acc[sp_tri(b, b)];
+            for (int bb = 1; bb < SP_B; ++bb) rbb = b == bb ? r[bb] : rbb;
+            const double inv_bb = 1.0 / rbb;
 #pragma unroll
-            for (int a = b - 1; a >= 0; --a) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int k = a + 1; k <= b; ++k) sacc += acc[sp_tri(a, k)] * inv[sp_tri(k, b)];
-                inv[sp_tri(a, b)] = -sacc / acc[sp_tri(a, a)];
-            }
+            for (int a = 0; a < SP_B; ++a) iv[a] = a == b ? inv_bb : 0.0;
         }
 #pragma unroll
-        for (int a = 0; a < SP_B; ++a)
+        for (int a = SP_B - 2; a >= 0; --a) {
+            double sacc = 0.0;
 #pragma unroll
-            for (int b = 0; b < SP_B; ++b) sh.z[a][b] = a <= b ? inv[sp_tri(a <= b ? a : b, a <= b ? b : a)] : 0.0;
+            for (int k = a + 1; k < SP_B; ++k) sacc += readlane_d(r[a], k) * iv[k];  // R[a][k] (R^-1)[k][b]; k > b adds 0
+            const double v = -sacc / readlane_d(r[a], a);
+            iv[a] = a < b ? v : iv[a];
+        }
+        if (tid < SP_B)
+#pragma unroll
+            for (int a = 0; a < SP_B; ++a) sh.z[a][b] = iv[a];
     }
+    SP_MARK(2);
     __syncthreads();
 #pragma unroll 1
     for (int r = tid; r < n; r += SP_THREADS) {
@@ -629,6 +716,7 @@ __device__ __forceinline__ void chol_qr_pass(double* __restrict__ X, int n, doub
         for (int j = 0; j < SP_B; ++j) X[(int64_t)r * SP_B + j] = y[j];
     }
     __syncthreads();
+    SP_MARK(3);
 }
 
 // Rayleigh-Ritz on the orthonormal block Q with LQ = L Q: H = Q^T LQ, H = Z Theta Z^T, Q <- Q Z, LQ <- LQ Z, residual norms
@@ -648,8 +736,11 @@ __device__ __forceinline__ void rayleigh_ritz(double* __restrict__ Q, double* __
 #pragma unroll
             for (int b = a; b < SP_B; ++b) acc[t++] += 0.5 * (q[a] * l[b] + q[b] * l[a]);  // the symmetric part
     }
+    SP_MARK(4);
     block_sum<36>(acc, sh.red);
+    SP_MARK(5);
     if (tid < 64) jacobi_eig_wave(acc, sh);
+    SP_MARK(6);
     __syncthreads();
     double rs[SP_B];
 #pragma unroll
@@ -680,6 +771,7 @@ __device__ __forceinline__ void rayleigh_ritz(double* __restrict__ Q, double* __
 #pragma unroll
         for (int j = 0; j < SP_B; ++j) sh.res[j] = sqrt(rs[j]);
     __syncthreads();
+    SP_MARK(7);
 }
 
 __device__ __forceinline__ double sp_init_value(int i, int j) {  // splitmix64 of (i, j): uniform in (-1, 1)
@@ -711,21 +803,55 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
     double* U = MODE == 2 ? ylds : blocks_all + (int64_t)img * 2 * n * SP_B;
     double* V = MODE == 2 ? ylds + (size_t)(n + 1) * SP_B : U + (int64_t)n * SP_B;
     int guard = 0, matvecs = 0, outer = 0, converged = 0;
+#ifdef SM_SPECTRAL_STAMPS
+    if (tid == 0) { for (int k = 0; k < 16; ++k) sh.dbg[k] = 0; sh.dbg_t = __builtin_readcyclecounter(); }
+#endif
     SpLdsGraph lg = {nullptr, nullptr, nullptr};
-    if (MODE) {  // the graph beside the block(s): [ylds (n + 1) * CG (x 2: MODE 2) | isd n | (16-B aligned) nb n * SP_PAD u16 | len n u16]
-        const size_t blocks = MODE == 2 ? sp_resident_offset(n) : (size_t)(n + 1) * CG * 8;
-        double* isdl = reinterpret_cast<double*>(reinterpret_cast<char*>(ylds) + blocks);
-        unsigned short* nbl = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ylds) + ((blocks + (size_t)(n + (MODE == 2)) * 8 + 15) & ~(size_t)15));
+    SpResGraph rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    if (MODE == 1) {  // the graph beside the staged block: [ylds (n + 1) * CG | isd n | (16-B aligned) nb n * SP_PAD u16 | len n u16]
+        double* isdl = ylds + (size_t)(n + 1) * CG;
+        unsigned short* nbl = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ylds) + sp_lds_graph_offset(n, CG));
         unsigned short* lenl = nbl + (size_t)n * SP_PAD;
         for (int t = tid; t < n * SP_PAD; t += SP_THREADS) {
             const int i = t / SP_PAD, u = t % SP_PAD;
-            const int nbr = u < g.len[i] ? g.col[g.ptr[i] + u] : n;
-            nbl[t] = (unsigned short)(MODE == 2 ? nbr * (SP_B * 8) : nbr);  // MODE 2: the byte offset of the row ((n + 1) * 64 <= 65535 there)
+            nbl[t] = (unsigned short)(u < g.len[i] ? g.col[g.ptr[i] + u] : n);
         }
         for (int t = tid; t < n; t += SP_THREADS) { lenl[t] = (unsigned short)g.len[t]; isdl[t] = g.isd[t]; }
-        if (MODE == 2 && tid < SP_B) { U[n * SP_B + tid] = 0.0; V[n * SP_B + tid] = 0.0; isdl[n] = 0.0; }  // what a list's padding points at
         lg.nb = nbl; lg.len = lenl; lg.isd = isdl;
     }
+    if (MODE == 2) {  // [U (n + 1) x 8 | V (n + 1) x 8 | isd n + 1 | lists (16-B aligned) | ptr4 n | len n | row n]
+        char* base = reinterpret_cast<char*>(ylds);
+        double* isdl = reinterpret_cast<double*>(base + sp_resident_isd_offset(n));
+        unsigned short* ent = reinterpret_cast<unsigned short*>(base + sp_resident_ent_offset(n));
+        unsigned short* ptr4 = ent + sp_resident_entries(n, m);
+        unsigned short* lenl = ptr4 + n;
+        unsigned short* rowl = lenl + n;
+        unsigned short* cntr = reinterpret_cast<unsigned short*>(V);  // scratch: the list lengths by row (V is not in use yet)
+        for (int t = tid; t < n; t += SP_THREADS) { cntr[t] = (unsigned short)g.len[t]; isdl[t] = g.isd[t]; }
+        __syncthreads();
+        // position of a row in the order (length descending, index ascending) and where its list starts: one pass over all lengths
+        for (int i = tid; i < n; i += SP_THREADS) {
+            const int ci = cntr[i];
+            int rank = 0, p4 = 0;
+            for (int j = 0; j < n; ++j) {
+                const int cj = cntr[j];
+                const bool before = cj > ci || (cj == ci && j < i);
+                rank += before ? 1 : 0;
+                p4 += before ? (cj + 3) >> 2 : 0;
+            }
+            rowl[rank] = (unsigned short)i; lenl[rank] = (unsigned short)ci; ptr4[rank] = (unsigned short)p4;
+        }
+        __syncthreads();
+        for (int t = tid; t < n * 4; t += SP_THREADS) {  // four lanes per list
+            const int pos = t >> 2, i = rowl[pos], cnt = lenl[pos], c4 = (cnt + 3) & ~3, s0 = g.ptr[i];
+            unsigned short* e = ent + (int)ptr4[pos] * 4;
+            for (int u = t & 3; u < c4; u += 4) e[u] = (unsigned short)((u < cnt ? g.col[s0 + u] : n) * (SP_B * 8));
+        }
+        __syncthreads();
+        if (tid < SP_B) { U[n * SP_B + tid] = 0.0; V[n * SP_B + tid] = 0.0; isdl[n] = 0.0; }  // what a list's padding points at
+        rg.ent = ent; rg.ptr4 = ptr4; rg.len = lenl; rg.row = rowl; rg.isd = isdl; rg.zoff = (unsigned)n * (SP_B * 8);
+    }
+    SP_MARK(8);  // graph build
 #ifdef SM_SPECTRAL_STAMPS  // experiment build: shader-clock cycles per phase instead of the residuals (scripts/spectral_stamps.py)
     unsigned long long t_filter = 0, t_chol = 0, t_apply = 0, t_rr = 0, t0 = 0;
 #define SP_T0 t0 = __builtin_readcyclecounter()
@@ -743,16 +869,18 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
     for (outer = 0;; ++outer) {
         // U holds the block to work on (the start block, then the filtered one): orthonormalise, V = L U, Rayleigh-Ritz
         SP_T0;
+        SP_MARK(9);  // (everything between the marked phases)
 #pragma unroll 1
         for (int pass = 0; pass < 3; ++pass) chol_qr_pass(U, n, pass == 0 ? 1e-11 : 0.0, sh, &guard);  // shifted Cholesky QR, three passes
         SP_T(t_chol);
         SP_T0;
-        if (MODE == 2) sp_apply_sym_resident(g, lg, U, V);
+        if (MODE == 2) sp_apply_sym_resident(rg, n, U, V);
         else sp_apply_sym(g, U, V);
         ++matvecs;
         __syncthreads();
         SP_T(t_apply);
         SP_T0;
+        SP_MARK(9);
         rayleigh_ritz(U, V, n, sh);
         SP_T(t_rr);
         double worst = 0.0;
@@ -775,7 +903,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
             double* yl = V;  // X_1
             const double f = sig / e;
             for (int t = tid; t < n * SP_B; t += SP_THREADS) {
-                const double w = lg.isd[t / SP_B], x = xl[t] * w;
+                const double w = rg.isd[t / SP_B], x = xl[t] * w;
                 xl[t] = x;
                 yl[t] = (yl[t] * w - c0 * x) * f;
             }
@@ -783,8 +911,8 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
             for (int it = 2; it <= degree; ++it) {
                 const double sn = 1.0 / (tau - sig);
                 const double f1 = 2.0 * sn / e, f2 = sig * sn;
-                if (it == degree) sp_filter_step_resident<true>(g, lg, yl, xl, c0, f1, f2);
-                else sp_filter_step_resident<false>(g, lg, yl, xl, c0, f1, f2);
+                if (it == degree) sp_filter_step_resident<true>(rg, n, yl, xl, c0, f1, f2);
+                else sp_filter_step_resident<false>(rg, n, yl, xl, c0, f1, f2);
                 ++matvecs;
                 double* sw = xl;
                 xl = yl;
@@ -837,9 +965,12 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         if (res_all) res_all[(int64_t)img * kw + tid] = sh.res[tid];
     }
 #ifdef SM_SPECTRAL_STAMPS
+    __syncthreads();
+    SP_MARK(10);  // results out
     if (tid == 0 && res_all && kw >= 4) {
         double* r = res_all + (int64_t)img * kw;
         r[0] = (double)t_filter; r[1] = (double)t_chol; r[2] = (double)t_apply; r[3] = (double)t_rr;
+        for (int k = 0; k < 16; ++k) emb[k] = (double)sh.dbg[k];  // over the first embedding values
     }
 #endif
     if (tid == 0 && info_all) {
@@ -1084,7 +1215,7 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
         // with the graph in the LDS too (58 B per row) when that fits with at least two columns, the block alone otherwise
         constexpr size_t LDS_MAX = 153600;
         int cg = 0, mode = 1;
-        if (sm::sp_resident_bytes(n) <= LDS_MAX && (size_t)n * 64 <= 65535) {  // (16-bit byte offsets of the rows)
+        if (sm::sp_resident_bytes(n, m) <= LDS_MAX && (size_t)n * 64 <= 65535) {  // (16-bit byte offsets of the rows)
             cg = 8; mode = 2; }
         for (int c : {8, 4, 2})
             if (!cg && sm::sp_lds_graph_bytes(n, c) <= LDS_MAX) cg = c;
@@ -1092,7 +1223,7 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
             mode = 0;
             cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
         }
-        const size_t lds = mode == 2 ? sm::sp_resident_bytes(n) : mode == 1 ? sm::sp_lds_graph_bytes(n, cg) : (size_t)(n + 1) * cg * 8;
+        const size_t lds = mode == 2 ? sm::sp_resident_bytes(n, m) : mode == 1 ? sm::sp_lds_graph_bytes(n, cg) : (size_t)(n + 1) * cg * 8;
         auto launch = [&](auto kern) {
             static bool once = false;  // per instantiation (the lambda is instantiated per kernel type)
             if (!once) {
