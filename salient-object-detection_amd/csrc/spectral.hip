@@ -826,20 +826,47 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         unsigned short* ptr4 = ent + sp_resident_entries(n, m);
         unsigned short* lenl = ptr4 + n;
         unsigned short* rowl = lenl + n;
-        unsigned short* cntr = reinterpret_cast<unsigned short*>(V);  // scratch: the list lengths by row (V is not in use yet)
-        for (int t = tid; t < n; t += SP_THREADS) { cntr[t] = (unsigned short)g.len[t]; isdl[t] = g.isd[t]; }
+        for (int t = tid; t < n; t += SP_THREADS) isdl[t] = g.isd[t];
+        // the rows in the order (length descending, index ascending): a bitonic sort of the keys (0xffff - length) << 16 | row, padded
+        // to a power of two (n <= 825 here: at most 1024, the padding sorts last) - 55 compare-exchange stages of 512 pairs at most.
+        // (Ranking every row against all others, 784 x 784 comparisons, had cost 200 k cycles: 6 % of a solve.)
+        unsigned* keys = reinterpret_cast<unsigned*>(ylds);  // scratch: U and V (128 (n + 1) bytes >= 4 np) are filled after this
+        int np = 2;
+        while (np < n) np <<= 1;
+        for (int t = tid; t < np; t += SP_THREADS) keys[t] = t < n ? ((0xffffu - (unsigned)g.len[t]) << 16) | (unsigned)t : 0xffffffffu;
         __syncthreads();
-        // position of a row in the order (length descending, index ascending) and where its list starts: one pass over all lengths
-        for (int i = tid; i < n; i += SP_THREADS) {
-            const int ci = cntr[i];
-            int rank = 0, p4 = 0;
-            for (int j = 0; j < n; ++j) {
-                const int cj = cntr[j];
-                const bool before = cj > ci || (cj == ci && j < i);
-                rank += before ? 1 : 0;
-                p4 += before ? (cj + 3) >> 2 : 0;
+#pragma unroll 1
+        for (int kk = 2; kk <= np; kk <<= 1)
+#pragma unroll 1
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                const int lo = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), hi = lo | j;
+                if (hi < np) {
+                    const unsigned x = keys[lo], y = keys[hi];
+                    const bool up = (lo & kk) == 0;
+                    if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+                }
+                __syncthreads();
             }
-            rowl[rank] = (unsigned short)i; lenl[rank] = (unsigned short)ci; ptr4[rank] = (unsigned short)p4;
+        // list starts: an exclusive scan of the padded lengths in that order (two positions per lane, wave scan, then the waves)
+        {
+            const int p0 = 2 * tid, p1 = p0 + 1;
+            const int l0 = p0 < n ? (int)(0xffffu - (keys[p0] >> 16)) : 0, l1 = p1 < n ? (int)(0xffffu - (keys[p1] >> 16)) : 0;
+            const int c0 = (l0 + 3) >> 2, c1 = (l1 + 3) >> 2;
+            int inc = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o, 64);
+                if ((tid & 63) >= o) inc += v;
+            }
+            int* wtot = reinterpret_cast<int*>(sh.red);
+            __syncthreads();
+            if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+            const int ex = base + inc - (c0 + c1);
+            if (p0 < n) { rowl[p0] = (unsigned short)(keys[p0] & 0xffffu); lenl[p0] = (unsigned short)l0; ptr4[p0] = (unsigned short)ex; }
+            if (p1 < n) { rowl[p1] = (unsigned short)(keys[p1] & 0xffffu); lenl[p1] = (unsigned short)l1; ptr4[p1] = (unsigned short)(ex + c0); }
         }
         __syncthreads();
         for (int t = tid; t < n * 4; t += SP_THREADS) {  // four lanes per list
