@@ -522,23 +522,24 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=T
     w = Workload(dev, P, S, B, streams=streams, forward_only=True, graph=False)
     model, x = w.model, w.x
 
-    def run(n_steps, ring):
+    def run(n_steps, ring, xb):
         pending = deque()
         ring.fork()
         for _ in range(n_steps):
             with ring.next():
-                pending.append(VT.vote_mask_batch_async(VT.extract_candidate_masks(model, x), winners=True))  # (B, 9, S, S) -> votes
+                pending.append(VT.vote_mask_batch_async(VT.extract_candidate_masks(model, xb), winners=True))  # (B, 9, H, W) -> votes
             if len(pending) >= len(ring.streams):
                 pending.popleft().winners_host()
         while pending:
             pending.popleft().winners_host()
         ring.join()
 
-    def timed(ring):
-        run(warmup + len(ring.streams), ring)
+    def timed(ring, xb=None, n_steps=steps):
+        xb = x if xb is None else xb
+        run(warmup + len(ring.streams), ring, xb)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(steps, ring)
+        run(n_steps, ring, xb)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
@@ -578,6 +579,25 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=T
                            "converged": int(info[:, 2].sum()), "of": B, "max_residual": float(det["residuals"].max())},
            "clusterer_phases_ms_per_batch": phases, "dominant_kernel": dom,
            "parity": "UNPINNED: the reference's `clusterings` module is absent in every form; scikit-learn is the witness (tests)"}
+    # the generator's own operating point: images at their NATIVE size (mask_generator.pyc@L136-200) - DUTS-TR is mostly 400 x 300:
+    # 19 x 25 patches -> 38 x 50 = 1900 points per image (the eigen-solver keeps 2 columns of its blocks in the LDS there)
+    Hn, Wn, Bn = 300, 400, 64
+    from selfmask_amd import synthetic_images
+    xn = torch.from_numpy(synthetic_images(4321, (Bn, 3, Hn, Wn))).to(dev)
+    sn = max(4, steps // 3)
+    dtn = timed(w.ring, xn, sn)
+    tokn = model(xn, encoder_only=True)["patch_tokens"]
+    ghn, gwn = tokn.shape[1:3]
+    featn = VT.upsample_tokens_aligned(tokn.reshape(Bn, ghn * gwn, 384), ghn, gwn, 2).reshape(Bn, 4 * ghn * gwn, 384)
+    _, detn = VT.spectral_cluster(featn, (2, 3, 4), return_details=True)
+    infon = detn["info"].cpu().numpy()
+    res["native_300x400"] = {"workload": f"the same chain on {Hn}x{Wn} images ({4 * ghn * gwn} points each), batch {Bn}, {len(w.ring.streams)} in flight",
+                             "value": round(sn * Bn / dtn, 1), "unit": "images/sec", "steps": sn, "ms_per_step": round(dtn / sn * 1e3, 3),
+                             "encoder_ms_per_batch": round(_event_ms(lambda: model(xn, encoder_only=True), 5, dev), 3),
+                             "spectral_cluster_ms_per_batch": round(_event_ms(lambda: VT.spectral_cluster(featn, (2, 3, 4)), 5, dev), 3),
+                             "clusterer_phases_ms_per_batch": time_taps(lambda: VT.spectral_cluster(featn, (2, 3, 4))),
+                             "eigensolver": {"block_matvecs_mean": round(float(infon[:, 1].mean()), 1), "converged": int(infon[:, 2].sum()), "of": Bn}}
+    del xn, tokn, featn, detn
     if cpu:
         from oracle import cluster_oracle as CO
         f0 = feats[0].cpu().numpy()

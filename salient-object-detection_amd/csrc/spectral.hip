@@ -303,74 +303,6 @@ __device__ __forceinline__ void sp_filter_step(const SpGraph& g, const double* _
     }
 }
 
-// The same step with the GRAPH in the LDS as well (round 4, second pass): the first SP_PAD = 24 neighbours of every row as 16-bit
-// indices padded with the zero row (48 B per row), the list lengths and 1 / sqrt(d) - filled once per solve, the graph does not change.
-// The item loop then has no global load on its critical path (the hand-pipelined global index loads above still cost a memory round
-// trip per item - 4.5 k cycles per item and wave at n = 784): the next item's three 16-B index reads and its X value are in flight
-// while the current item's 24 gathers are summed.  Same sums in the same order as sp_filter_step: bit-identical results.
-constexpr int SP_PAD = 24;
-
-struct SpLdsGraph {
-    const unsigned short* nb;   // n x SP_PAD
-    const unsigned short* len;  // n
-    const double* isd;          // n
-};
-
-__host__ __device__ constexpr size_t sp_lds_graph_offset(int n, int cg) { return (((size_t)(n + 1) * cg * 8 + (size_t)n * 8) + 15) & ~(size_t)15; }
-__host__ __device__ constexpr size_t sp_lds_graph_bytes(int n, int cg) {
-    return ((sp_lds_graph_offset(n, cg) + (size_t)n * SP_PAD * 2 + (size_t)n * 2) + 15) & ~(size_t)15;
-}
-
-template <int CG, bool LAST>
-__device__ __forceinline__ void sp_filter_step_lds(const SpGraph& g, const SpLdsGraph& lg, const double* __restrict__ Yr, double* __restrict__ Xw,
-                                                   double* ylds, double c0, double f1, double f2) {
-    const int total = g.n * CG;
-    struct Idx { uint4 q[3]; };
-    auto indices = [&](int t) {
-        Idx x;
-        const uint4* p = reinterpret_cast<const uint4*>(lg.nb + (t < total ? t / CG : 0) * SP_PAD);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) x.q[k] = p[k];
-        return x;
-    };
-#pragma unroll 1
-    for (int c = 0; c < SP_B; c += CG) {
-        for (int t = threadIdx.x; t < total; t += SP_THREADS) ylds[t] = Yr[(t / CG) * SP_B + c + t % CG];
-        if (threadIdx.x < CG) ylds[total + threadIdx.x] = 0.0;
-        int t = threadIdx.x;
-        double xo_next = t < total ? Xw[(t / CG) * SP_B + c + t % CG] : 0.0;
-        __syncthreads();
-        Idx x_cur = indices(t);
-#pragma unroll 1
-        for (; t < total; t += SP_THREADS) {
-            const int i = t / CG, jj = t % CG, tn = t + SP_THREADS;
-            const double xo = xo_next;
-            if (tn < total) xo_next = Xw[(tn / CG) * SP_B + c + tn % CG];
-            const Idx x_next = indices(tn);
-            const unsigned wq[12] = {x_cur.q[0].x, x_cur.q[0].y, x_cur.q[0].z, x_cur.q[0].w, x_cur.q[1].x, x_cur.q[1].y,
-                                     x_cur.q[1].z, x_cur.q[1].w, x_cur.q[2].x, x_cur.q[2].y, x_cur.q[2].z, x_cur.q[2].w};
-            double y[SP_PAD];
-#pragma unroll
-            for (int u = 0; u < SP_PAD; ++u) y[u] = ylds[(int)((wq[u >> 1] >> (16 * (u & 1))) & 0xffffu) * CG + jj];  // padding: the zero row
-            const double yo = ylds[t], w = lg.isd[i];
-            const int cnt = lg.len[i];
-            asm volatile("" ::: "memory");  // every load above is issued before the first add below
-            double acc = 0.0;
-#pragma unroll
-            for (int u = 0; u < SP_PAD; ++u) acc += y[u];
-            if (cnt > SP_PAD) {
-                const int s0 = g.ptr[i];
-                for (int e = SP_PAD; e < cnt; ++e) acc += ylds[g.col[s0 + e] * CG + jj];  // hubs: the rest of the list from memory
-            }
-            const double ly = yo - (0.5 * w * w) * acc;
-            const double xn = (ly - c0 * yo) * f1 - f2 * xo;
-            Xw[i * SP_B + c + jj] = LAST ? xn / w : xn;
-            x_cur = x_next;
-        }
-        __syncthreads();
-    }
-}
-
 // And with BOTH blocks of the recurrence in the LDS beside the graph (MODE 2; n = 784, the 28 x 28 x 4 points of a 224^2 image, with
 // 10 neighbours: 144 KB of the 150): the whole solve runs without touching memory - a filter step gathers from yl, rewrites xl in
 // place (each lane its own elements), and the two exchange roles.  With two waves per SIMD nothing hid the memory round trips of the
@@ -381,8 +313,12 @@ __device__ __forceinline__ void sp_filter_step_lds(const SpGraph& g, const SpLds
 // long tail (mean 13, maximum 60-70 entries at n = 784), and both the padding of every list to 24 and the serial walk of the hubs'
 // tails through memory (33 k cycles for one 71-entry row: the step's critical path) are gone.  Every row's sum still runs in list
 // order (the padding adds + 0.0): the results are bit-identical to the other modes'.
+// MODE 3 (826 <= n <= ~2100: the 38 x 50 = 1900 points of a 300 x 400 image) keeps the same graph in the LDS beside CG = 4 or 2 COLUMNS
+// of the two blocks: the recurrence never mixes columns, so a filter runs all its steps on one column group after the other, each
+// resident like MODE 2 (the block itself stays in memory and is read and written once per group and filter); the lists take what the
+// launch's 150 KB leave, and a graph that does not fit (decided on the device, where the list lengths are) falls back to MODE 0's steps.
 struct SpResGraph {
-    const unsigned short* ent;   // the lists: byte offsets (row * 64), each list a multiple of 4 entries
+    const unsigned short* ent;   // the lists: byte offsets (row * bytes per row), each list a multiple of 4 entries
     const unsigned short* ptr4;  // (n) list start / 4, by sorted position
     const unsigned short* len;   // (n) list length, by sorted position (descending)
     const unsigned short* row;   // (n) the row at a sorted position
@@ -390,11 +326,15 @@ struct SpResGraph {
     unsigned zoff;               // byte offset of the zero row: n * 64
 };
 
+// layout: [block A (n + 1) x W | block B (n + 1) x W | isd n + 1 (MODE 2 only) | ptr4 n | len n | row n | lists (16-B aligned, to the end)],
+// W doubles per row.  (The lists hold m + in-degree entries per row - a mutual pair twice, every entry weighing 1/2 - 2 n m in all.)
 __host__ __device__ constexpr size_t sp_resident_entries(int n, int m) { return (((size_t)(2 * m + 3) * n) + 7) & ~(size_t)7; }  // sum of cnt <= 2 n m
-__host__ __device__ constexpr size_t sp_resident_isd_offset(int n) { return (size_t)2 * (n + 1) * SP_B * 8; }
-__host__ __device__ constexpr size_t sp_resident_ent_offset(int n) { return (sp_resident_isd_offset(n) + (size_t)(n + 1) * 8 + 15) & ~(size_t)15; }
-__host__ __device__ constexpr size_t sp_resident_bytes(int n, int m) {
-    return (sp_resident_ent_offset(n) + sp_resident_entries(n, m) * 2 + (size_t)3 * n * 2 + 15) & ~(size_t)15;
+__host__ __device__ constexpr size_t sp_resident_isd_offset(int n, int w) { return (size_t)2 * (n + 1) * w * 8; }
+__host__ __device__ constexpr size_t sp_resident_ent_offset(int n, int w) {  // MODE 3 (w < 8) reads 1 / sqrt(d) from memory, once per item
+    return (sp_resident_isd_offset(n, w) + (w == SP_B ? (size_t)(n + 1) * 8 : 0) + (size_t)3 * n * 2 + 15) & ~(size_t)15;
+}
+__host__ __device__ constexpr size_t sp_resident_bytes(int n, int m) {  // MODE 2: room for the longest lists there can be
+    return (sp_resident_ent_offset(n, SP_B) + sp_resident_entries(n, m) * 2 + 15) & ~(size_t)15;
 }
 
 // the gathers of one chunk: four neighbours' (two-column) values
@@ -410,10 +350,10 @@ __device__ __forceinline__ SpChunk sp_gather_chunk(const char* col, uint2 q) {
 
 // (Two items per lane at a time - two independent chains of LDS round trips per wave - changed nothing: 17.0 k against 16.7 k cycles
 // per step; the step is not bound by one chain's latency.)
-template <bool LAST>
+template <int W, bool LAST>
 __device__ __forceinline__ void sp_filter_step_resident(const SpResGraph& rg, int n, const double* yl, double* xl, double c0, double f1,
                                                         double f2) {
-    constexpr int TC = 2, PER_ROW = SP_B / TC;
+    constexpr int TC = 2, PER_ROW = W / TC;
     const int total = n * PER_ROW;
     const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
 #pragma unroll 1
@@ -423,8 +363,8 @@ __device__ __forceinline__ void sp_filter_step_resident(const SpResGraph& rg, in
         const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
         const int nch = __builtin_amdgcn_readfirstlane(my);  // the wave's first row is its longest
         const char* ycol = reinterpret_cast<const char*>(yl + jj);
-        const double2 yo = *reinterpret_cast<const double2*>(yl + i * SP_B + jj);
-        const double2 xo = *reinterpret_cast<const double2*>(xl + i * SP_B + jj);
+        const double2 yo = *reinterpret_cast<const double2*>(yl + i * W + jj);
+        const double2 xo = *reinterpret_cast<const double2*>(xl + i * W + jj);
         const double w = rg.isd[i];
         double a0 = 0.0, a1 = 0.0;
         SpChunk cur = sp_gather_chunk(ycol, 0 < my ? e[0] : zz);
@@ -445,7 +385,7 @@ __device__ __forceinline__ void sp_filter_step_resident(const SpResGraph& rg, in
         xn.x = (l0 - c0 * yo.x) * f1 - f2 * xo.x;
         xn.y = (l1 - c0 * yo.y) * f1 - f2 * xo.y;
         if (LAST) { xn.x = xn.x / w; xn.y = xn.y / w; }  // back to the symmetric variables on the way out (last step only)
-        *reinterpret_cast<double2*>(xl + i * SP_B + jj) = xn;
+        *reinterpret_cast<double2*>(xl + i * W + jj) = xn;
     }
     __syncthreads();
 }
@@ -480,8 +420,9 @@ __device__ __forceinline__ void sp_apply_sym(const SpGraph& g, const double* __r
 
 // Out = L In with both blocks and the graph in the LDS (MODE 2): the same products isd[nb] * In[nb] summed in list order (the padding
 // adds isd[n] * In[n] = 0 * 0)
+template <int W>
 __device__ __forceinline__ void sp_apply_sym_resident(const SpResGraph& rg, int n, const double* in, double* out) {
-    constexpr int TC = 2, PER_ROW = SP_B / TC;
+    constexpr int TC = 2, PER_ROW = W / TC, ISD_SHIFT = W == 8 ? 3 : W == 4 ? 2 : 1;  // row byte offset -> isd byte offset
     const int total = n * PER_ROW;
     const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
     const char* isdb = reinterpret_cast<const char*>(rg.isd);
@@ -492,19 +433,19 @@ __device__ __forceinline__ void sp_apply_sym_resident(const SpResGraph& rg, int 
         const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
         const int nch = __builtin_amdgcn_readfirstlane(my);
         const char* col = reinterpret_cast<const char*>(in + jj);
-        const double2 self = *reinterpret_cast<const double2*>(in + i * SP_B + jj);
+        const double2 self = *reinterpret_cast<const double2*>(in + i * W + jj);
         const double wi = rg.isd[i];
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             const uint2 q = c < my ? e[c] : zz;
-            const unsigned off[4] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16};  // 64 B per row, 8 per isd entry
+            const unsigned off[4] = {q.x & 0xffffu, q.x >> 16, q.y & 0xffffu, q.y >> 16};  // W * 8 B per row, 8 per isd entry
             double2 y[4];
             double w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 y[u] = *reinterpret_cast<const double2*>(col + off[u]);
-                w[u] = *reinterpret_cast<const double*>(isdb + (off[u] >> 3));
+                w[u] = *reinterpret_cast<const double*>(isdb + (off[u] >> ISD_SHIFT));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { a0 += w[u] * y[u].x; a1 += w[u] * y[u].y; }
@@ -512,7 +453,44 @@ __device__ __forceinline__ void sp_apply_sym_resident(const SpResGraph& rg, int 
         double2 o;
         o.x = self.x - 0.5 * wi * a0;
         o.y = self.y - 0.5 * wi * a1;
-        *reinterpret_cast<double2*>(out + i * SP_B + jj) = o;
+        *reinterpret_cast<double2*>(out + i * W + jj) = o;
+    }
+}
+
+// The same for one group of W columns (MODE 3): `xs` holds isd[row] * In[row][c .. c + W) in the LDS (the product every neighbour
+// contributes, rounded as sp_gather2 rounds it), In itself and 1 / sqrt(d) of the row come from memory once per item.
+template <int W>
+__device__ __forceinline__ void sp_apply_sym_cols(const SpResGraph& rg, int n, const double* xs, const double* __restrict__ In,
+                                                  double* __restrict__ Out, int c) {
+    constexpr int TC = 2, PER_ROW = W / TC;
+    const int total = n * PER_ROW;
+    const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
+#pragma unroll 1
+    for (int t = threadIdx.x; t < total; t += SP_THREADS) {
+        const int pos = t / PER_ROW, jj = (t % PER_ROW) * TC;
+        const int i = rg.row[pos], my = (rg.len[pos] + 3) >> 2;
+        const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
+        const int nch = __builtin_amdgcn_readfirstlane(my);
+        const char* col = reinterpret_cast<const char*>(xs + jj);
+        const double2 self = *reinterpret_cast<const double2*>(In + (int64_t)i * SP_B + c + jj);
+        const double wi = rg.isd[i];
+        double a0 = 0.0, a1 = 0.0;
+        SpChunk cur = sp_gather_chunk(col, 0 < my ? e[0] : zz);
+        uint2 qn = 1 < my ? e[1] : zz;
+#pragma unroll 1
+        for (int k = 0; k < nch; ++k) {
+            SpChunk nxt = cur;
+            if (k + 1 < nch) nxt = sp_gather_chunk(col, qn);
+            const uint2 qnn = k + 2 < my ? e[k + 2] : zz;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a0 += cur.v[u].x; a1 += cur.v[u].y; }
+            cur = nxt;
+            qn = qnn;
+        }
+        double2 o;
+        o.x = self.x - 0.5 * wi * a0;
+        o.y = self.y - 0.5 * wi * a1;
+        *reinterpret_cast<double2*>(Out + (int64_t)i * SP_B + c + jj) = o;
     }
 }
 
@@ -782,14 +760,15 @@ __device__ __forceinline__ double sp_init_value(int i, int j) {  // splitmix64 o
     return (double)(long long)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
-// MODE 0: graph in memory, CG columns of the block staged per pass; 1: graph in the LDS too; 2: graph and both blocks in the LDS (CG = 8)
+// MODE 0: graph in memory, CG columns of the block staged per step; 2: graph and both blocks in the LDS for the whole solve (CG = 8);
+// 3: graph and CG columns of both blocks in the LDS for a whole filter, column group after column group
 template <int CG, int MODE>
 __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* __restrict__ ptr_all, const int* __restrict__ len_all,
                                                                     const int* __restrict__ col_all,
                                                                     const double* __restrict__ isd_all, int n, int m, int kw, int degree,
                                                                     int max_outer, double tol, double* __restrict__ blocks_all,
                                                                     double* __restrict__ eig_all, double* __restrict__ emb_all,
-                                                                    double* __restrict__ res_all, int* __restrict__ info_all) {
+                                                                    double* __restrict__ res_all, int* __restrict__ info_all, unsigned lds_bytes) {
     __shared__ SpShared sh;
     extern __shared__ __attribute__((aligned(16))) double ylds[];  // (n + 1) * CG doubles: the gathered block of a filter step + a zero row
     const int tid = threadIdx.x, img = blockIdx.x;
@@ -806,31 +785,25 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
 #ifdef SM_SPECTRAL_STAMPS
     if (tid == 0) { for (int k = 0; k < 16; ++k) sh.dbg[k] = 0; sh.dbg_t = __builtin_readcyclecounter(); }
 #endif
-    SpLdsGraph lg = {nullptr, nullptr, nullptr};
     SpResGraph rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
-    if (MODE == 1) {  // the graph beside the staged block: [ylds (n + 1) * CG | isd n | (16-B aligned) nb n * SP_PAD u16 | len n u16]
-        double* isdl = ylds + (size_t)(n + 1) * CG;
-        unsigned short* nbl = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(ylds) + sp_lds_graph_offset(n, CG));
-        unsigned short* lenl = nbl + (size_t)n * SP_PAD;
-        for (int t = tid; t < n * SP_PAD; t += SP_THREADS) {
-            const int i = t / SP_PAD, u = t % SP_PAD;
-            nbl[t] = (unsigned short)(u < g.len[i] ? g.col[g.ptr[i] + u] : n);
-        }
-        for (int t = tid; t < n; t += SP_THREADS) { lenl[t] = (unsigned short)g.len[t]; isdl[t] = g.isd[t]; }
-        lg.nb = nbl; lg.len = lenl; lg.isd = isdl;
-    }
-    if (MODE == 2) {  // [U (n + 1) x 8 | V (n + 1) x 8 | isd n + 1 | lists (16-B aligned) | ptr4 n | len n | row n]
+    constexpr int RW = MODE == 2 ? SP_B : CG;  // doubles per row of the LDS blocks
+    bool lds_graph = false;
+    double* xa = ylds;                            // MODE 3: the two column-group blocks
+    double* xb = ylds + (size_t)(n + 1) * RW;
+    if (MODE >= 2) {
         char* base = reinterpret_cast<char*>(ylds);
-        double* isdl = reinterpret_cast<double*>(base + sp_resident_isd_offset(n));
-        unsigned short* ent = reinterpret_cast<unsigned short*>(base + sp_resident_ent_offset(n));
-        unsigned short* ptr4 = ent + sp_resident_entries(n, m);
+        double* isdl = reinterpret_cast<double*>(base + sp_resident_isd_offset(n, RW));  // MODE 2 only
+        unsigned short* ptr4 = reinterpret_cast<unsigned short*>(isdl + (MODE == 2 ? n + 1 : 0));
         unsigned short* lenl = ptr4 + n;
         unsigned short* rowl = lenl + n;
-        for (int t = tid; t < n; t += SP_THREADS) isdl[t] = g.isd[t];
+        unsigned short* ent = reinterpret_cast<unsigned short*>(base + sp_resident_ent_offset(n, RW));
+        const int cap4 = (int)((lds_bytes - sp_resident_ent_offset(n, RW)) / 8);  // room for the lists, in groups of four entries
+        if (MODE == 2)
+            for (int t = tid; t < n; t += SP_THREADS) isdl[t] = g.isd[t];
         // the rows in the order (length descending, index ascending): a bitonic sort of the keys (0xffff - length) << 16 | row, padded
-        // to a power of two (n <= 825 here: at most 1024, the padding sorts last) - 55 compare-exchange stages of 512 pairs at most.
-        // (Ranking every row against all others, 784 x 784 comparisons, had cost 200 k cycles: 6 % of a solve.)
-        unsigned* keys = reinterpret_cast<unsigned*>(ylds);  // scratch: U and V (128 (n + 1) bytes >= 4 np) are filled after this
+        // to a power of two (the padding sorts last).  (Ranking every row against all others, 784 x 784 comparisons, had cost 200 k
+        // cycles: 6 % of a solve.)
+        unsigned* keys = reinterpret_cast<unsigned*>(ylds);  // scratch: the blocks (16 RW (n + 1) bytes >= 4 np) are filled after this
         int np = 2;
         while (np < n) np <<= 1;
         for (int t = tid; t < np; t += SP_THREADS) keys[t] = t < n ? ((0xffffu - (unsigned)g.len[t]) << 16) | (unsigned)t : 0xffffffffu;
@@ -839,20 +812,20 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         for (int kk = 2; kk <= np; kk <<= 1)
 #pragma unroll 1
             for (int j = kk >> 1; j > 0; j >>= 1) {
-                const int lo = ((tid & ~(j - 1)) << 1) | (tid & (j - 1)), hi = lo | j;
-                if (hi < np) {
+                for (int pr = tid; pr < np / 2; pr += SP_THREADS) {
+                    const int lo = ((pr & ~(j - 1)) << 1) | (pr & (j - 1)), hi = lo | j;
                     const unsigned x = keys[lo], y = keys[hi];
                     const bool up = (lo & kk) == 0;
                     if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
                 }
                 __syncthreads();
             }
-        // list starts: an exclusive scan of the padded lengths in that order (two positions per lane, wave scan, then the waves)
+        // list starts: an exclusive scan of the padded lengths in that order (a run of positions per lane, wave scan, then the waves)
         {
-            const int p0 = 2 * tid, p1 = p0 + 1;
-            const int l0 = p0 < n ? (int)(0xffffu - (keys[p0] >> 16)) : 0, l1 = p1 < n ? (int)(0xffffu - (keys[p1] >> 16)) : 0;
-            const int c0 = (l0 + 3) >> 2, c1 = (l1 + 3) >> 2;
-            int inc = c0 + c1;
+            const int per = np / SP_THREADS > 2 ? np / SP_THREADS : 2, p0 = tid * per;
+            int mine = 0;
+            for (int u = 0; u < per; ++u) mine += p0 + u < n ? (int)(0xffffu - (keys[p0 + u] >> 16) + 3) >> 2 : 0;
+            int inc = mine;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int v = __shfl_up(inc, o, 64);
@@ -862,21 +835,33 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
             __syncthreads();
             if ((tid & 63) == 63) wtot[tid >> 6] = inc;
             __syncthreads();
-            int base = 0;
-            for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
-            const int ex = base + inc - (c0 + c1);
-            if (p0 < n) { rowl[p0] = (unsigned short)(keys[p0] & 0xffffu); lenl[p0] = (unsigned short)l0; ptr4[p0] = (unsigned short)ex; }
-            if (p1 < n) { rowl[p1] = (unsigned short)(keys[p1] & 0xffffu); lenl[p1] = (unsigned short)l1; ptr4[p1] = (unsigned short)(ex + c0); }
+            int run = inc - mine, total4 = 0;
+            for (int w = 0; w < SP_WAVES; ++w) { run += w < (tid >> 6) ? wtot[w] : 0; total4 += wtot[w]; }
+            lds_graph = total4 <= cap4 && total4 <= 0xffff;  // (MODE 2: always - the host sized the launch for the longest lists)
+#ifdef SM_SPECTRAL_STAMPS
+            if (tid == 0) { sh.dbg[11] = (unsigned long long)total4; sh.dbg[12] = (unsigned long long)cap4; }
+#endif
+            if (lds_graph)
+                for (int u = 0; u < per; ++u)
+                    if (p0 + u < n) {
+                        const unsigned key = keys[p0 + u];
+                        const int len = (int)(0xffffu - (key >> 16));
+                        rowl[p0 + u] = (unsigned short)(key & 0xffffu); lenl[p0 + u] = (unsigned short)len; ptr4[p0 + u] = (unsigned short)run;
+                        run += (len + 3) >> 2;
+                    }
         }
         __syncthreads();
-        for (int t = tid; t < n * 4; t += SP_THREADS) {  // four lanes per list
-            const int pos = t >> 2, i = rowl[pos], cnt = lenl[pos], c4 = (cnt + 3) & ~3, s0 = g.ptr[i];
-            unsigned short* e = ent + (int)ptr4[pos] * 4;
-            for (int u = t & 3; u < c4; u += 4) e[u] = (unsigned short)((u < cnt ? g.col[s0 + u] : n) * (SP_B * 8));
+        if (lds_graph) {
+            for (int t = tid; t < n * 4; t += SP_THREADS) {  // four lanes per list
+                const int pos = t >> 2, i = rowl[pos], cnt = lenl[pos], c4 = (cnt + 3) & ~3, s0 = g.ptr[i];
+                unsigned short* e = ent + (int)ptr4[pos] * 4;
+                for (int u = t & 3; u < c4; u += 4) e[u] = (unsigned short)((u < cnt ? g.col[s0 + u] : n) * (RW * 8));
+            }
+            if (MODE == 2 && tid == 0) isdl[n] = 0.0;  // what a list's padding points at (with the blocks' zero rows)
+            rg.ent = ent; rg.ptr4 = ptr4; rg.len = lenl; rg.row = rowl; rg.isd = MODE == 2 ? isdl : g.isd; rg.zoff = (unsigned)n * (RW * 8);
         }
         __syncthreads();
-        if (tid < SP_B) { U[n * SP_B + tid] = 0.0; V[n * SP_B + tid] = 0.0; isdl[n] = 0.0; }  // what a list's padding points at
-        rg.ent = ent; rg.ptr4 = ptr4; rg.len = lenl; rg.row = rowl; rg.isd = isdl; rg.zoff = (unsigned)n * (SP_B * 8);
+        if (tid < RW) { xa[n * RW + tid] = 0.0; xb[n * RW + tid] = 0.0; }
     }
     SP_MARK(8);  // graph build
 #ifdef SM_SPECTRAL_STAMPS  // experiment build: shader-clock cycles per phase instead of the residuals (scripts/spectral_stamps.py)
@@ -901,8 +886,16 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         for (int pass = 0; pass < 3; ++pass) chol_qr_pass(U, n, pass == 0 ? 1e-11 : 0.0, sh, &guard);  // shifted Cholesky QR, three passes
         SP_T(t_chol);
         SP_T0;
-        if (MODE == 2) sp_apply_sym_resident(rg, n, U, V);
-        else sp_apply_sym(g, U, V);
+        if (MODE == 2) sp_apply_sym_resident<SP_B>(rg, n, U, V);
+        else if (MODE == 3 && lds_graph) {
+#pragma unroll 1
+            for (int c = 0; c < SP_B; c += CG) {  // a column group at a time through the LDS
+                for (int t = tid; t < n * CG; t += SP_THREADS) xa[t] = g.isd[t / CG] * U[(t / CG) * SP_B + c + t % CG];
+                __syncthreads();
+                sp_apply_sym_cols<CG>(rg, n, xa, U, V, c);
+                __syncthreads();
+            }
+        } else sp_apply_sym(g, U, V);
         ++matvecs;
         __syncthreads();
         SP_T(t_apply);
@@ -938,8 +931,8 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
             for (int it = 2; it <= degree; ++it) {
                 const double sn = 1.0 / (tau - sig);
                 const double f1 = 2.0 * sn / e, f2 = sig * sn;
-                if (it == degree) sp_filter_step_resident<true>(rg, n, yl, xl, c0, f1, f2);
-                else sp_filter_step_resident<false>(rg, n, yl, xl, c0, f1, f2);
+                if (it == degree) sp_filter_step_resident<SP_B, true>(rg, n, yl, xl, c0, f1, f2);
+                else sp_filter_step_resident<SP_B, false>(rg, n, yl, xl, c0, f1, f2);
                 ++matvecs;
                 double* sw = xl;
                 xl = yl;
@@ -948,6 +941,34 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
             }
             U = yl;  // the filtered block
             V = xl;
+        } else if (MODE == 3 && lds_graph) {
+            const double f = sig / e, sig1 = sig;
+#pragma unroll 1
+            for (int c = 0; c < SP_B; c += CG) {
+                double* xl = xa;  // X_0 = D^-1/2 U, these columns
+                double* yl = xb;  // X_1
+                for (int t = tid; t < n * CG; t += SP_THREADS) {
+                    const int at = (t / CG) * SP_B + c + t % CG;
+                    const double w = rg.isd[t / CG], x = U[at] * w;
+                    xl[t] = x;
+                    yl[t] = (V[at] * w - c0 * x) * f;
+                }
+                __syncthreads();
+                sig = sig1;
+                for (int it = 2; it <= degree; ++it) {
+                    const double sn = 1.0 / (tau - sig);
+                    const double f1 = 2.0 * sn / e, f2 = sig * sn;
+                    if (it == degree) sp_filter_step_resident<CG, true>(rg, n, yl, xl, c0, f1, f2);
+                    else sp_filter_step_resident<CG, false>(rg, n, yl, xl, c0, f1, f2);
+                    double* sw = xl;
+                    xl = yl;
+                    yl = sw;
+                    sig = sn;
+                }
+                for (int t = tid; t < n * CG; t += SP_THREADS) U[(t / CG) * SP_B + c + t % CG] = yl[t];  // the filtered columns, in place
+                __syncthreads();
+            }
+            matvecs += degree - 1;
         } else {
             double* X = U;
             double* Y = V;
@@ -963,13 +984,8 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
             for (int it = 2; it <= degree; ++it) {
                 const double sn = 1.0 / (tau - sig);
                 const double f1 = 2.0 * sn / e, f2 = sig * sn;
-                if (MODE == 1) {
-                    if (it == degree) sp_filter_step_lds<CG, true>(g, lg, Y, X, ylds, c0, f1, f2);
-                    else sp_filter_step_lds<CG, false>(g, lg, Y, X, ylds, c0, f1, f2);
-                } else {
-                    if (it == degree) sp_filter_step<CG, true>(g, Y, X, ylds, c0, f1, f2);
-                    else sp_filter_step<CG, false>(g, Y, X, ylds, c0, f1, f2);
-                }
+                if (it == degree) sp_filter_step<CG, true>(g, Y, X, ylds, c0, f1, f2);
+                else sp_filter_step<CG, false>(g, Y, X, ylds, c0, f1, f2);
                 ++matvecs;
                 double* sw = X;
                 X = Y;
@@ -1005,7 +1021,11 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         info[0] = outer;
         info[1] = matvecs;
         info[2] = converged;
+#ifdef SM_SPECTRAL_STAMPS
+        info[3] = guard | (lds_graph ? 0 : 2) | (MODE << 4) | (CG << 8);
+#else
         info[3] = guard;
+#endif
     }
 }
 
@@ -1238,19 +1258,17 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
     const int degree = a->degree > 1 ? a->degree : 24, max_outer = a->max_outer > 0 ? a->max_outer : 60;
     const double tol = a->tol > 0.0 ? a->tol : 1e-9;
     {
-        // columns staged per filter pass: as many as fit 150 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950);
-        // with the graph in the LDS too (58 B per row) when that fits with at least two columns, the block alone otherwise
+        // 150 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950).  MODE 2 when graph (longest possible lists)
+        // and both whole blocks fit; else MODE 3 with the most columns (4 or 2) that leave room for the 2 n m list entries plus one
+        // entry of padding per row (lists are padded to fours: the kernel sees the real lengths and falls back to MODE 0's steps when
+        // they do not fit); else MODE 0 with as many staged columns as fit.
         constexpr size_t LDS_MAX = 153600;
-        int cg = 0, mode = 1;
-        if (sm::sp_resident_bytes(n, m) <= LDS_MAX && (size_t)n * 64 <= 65535) {  // (16-bit byte offsets of the rows)
-            cg = 8; mode = 2; }
-        for (int c : {8, 4, 2})
-            if (!cg && sm::sp_lds_graph_bytes(n, c) <= LDS_MAX) cg = c;
-        if (!cg) {
-            mode = 0;
-            cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
-        }
-        const size_t lds = mode == 2 ? sm::sp_resident_bytes(n, m) : mode == 1 ? sm::sp_lds_graph_bytes(n, cg) : (size_t)(n + 1) * cg * 8;
+        int cg = 0, mode = 0;
+        if (sm::sp_resident_bytes(n, m) <= LDS_MAX && (size_t)n * 64 <= 65535) { cg = 8; mode = 2; }  // (16-bit byte offsets of the rows)
+        for (int c : {4, 2})
+            if (!cg && sm::sp_resident_ent_offset(n, c) + (size_t)(2 * m + 1) * n * 2 <= LDS_MAX && (size_t)n * c * 8 <= 65535) { cg = c; mode = 3; }
+        if (!cg) cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
+        const size_t lds = mode == 2 ? sm::sp_resident_bytes(n, m) : mode == 3 ? LDS_MAX : (size_t)(n + 1) * cg * 8;
         auto launch = [&](auto kern) {
             static bool once = false;  // per instantiation (the lambda is instantiated per kernel type)
             if (!once) {
@@ -1260,18 +1278,18 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
             hipLaunchKernelGGL(kern, dim3(B), dim3(sm::SP_THREADS), lds, st, (const int*)(ws + l.inptr), (const int*)(ws + l.inlen),
                                (const int*)(ws + l.incol),
                                (const double*)(ws + l.isd), n, m, kw, degree, max_outer, tol, (double*)(ws + l.blocks), a->eigenvalues, emb,
-                               a->residuals, a->info);
+                               a->residuals, a->info, (unsigned)lds);
         };
         // (bytes: what ONE block mat-vec moves - the block read and written + the adjacency lists; the count of mat-vecs is data-dependent)
-        static const char* const names[3][3] = {{"spectral_embed_kernel<8, 0>", "spectral_embed_kernel<4, 0>", "spectral_embed_kernel<2, 0>"},
-                                                {"spectral_embed_kernel<8, 1>", "spectral_embed_kernel<4, 1>", "spectral_embed_kernel<2, 1>"},
-                                                {"spectral_embed_kernel<8, 2>", "", ""}};
+        static const char* const names[4][3] = {{"spectral_embed_kernel<8, 0>", "spectral_embed_kernel<4, 0>", "spectral_embed_kernel<2, 0>"},
+                                                {"", "", ""},
+                                                {"spectral_embed_kernel<8, 2>", "", ""},
+                                                {"", "spectral_embed_kernel<4, 3>", "spectral_embed_kernel<2, 3>"}};
         sm::TapGuard tap2(stream, names[mode][cg == 8 ? 0 : cg == 4 ? 1 : 2], 0.0, Bd * (2.0 * nd * 8 * 8 + 2.0 * nd * m * 4));
         if (mode == 2) launch(&sm::spectral_embed_kernel<8, 2>);
-        else if (mode == 1) {
-            if (cg == 8) launch(&sm::spectral_embed_kernel<8, 1>);
-            else if (cg == 4) launch(&sm::spectral_embed_kernel<4, 1>);
-            else launch(&sm::spectral_embed_kernel<2, 1>);
+        else if (mode == 3) {
+            if (cg == 4) launch(&sm::spectral_embed_kernel<4, 3>);
+            else launch(&sm::spectral_embed_kernel<2, 3>);
         } else {
             if (cg == 8) launch(&sm::spectral_embed_kernel<8, 0>);
             else if (cg == 4) launch(&sm::spectral_embed_kernel<4, 0>);

@@ -14,8 +14,10 @@ VT.spectral_cluster(x, (2, 3, 4))
 _, det = VT.spectral_cluster(x, (2, 3, 4), return_details=True)
 st, info = det["residuals"].cpu().numpy(), det["info"].cpu().numpy()
 for b in range(4):
+    d = det["embedding"][b].cpu().numpy().reshape(-1)[:16]
+    print(f"    list groups of four: {d[11]:.0f} of {d[12]:.0f} that fit")
     f, c, a, r = st[b]
     tot = f + c + a + r
-    print(f"n = {g * g}, image {b}: {info[b, 0]} filters, {info[b, 1]} block mat-vecs; cycles (100 MHz counter units x clock ratio): filter {f:.0f} ({f / tot:.0%}; "
+    print(f"[info {info[b, 3]:#x}] n = {g * g}, image {b}: {info[b, 0]} filters, {info[b, 1]} block mat-vecs; cycles (100 MHz counter units x clock ratio): filter {f:.0f} ({f / tot:.0%}; "
           f"{f / max(1, info[b, 1] - info[b, 0] - 1):.0f} per step), Cholesky-QR {c:.0f} ({c / tot:.0%}; {c / (3 * (info[b, 0] + 1)):.0f} per pass), "
           f"symmetric mat-vec {a:.0f} ({a / tot:.0%}), Rayleigh-Ritz {r:.0f} ({r / tot:.0%}; {r / (info[b, 0] + 1):.0f} per call)")
