@@ -559,14 +559,17 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=T
     dom_name = next(iter(phases))
     dom = dict(phases[dom_name])
     if dom_name.startswith("spectral_embed_kernel"):
-        # one launch = B workgroups (one per image), each running its image's whole eigen-solve out of LDS; algorithmic bytes of ONE
-        # block mat-vec = the (n x 8) fp64 block read + written + the 2 n m adjacency entries (index + weight folded: 4 B)
-        mv = float(info[:, 1].sum())
-        per_mv = 2.0 * n * 8 * 8 + 2.0 * n * 10 * 4
-        dom.update({"kernel": dom_name, "bound": "latency: one workgroup (8 waves) per image, dependent sparse mat-vecs served from LDS - not an "
-                                                 "HBM or MFMA roofline kernel",
-                    "block_matvecs_per_launch": mv, "lds_bytes_per_block_matvec": per_mv,
-                    "achieved_lds_gbs": round(mv * per_mv / (dom["ms_per_call"] * 1e-3) / 1e9, 1),
+        # one launch = B workgroups (one per image, one per CU), each running its image's whole eigen-solve out of its CU's LDS.  LDS bytes
+        # of ONE block mat-vec (8 columns): every list entry (2 m per row: m out- + m in-neighbours, a mutual pair twice) gathers a row's
+        # 8 doubles and reads its 2-byte offset; the row's own X and Y are read and X written
+        mv, m = float(info[:, 1].sum()), 9
+        per_mv = n * (2.0 * m * 64 + 2.0 * m * 2 + 3 * 64)
+        lds_peak = min(B, 256) * 128 * 2.4  # GB/s: 128 B / clk per CU at 2.4 GHz, on the CUs the launch occupies
+        gbs = mv * per_mv / (dom["ms_per_call"] * 1e-3) / 1e9
+        dom.update({"kernel": dom_name, "bound": "lds: one workgroup (8 waves) per image on its own CU, dependent sparse mat-vecs gathered from the LDS "
+                                                 "(fp64, 16-B random reads) - not an HBM or MFMA roofline kernel",
+                    "block_matvecs_per_launch": mv, "lds_bytes_per_block_matvec": per_mv, "achieved_lds_gbs": round(gbs, 1),
+                    "lds_peak_gbs_on_the_cus_used": round(lds_peak, 1), "lds_frac": round(gbs / lds_peak, 3),
                     "us_per_block_matvec_per_image": round(dom["ms_per_call"] * 1e3 / (mv / B), 3)})
     res = {"workload": f"ViT-S/{P} {S}x{S}, batch={B}: encoder -> bilinear x2 ({n} points x 384) -> spectral clustering k=2,3,4 (10-NN graph, "
                        f"normalised Laplacian, 4 eigenvectors, k-means) -> 9 candidates -> vote",

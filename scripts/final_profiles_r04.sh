@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything DESIGN.md section 5 (round 4) quotes, from ONE box.  Outputs under gpurun_out/final4/ (copied into profiles/ as r04_*).
-# usage: bash scripts/final_profiles_r04.sh [part]   part: a = tests + bench + kernel traces, b = PMC passes + sweeps (default: both)
+# usage: bash scripts/final_profiles_r04.sh [part]   part: a = tests + bench + kernel traces, b = PMC passes + sweeps, c = pseudo-mask path (default: ab)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"; mkdir -p gpurun_out/final4; O=gpurun_out/final4
@@ -33,5 +33,15 @@ for s in 1 2 3 4; do python bench.py --quick --steps 60 --warmup 12 --streams $s
 python bench.py --quick --steps 60 --warmup 12 --forward-only 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('forward-only (no evaluator kernels), 3 streams', d['value'], 'images/s')" >> $O/r04_streams.txt
 python bench.py --quick --steps 60 --warmup 12 --zero-data 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('all-zero weights and images (diagnostic), 3 streams', d['value'], 'images/s')" >> $O/r04_streams.txt
 cat $O/r04_streams.txt; tail -8 $O/pmc_traffic.log
+fi
+if [[ $PART == *c* ]]; then   # the pseudo-mask path: batch x streams sweep, the clusterer by size / filter degree / phase, its SQ counters
+bash scripts/r4_pseudo_batches.sh > /dev/null 2>&1; cp gpurun_out/r4/pseudo_batches.log $O/r04_pseudo_masks_by_batch.log
+bash scripts/r4_spectral_sizes.sh > /dev/null 2>&1; cp gpurun_out/r4/spectral_sizes.log $O/r04_spectral_by_points.log
+python scripts/spectral_degree.py 28 16 > $O/r04_spectral_degree_scenes.log 2>&1
+python scripts/spectral_degree.py bench 128 > $O/r04_spectral_degree_bench.log 2>&1
+for g in 28 32 44; do SM_HIP_LIB=$ROOT/salient-object-detection_amd/lib/libselfmask_hip_spstamps.so python scripts/spectral_stamps.py $g; done > $O/r04_spectral_phases.log 2>&1
+SM_HIP_LIB=$ROOT/salient-object-detection_amd/lib/libselfmask_hip_spstamps.so python scripts/spectral_bench_features.py 4 >> $O/r04_spectral_phases.log 2>&1
+bash scripts/r4_spectral_pmc.sh > /dev/null 2>&1; cp gpurun_out/r4/spectral_sq_counters.txt $O/r04_spectral_sq_counters.txt
+tail -3 $O/r04_pseudo_masks_by_batch.log | cut -c1-200; cat $O/r04_spectral_by_points.log
 fi
 tail -c 600 $O/r04_bench_default.json 2>/dev/null; echo; head -6 $O/r04_kernel_stats.csv 2>/dev/null | cut -c1-150
