@@ -346,6 +346,20 @@ int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int3
 int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, int32_t remove_long,
                            int32_t remove_small_large, int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* Run-length form of B binary masks (B, H, W) uint8 (any non-zero byte = 1) in COCO's order - column-major, pycocotools.mask.encode
+ * (mask_generator.pyc@L232-252 encodes every voted mask with it): starts (B, cap) receives, per image and ascending, the column-major
+ * positions q = x * H + y (1 <= q < H W) whose pixel differs from the one before; info (B, 2) = {number of such positions (also when it
+ * exceeds cap: only the first cap are stored), value of pixel 0}.  The counts of the uncompressed RLE are the differences of
+ * [0, starts..., H W], with a leading 0 when pixel 0 is set.  sizes (device, (B, 2), or NULL): image b is the top-left sizes[b] = {H_b, W_b}
+ * of its H x W plane, and its positions count in H_b. */
+int sm_rle_runs_u8(const uint8_t* masks, int32_t B, int32_t H, int32_t W, const int32_t* sizes, int32_t* starts, int32_t cap, int32_t* info,
+                   void* stream);
+/* sm_vote_masks_batch_u8 for images of DIFFERENT sizes that share planes of H x W (images padded to one token grid, as
+ * make_input_divisible pads each of them): sizes (device, (B, 2)) = {H_b, W_b} per image; candidates count only inside the top-left
+ * H_b x W_b, and the filters use H_b, W_b - image b's results are those of sm_vote_masks_u8 on its cropped candidates.  NULL: as above. */
+int sm_vote_masks_sized_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, const int32_t* sizes, int32_t remove_long,
+                           int32_t remove_small_large, int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* labels (B, n_sizes, lh * lw) int32 of sm_spectral_cluster_f32 (or any clusterer) -> masks (B, sum of cluster_sizes, H, W) uint8 in one
  * launch: sm_labels_to_masks_u8 for every (image, cluster size).  cluster_sizes: HOST array of n_sizes <= 8 entries. */
 int sm_labels_to_masks_batch_u8(const int32_t* labels, int32_t B, int32_t n_sizes, const int32_t* cluster_sizes, int32_t lh, int32_t lw,

@@ -21,10 +21,14 @@ struct VoteBox { int ymin, ymax, xmin, xmax; unsigned area; };
 // 16 pixels per lane: four lanes assemble one 64-pixel bitmap word, a workgroup covers 4096 pixels and issues ONE set of box atomics
 // (a wave per word and five atomics per wave made 784 x 5 atomics per 224^2 mask on five addresses: 1.5 ms per 128 images x 9 masks;
 // this form: see profiles/r04_kernel_stats_pseudo_masks.csv).  VEC: one 16-byte load per lane (every mask starts 16-byte aligned).
+// `sizes` (per image: H_b, W_b; may be null): only the top-left H_b x W_b of an image's H x W planes counts - images of different sizes
+// that pad to one token grid share a batch (the candidates of the padding are ignored, the coordinates are those of the image alone).
 template <bool VEC>
 __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __restrict__ masks, unsigned long long* __restrict__ bits,
-                                                       VoteBox* __restrict__ box, int H, int W, int words, int M) {
+                                                       VoteBox* __restrict__ box, int H, int W, int words, int M,
+                                                       const int* __restrict__ sizes) {
     const int m = blockIdx.y;
+    const int Hb = sizes ? sizes[2 * blockIdx.z] : H, Wb = sizes ? sizes[2 * blockIdx.z + 1] : W;
     const int64_t npx = (int64_t)H * W;
     masks += (int64_t)blockIdx.z * M * npx;  // blockIdx.z: image of a batch (every per-image array is laid end to end)
     bits += (int64_t)blockIdx.z * M * words;
@@ -48,6 +52,16 @@ __global__ __launch_bounds__(256) void vote_pack_kernel(const unsigned char* __r
         } else {
             for (int k = 0; k < 16; ++k)
                 if (p0 + k < npx && src[p0 + k] != 0) b16 |= 1u << k;
+        }
+        if (b16 && (Hb < H || Wb < W)) {  // drop what lies outside the image's own H_b x W_b
+            const int y0 = (int)(p0 / W), x0 = (int)(p0 - (int64_t)y0 * W);
+            if (!(y0 < Hb && x0 + 15 < Wb))  // (inside in one piece: the 16 pixels are in row y0, left of W_b)
+                for (unsigned r = b16; r; r &= r - 1) {
+                    const int k = __ffs(r) - 1;
+                    const int64_t p = p0 + k;
+                    const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+                    if (y >= Hb || x >= Wb) b16 &= ~(1u << k);
+                }
         }
         unsigned long long part = (unsigned long long)b16 << (16 * (lane & 3));
         part |= __shfl_xor(part, 1, 64);
@@ -118,8 +132,10 @@ __global__ __launch_bounds__(256) void vote_pairs_kernel(const unsigned long lon
 
 __global__ __launch_bounds__(64) void vote_finalize_kernel(const VoteBox* __restrict__ box, const unsigned* __restrict__ inter, int M, int H,
                                                           int W, int remove_long, int remove_small_large, int* __restrict__ keep,
-                                                          float* __restrict__ iou, float* __restrict__ row_sums, int* __restrict__ best) {
+                                                          float* __restrict__ iou, float* __restrict__ row_sums, int* __restrict__ best,
+                                                          const int* __restrict__ sizes) {
     const int t = threadIdx.x;
+    if (sizes) { H = sizes[2 * blockIdx.z]; W = sizes[2 * blockIdx.z + 1]; }
     box += (int64_t)blockIdx.z * M; inter += (int64_t)blockIdx.z * M * M; keep += (int64_t)blockIdx.z * M;
     iou += (int64_t)blockIdx.z * M * M; row_sums += (int64_t)blockIdx.z * M; best += blockIdx.z;
     __shared__ int skeep[64];
@@ -172,7 +188,59 @@ __global__ __launch_bounds__(64) void vote_finalize_kernel(const VoteBox* __rest
     }
 }
 
+// Run boundaries of a mask in column-major order (the order of COCO's run-length code): one workgroup per image, every lane a
+// contiguous stretch of positions q = x * H + y - count the changes, scan the counts over the workgroup, write the positions in place.
+__global__ __launch_bounds__(1024) void rle_runs_kernel(const unsigned char* __restrict__ masks, int Hp, int Wp, const int* __restrict__ sizes,
+                                                        int* __restrict__ starts, int cap, int* __restrict__ info) {
+    // the image's own H x W inside planes of Hp x Wp (sizes null: the whole plane); positions count in the image's H
+    const int H = sizes ? sizes[2 * blockIdx.x] : Hp, W = sizes ? sizes[2 * blockIdx.x + 1] : Wp;
+    const int64_t npx = (int64_t)H * W;
+    const unsigned char* m = masks + blockIdx.x * (int64_t)Hp * Wp;
+    int* out = starts + (int64_t)blockIdx.x * cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int np = (int)npx, per = (np + 1023) / 1024, q0 = tid * per, q1 = q0 + per < np ? q0 + per : np;
+    // the pixel before the stretch (pixel 0 itself for the first stretch: no change there)
+    const int qb = q0 > 0 ? q0 - 1 : 0;
+    const bool before = q0 < q1 ? m[(int64_t)(qb % H) * Wp + qb / H] != 0 : false;
+    auto walk = [&](auto&& on_change) {  // (y, x) advance with q: no division per pixel
+        int y = q0 % H, x = q0 / H;
+        bool prev = before;
+        for (int q = q0; q < q1; ++q) {
+            const bool v = m[(int64_t)y * Wp + x] != 0;
+            if (v != prev) on_change(q);
+            prev = v;
+            if (++y == H) { y = 0; ++x; }
+        }
+    };
+    int mine = 0;
+    walk([&](int) { ++mine; });
+    int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    __shared__ int wtot[16];
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int at_out = inc - mine, total = 0;
+    for (int w = 0; w < 16; ++w) { at_out += w < wave ? wtot[w] : 0; total += wtot[w]; }
+    if (tid == 0) { info[2 * blockIdx.x] = total; info[2 * blockIdx.x + 1] = m[0] != 0 ? 1 : 0; }
+    walk([&](int q) {
+        if (at_out < cap) out[at_out] = q;
+        ++at_out;
+    });
+}
+
 }  // namespace sm
+
+extern "C" int sm_rle_runs_u8(const uint8_t* masks, int32_t B, int32_t H, int32_t W, const int32_t* sizes, int32_t* starts, int32_t cap,
+                              int32_t* info, void* stream) {
+    SM_REQUIRE(masks && starts && info, "sm_rle_runs_u8: null pointer");
+    SM_REQUIRE(B > 0 && H > 0 && W > 0 && cap > 0 && (int64_t)H * W < (int64_t)1 << 31, "sm_rle_runs_u8: %d masks of %dx%d, cap %d", B, H, W, cap);
+    hipLaunchKernelGGL(sm::rle_runs_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, masks, H, W, sizes, starts, cap, info);
+    return sm::check_launch("sm_rle_runs_u8");
+}
 
 extern "C" size_t sm_vote_workspace_bytes(int32_t M, int32_t H, int32_t W) {
     if (M <= 0 || M > 64 || H <= 0 || W <= 0) return 0;
@@ -181,7 +249,7 @@ extern "C" size_t sm_vote_workspace_bytes(int32_t M, int32_t H, int32_t W) {
            (((size_t)M * M * 4 + 255) & ~(size_t)255);
 }
 
-extern "C" int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, int32_t remove_long,
+extern "C" int sm_vote_masks_sized_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, const int32_t* sizes, int32_t remove_long,
                                       int32_t remove_small_large, int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace,
                                       size_t workspace_bytes, void* stream) {
     SM_REQUIRE(masks && keep && iou && row_sums && best && workspace, "sm_vote_masks_u8: null pointer");
@@ -199,14 +267,21 @@ extern "C" int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M
     hipLaunchKernelGGL(sm::vote_init_kernel, dim3((M * M + 255) / 256, 1, B), dim3(256), 0, st, box, inter, M);
     const int gx = (words + 63) / 64 < 64 ? (words + 63) / 64 : 64;  // 64 words (4096 pixels) per workgroup and pass
     if (((uintptr_t)masks % 16) == 0 && ((int64_t)H * W) % 16 == 0)
-        hipLaunchKernelGGL(sm::vote_pack_kernel<true>, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M);
+        hipLaunchKernelGGL(sm::vote_pack_kernel<true>, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M, sizes);
     else
-        hipLaunchKernelGGL(sm::vote_pack_kernel<false>, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M);
+        hipLaunchKernelGGL(sm::vote_pack_kernel<false>, dim3(gx, M, B), dim3(256), 0, st, masks, bits, box, H, W, words, M, sizes);
     hipLaunchKernelGGL(sm::vote_pairs_kernel, dim3((words + 255) / 256 < 16 ? (words + 255) / 256 : 16, M * (M + 1) / 2, B), dim3(256), 0, st,
                        bits, inter, M, words);
     hipLaunchKernelGGL(sm::vote_finalize_kernel, dim3(1, 1, B), dim3(64), 0, st, box, inter, M, H, W, remove_long, remove_small_large, keep, iou,
-                       row_sums, best);
+                       row_sums, best, sizes);
     return sm::check_launch("sm_vote_masks_u8");
+}
+
+extern "C" int sm_vote_masks_batch_u8(const uint8_t* masks, int32_t B, int32_t M, int32_t H, int32_t W, int32_t remove_long,
+                                      int32_t remove_small_large, int32_t* keep, float* iou, float* row_sums, int32_t* best, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    return sm_vote_masks_sized_u8(masks, B, M, H, W, nullptr, remove_long, remove_small_large, keep, iou, row_sums, best, workspace,
+                                  workspace_bytes, stream);
 }
 
 extern "C" int sm_vote_masks_u8(const uint8_t* masks, int32_t M, int32_t H, int32_t W, int32_t remove_long, int32_t remove_small_large,

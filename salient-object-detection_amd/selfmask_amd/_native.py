@@ -166,6 +166,8 @@ SYMBOLS = {
     "sm_pick_mask_f32": (C.c_int, [fp, C.c_int64, fp, C.c_int64, fp, fp, C.c_int32, C.c_int32, C.c_int32, fp]),
     "sm_vote_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sm_vote_masks_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),
+    "sm_rle_runs_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, fp, fp, C.c_int32, fp, fp]),
+    "sm_vote_masks_sized_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),
     "sm_vote_masks_batch_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, fp, fp, C.c_size_t, fp]),
     "sm_labels_to_masks_batch_u8": (C.c_int, [fp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                               C.c_int32, fp, fp]),

@@ -7,8 +7,9 @@ its constants are pinned by tests/golden/evaluator_constants.json), DINO branch,
 ``extract_candidate_masks`` (@L136-200): every image at its native resolution, normalised as ``CustomDataset`` does
 (/root/reference/datasets/custom_dataset.py:26-32: RGB, ``to_tensor``, ImageNet mean / std), zero-padded to a multiple of the stride
 (``pad_input_image`` @L124-134 = what ``make_input_divisible`` does inside the encoder), layer-12 tokens -> bilinear x2
-(``align_corners=True``) -> ``clusterer(features, k)`` for k in cluster_sizes -> one-hot -> nearest up-sample -> crop.  Images of one size
-share a batch (the reference's DataLoader runs batch 1; images are independent).  ``vote_mask`` (@L202-230) picks the candidate that
+(``align_corners=True``) -> ``clusterer(features, k)`` for k in cluster_sizes -> one-hot -> nearest up-sample -> crop.  Images that pad to
+one patch grid share a batch (the reference's DataLoader runs batch 1; images are independent, and an image's padded input is the same
+in a batch as alone): the crop to its own H x W happens inside the vote and the run-length kernels.  ``vote_mask`` (@L202-230) picks the candidate that
 agrees most with the others.  ``__call__`` (@L232-252) returns the winner per file name, run-length encoded.
 
 Differences kept on purpose: (1) only the ``"dino"`` feature type - the MoCo-v2 / SwAV ResNet-50 branches need backbones and weights that
@@ -86,27 +87,32 @@ class MaskGenerator:
         return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
 
     def _batches(self, p_images: Sequence[str]):
-        """-> (file names, decoded uint8 RGB arrays) per batch of images of ONE size, at most ``batch_size``: the headers give the
-        sizes, the decode processes of the input pipeline (decode_pool.py) the pixels, a few batches ahead of the device."""
+        """-> (file names, decoded uint8 RGB arrays) per batch of at most ``batch_size`` images that pad to ONE patch grid
+        (``pipeline.native_buckets``: the evaluator's native-resolution buckets): the headers give the sizes, the decode processes of the
+        input pipeline (decode_pool.py) the pixels, a few batches ahead of the device.  Largest buckets first."""
         from PIL import Image
-        from .pipeline import PrefetchingLoader
+        from .pipeline import PrefetchingLoader, native_buckets
         p_images = list(p_images)
-        by_size = defaultdict(list)
-        for i, p in enumerate(p_images):
+        sizes = []
+        for p in p_images:
             with Image.open(p) as im:  # header only
-                by_size[im.size].append(i)
-        batches = [idx[s:s + self.batch_size] for idx in by_size.values() for s in range(0, len(idx), self.batch_size)]
+                sizes.append((im.size[1], im.size[0]))
+        batches = sorted(native_buckets(sizes, self.network.encoder.patch_size, self.batch_size), key=len, reverse=True)
         loader = PrefetchingLoader(_Files(p_images), range(len(p_images)), self.batch_size, workers=self.workers, batches=batches)
         for rgbs, _gts, idx in loader:
             yield [p_images[i].split("/")[-1] for i in idx], rgbs
 
-    def _candidates(self, rgbs) -> torch.Tensor:
-        """decoded images of one size -> (B, sum(cluster_sizes), H, W) uint8 candidates, queued on the current stream"""
+    def _candidates(self, rgbs):
+        """decoded images of one patch grid -> ((B, sum(cluster_sizes), Hp, Wp) uint8 candidates, [(H_b, W_b)]), queued on the current
+        stream: every image zero-padded to the grid's Hp x Wp after normalisation - what ``pad_input_image`` (@L124-134) builds for it
+        alone - and its candidates are the top-left H_b x W_b of its planes"""
         from .pipeline import preprocess_on_device
-        H, W = rgbs[0].shape[:2]
-        x = preprocess_on_device(rgbs, None, self.device, pinned=True, pad_to=(H, W))  # (B, 3, H, W): to_tensor + normalize on the device
+        P = self.network.encoder.patch_size
+        sizes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
+        Hp, Wp = -(-max(h for h, _ in sizes) // P) * P, -(-max(w for _, w in sizes) // P) * P
+        x = preprocess_on_device(rgbs, None, self.device, pinned=True, pad_to=(Hp, Wp))  # to_tensor + normalize + pad, on the device
         cands = VT.extract_candidate_masks(self.network, x, self.cluster_sizes, cluster_type=self.cluster_type, n_neighbors=self.n_neighbors)
-        return cands[None] if cands.dim() == 3 else cands
+        return (cands[None] if cands.dim() == 3 else cands), sizes
 
     @torch.no_grad()
     def extract_candidate_masks(self, p_images: Sequence[str]) -> Dict[str, torch.Tensor]:
@@ -114,8 +120,9 @@ class MaskGenerator:
         feature types per file name; here there is one)."""
         out: Dict[str, torch.Tensor] = {}
         for names, rgbs in self._batches(p_images):
-            for n, c in zip(names, self._candidates(rgbs)):
-                out[n] = c
+            cands, sizes = self._candidates(rgbs)
+            for n, c, (h, w) in zip(names, cands, sizes):
+                out[n] = c[:, :h, :w]
         return out
 
     # ---- mask_generator.pyc@L202-230 --------------------------------------------------------------------------------------------
@@ -147,14 +154,21 @@ class MaskGenerator:
         result: Dict[str, object] = {}
 
         def settle():
-            names, votes = pending.popleft()
-            for n, m in zip(names, votes.winners_host().numpy()):
-                result[n] = rle_encode(m) if encode else m.copy()
+            names, votes, runs = pending.popleft()
+            names, sizes = names
+            if runs is not None:  # the run boundaries were found on the device: two small copies per batch instead of the masks
+                votes.result()    # (raises if a batch came back without a winner)
+                result.update(zip(names, runs.result()))
+            else:
+                for n, m, (h, w) in zip(names, votes.winners_host().numpy(), sizes):
+                    result[n] = m[:h, :w].copy()
 
         for names, rgbs in self._batches(p_images):
             with ring.next():
-                pending.append((names, VT.vote_mask_batch_async(self._candidates(rgbs), remove_long_masks, remove_small_large_masks,
-                                                                winners=True)))
+                cands, sizes = self._candidates(rgbs)
+                votes = VT.vote_mask_batch_async(cands, remove_long_masks, remove_small_large_masks, winners="device" if encode else True,
+                                                 sizes=sizes)
+                pending.append(((names, sizes), votes, VT.rle_runs_async(votes.winners, sizes=sizes) if encode else None))
             if len(pending) >= len(ring.streams):
                 settle()
         while pending:

@@ -71,10 +71,11 @@ class PendingVotes:
         self._host = torch.empty((B, M + 1), dtype=torch.int32, pin_memory=True)
         self._host.copy_(torch.cat([keep, best[:, None]], dim=1), non_blocking=True)
         self.winners = self._winners_host = None
-        if want_winners:
+        if want_winners:  # True: on the device and in page-locked host memory; "device": on the device only
             self.winners = masks[torch.arange(B, device=masks.device), best.long().clamp_(min=0)]
-            self._winners_host = torch.empty(self.winners.shape, dtype=torch.uint8, pin_memory=True)
-            self._winners_host.copy_(self.winners, non_blocking=True)
+            if want_winners != "device":
+                self._winners_host = torch.empty(self.winners.shape, dtype=torch.uint8, pin_memory=True)
+                self._winners_host.copy_(self.winners, non_blocking=True)
         self._done = torch.cuda.Event()
         self._done.record(torch.cuda.current_stream(masks.device))
 
@@ -86,8 +87,10 @@ class PendingVotes:
         return rows
 
     def winners_host(self) -> torch.Tensor:
-        assert self._winners_host is not None, "vote_mask_batch_async(..., winners=True)"
+        assert self.winners is not None, "vote_mask_batch_async(..., winners=True)"
         self._rows()
+        if self._winners_host is None:  # asked for on the device only: copy now
+            self._winners_host = self.winners.cpu()
         return self._winners_host
 
     def result(self):
@@ -103,9 +106,70 @@ class PendingVotes:
         return out
 
 
+class PendingRuns:
+    """Run boundaries of a batch of masks (``rle_runs_async``), queued on a stream: ``result()`` waits for the batch's two small copies
+    and returns one COCO uncompressed run-length dict per mask ({"size": [H, W], "counts": [...]}: column-major runs, zeros first)."""
+
+    def __init__(self, masks: torch.Tensor, cap: int, sizes=None):
+        B, H, W = masks.shape
+        self.masks, self.cap = masks, cap
+        self.sizes = [(int(H), int(W))] * B if sizes is None else [(int(h), int(w)) for h, w in sizes]
+        dev = masks.device
+        self._starts = torch.empty((B, cap), dtype=torch.int32, device=dev)
+        self._info = torch.empty((B, 2), dtype=torch.int32, device=dev)
+        self._sizes_dev = None if sizes is None else _sizes_tensor(self.sizes, (H, W), dev)
+        N.check(N.load().sm_rle_runs_u8(masks.data_ptr(), B, H, W, None if sizes is None else self._sizes_dev.data_ptr(),
+                                        self._starts.data_ptr(), cap, self._info.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                "sm_rle_runs_u8")
+        self._info_h = torch.empty((B, 2), dtype=torch.int32, pin_memory=True)
+        self._info_h.copy_(self._info, non_blocking=True)
+        self._done = torch.cuda.Event()
+        self._done.record(torch.cuda.current_stream(dev))
+
+    def result(self):
+        import numpy as np
+        self._done.synchronize()
+        info = self._info_h.numpy()
+        longest = int(min(info[:, 0].max(initial=0), self.cap))
+        starts = self._starts[:, :max(longest, 1)].cpu().numpy()  # only as many columns as the longest code needs
+        out = []
+        for b in range(info.shape[0]):
+            n, first = int(info[b, 0]), int(info[b, 1])
+            H, W = self.sizes[b]
+            if n > self.cap:  # more runs than the buffer holds (noise-like masks): this one on the host
+                from .mask_generator import rle_encode
+                out.append(rle_encode(self.masks[b, :H, :W].cpu().numpy()))
+                continue
+            bounds = np.concatenate([[0], starts[b, :n], [H * W]])
+            counts = np.diff(bounds).tolist()
+            out.append({"size": [H, W], "counts": ([0] + counts) if first else counts})
+        return out
+
+
+def _sizes_tensor(sizes, plane, dev) -> torch.Tensor:
+    """[(H_b, W_b)] -> (B, 2) int32 on the device, checked against the planes they are cut from"""
+    t = torch.tensor(sizes, dtype=torch.int32).reshape(-1, 2)
+    assert int(t[:, 0].min()) >= 1 and int(t[:, 1].min()) >= 1 and int(t[:, 0].max()) <= plane[0] and int(t[:, 1].max()) <= plane[1], \
+        f"sizes must lie inside the {plane[0]}x{plane[1]} planes"
+    return t.to(dev, non_blocking=True)
+
+
+def rle_runs_async(masks: torch.Tensor, cap: int = 8192, sizes=None) -> PendingRuns:
+    """masks (B, H, W) uint8 on a HIP device (non-zero = set) -> their run-length codes, without waiting (``.result()``).  What
+    ``mask_generator.rle_encode`` computes on the host, from the run boundaries the device finds (``sm_rle_runs_u8``).  ``sizes``
+    [(H_b, W_b)]: image b is the top-left H_b x W_b of its plane."""
+    if not masks.is_cuda:
+        raise RuntimeError("rle_runs_async (MI355X) needs its masks on a HIP device; mask_generator.rle_encode is the host form")
+    m = masks.to(torch.uint8).contiguous()
+    assert m.dim() == 3
+    return PendingRuns(m, int(min(cap, max(1, m.shape[1] * m.shape[2]))), sizes)
+
+
 def vote_mask_batch_async(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False,
-                          winners: bool = False) -> PendingVotes:
-    """``vote_mask`` for B images of one size in one launch sequence on the current stream, without waiting for it."""
+                          winners: bool = False, sizes=None) -> PendingVotes:
+    """``vote_mask`` for B images in one launch sequence on the current stream, without waiting for it.  ``sizes`` [(H_b, W_b)]: the
+    images have different sizes inside planes of one size (padded to one token grid): image b's candidates are the top-left
+    H_b x W_b of its planes, and its result is that of ``vote_mask`` on those crops."""
     if not batch_pred_masks.is_cuda:
         raise RuntimeError("vote_mask_batch (MI355X) needs its candidates on a HIP device; there is no CPU fallback")
     m = batch_pred_masks.to(torch.uint8).contiguous()
@@ -120,10 +184,14 @@ def vote_mask_batch_async(batch_pred_masks: torch.Tensor, remove_long_masks: boo
     iou = torch.empty((B, M, M), dtype=torch.float32, device=dev)
     sums = torch.empty((B, M), dtype=torch.float32, device=dev)
     best = torch.empty(B, dtype=torch.int32, device=dev)
-    N.check(lib.sm_vote_masks_batch_u8(m.data_ptr(), B, M, H, W, int(remove_long_masks), int(remove_small_large_masks), keep.data_ptr(),
-                                       iou.data_ptr(), sums.data_ptr(), best.data_ptr(), ws.data_ptr(), nbytes * B,
-                                       torch.cuda.current_stream(dev).cuda_stream), "sm_vote_masks_batch_u8")
-    return PendingVotes(batch_pred_masks, m, keep, iou, sums, best, winners)
+    sz = None if sizes is None else _sizes_tensor([(int(h), int(w)) for h, w in sizes], (H, W), dev)
+    assert sz is None or sz.shape[0] == B
+    N.check(lib.sm_vote_masks_sized_u8(m.data_ptr(), B, M, H, W, None if sz is None else sz.data_ptr(), int(remove_long_masks),
+                                       int(remove_small_large_masks), keep.data_ptr(), iou.data_ptr(), sums.data_ptr(), best.data_ptr(),
+                                       ws.data_ptr(), nbytes * B, torch.cuda.current_stream(dev).cuda_stream), "sm_vote_masks_sized_u8")
+    pend = PendingVotes(batch_pred_masks, m, keep, iou, sums, best, winners)
+    pend.sizes_dev = sz  # (kept alive until the launches have run)
+    return pend
 
 
 def vote_mask_batch(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, remove_small_large_masks: bool = False):

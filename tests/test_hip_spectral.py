@@ -24,7 +24,7 @@ def run(x, sizes=(2, 3, 4), n_neighbors=10, **kw):
     return labels[0].cpu().numpy(), {k: v[0].cpu().numpy() for k, v in det.items()}
 
 
-@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (1024, 2), (1444, 3), (1936, 4), (3136, 2), (3136, 3), (3136, 4), (6400, 3)])
+@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (1024, 2), (1444, 3), (1936, 4), (2000, 3), (3136, 2), (3136, 3), (3136, 4), (6400, 3)])
 def test_separable_features_come_back_as_the_true_partition(n, k):
     x, truth = blobs(n, k, seed=n + k)
     labels, det = run(x, (k,))
@@ -35,7 +35,9 @@ def test_separable_features_come_back_as_the_true_partition(n, k):
 
 @pytest.mark.parametrize("g,k,seed,nn", [(28, 2, 1, 10), (28, 3, 2, 10), (28, 4, 3, 10), (56, 4, 4, 10), (56, 3, 7, 10), (28, 4, 3, 20), (28, 3, 5, 6),
                                           (32, 3, 11, 10), (38, 3, 8, 10), (44, 4, 13, 10), (38, 2, 10, 24)])
-# (28^2: graph and both blocks of the recurrence in the LDS; 32^2, 38^2, 44^2: the graph in the LDS with 8 / 4 / 2 columns staged per pass; 56^2: neither)
+# (28^2: graph and both blocks of the recurrence in the LDS for the whole solve; 32^2, 38^2: the graph and 4 columns of the blocks per filter,
+# 44^2: 2 columns; 38^2 with 24 neighbours and 56^2: graph in memory.  2 000 points above: admitted to the 2-column plan by the launch, sent back to
+# the graph-in-memory steps by the kernel once it has seen the real list lengths)
 def test_every_stage_against_its_restatement(g, k, seed, nn):
     x, truth = scene(g, k, seed)
     n = g * g
@@ -150,14 +152,14 @@ def test_mask_generator_files_to_encoded_masks(tmp_path):
     m = m.to(DEV)
     rng = np.random.Generator(np.random.PCG64(4))
     paths = []
-    for i, (h, w) in enumerate([(96, 128), (100, 120), (96, 128), (96, 128)]):
+    for i, (h, w) in enumerate([(96, 128), (100, 120), (96, 128), (96, 128), (90, 125)]):  # the last one pads to the first one's 6 x 8 patch grid
         img, _ = synthetic_scene(rng, h, w)
         p = str(tmp_path / f"img_{i}.png")  # PNG: the file holds exactly these pixels
         Image.fromarray(img).save(p)
         paths.append(p)
     gen = MaskGenerator(network=m, device=DEV, batch_size=2)
     out = gen(paths)
-    assert sorted(out) == [f"img_{i}.png" for i in range(4)]
+    assert sorted(out) == [f"img_{i}.png" for i in range(5)]
     for p in paths:
         name = p.split("/")[-1]
         got = rle_decode(out[name])
@@ -176,13 +178,17 @@ def test_mask_generator_files_to_encoded_masks(tmp_path):
     assert np.array_equal(raw["img_0.png"], rle_decode(out["img_0.png"]))
     # the batches the generator feeds the encoder hold exactly what CustomDataset would (to_tensor + normalize), per file
     from selfmask_amd.pipeline import preprocess_on_device
-    seen = {}
+    seen, sizes_seen = {}, []
     for names, rgbs in gen._batches(paths):
-        H, W = rgbs[0].shape[:2]
-        xb = preprocess_on_device(rgbs, None, DEV, pinned=True, pad_to=(H, W)).cpu()
+        Hp, Wp = (-(-max(r.shape[d] for r in rgbs) // patch) * patch for d in (0, 1))
+        xb = preprocess_on_device(rgbs, None, DEV, pinned=True, pad_to=(Hp, Wp)).cpu()
         seen.update(zip(names, xb))
+        sizes_seen.append(sorted({r.shape[:2] for r in rgbs}))
+    assert [(90, 125), (96, 128)] in sizes_seen  # two sizes, one patch grid, one batch
     for p in paths:
-        assert torch.equal(seen[p.split("/")[-1]], gen._load(p))
+        want, got_x = gen._load(p), seen[p.split("/")[-1]]
+        h, w = want.shape[-2:]
+        assert torch.equal(got_x[:, :h, :w], want) and not got_x[:, h:].any() and not got_x[:, :, w:].any()  # zero padding, as alone
     # neither the batch size nor the number of batches in flight changes a result
     for bs, st in ((1, 1), (4, 2)):
         again = MaskGenerator(network=m, device=DEV, batch_size=bs, streams=st)(paths)

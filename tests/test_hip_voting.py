@@ -103,3 +103,56 @@ def test_pack_shapes_bytes_and_batches(h, w):
             one = vote_mask(masks[b].to(DEV), *flags)
             ref = V.vote_mask(binary, *flags)
             assert one[1] == ref[1] and one[2] == ref[2]
+
+
+@pytest.mark.parametrize("h,w", [(224, 224), (300, 400), (37, 53), (1, 9), (5, 1)])
+def test_run_length_codes_from_the_device(h, w):
+    """sm_rle_runs_u8 + the host's differences against mask_generator.rle_encode (COCO's uncompressed form: column-major, zeros first):
+    blobs, a mask starting with a set pixel, all zeros, all ones, any non-zero byte, and more runs than the buffer (host fallback)."""
+    from selfmask_amd.mask_generator import rle_decode, rle_encode
+    from selfmask_amd.voting import rle_runs_async
+    rng = np.random.Generator(np.random.PCG64(h * 7 + w))
+    yy, xx = np.mgrid[:h, :w]
+    blob = ((((yy - h * 0.4) / max(1.0, h * 0.3)) ** 2 + ((xx - w * 0.55) / max(1.0, w * 0.25)) ** 2) <= 1).astype(np.uint8)
+    first = blob.copy()
+    first[0, 0] = 200
+    masks = np.stack([blob, first, np.zeros((h, w), np.uint8), np.full((h, w), 3, np.uint8), (rng.random((h, w)) < 0.5).astype(np.uint8) * 255])
+    for cap in (8192, 4):
+        got = rle_runs_async(torch.from_numpy(masks).to(DEV), cap=cap).result()
+        for b in range(len(masks)):
+            want = rle_encode(masks[b])
+            assert got[b] == want, (b, cap)
+            assert np.array_equal(rle_decode(got[b]), (masks[b] != 0).astype(np.uint8))
+
+
+def test_images_of_different_sizes_in_one_batch():
+    """sm_vote_masks_sized_u8 / sm_rle_runs_u8 with per-image sizes: candidates of 3 images inside planes of 64 x 80 (what sharing a patch
+    grid gives), rubbish outside every image's own H x W - each image's vote and run-length code are those of its cropped candidates alone."""
+    from selfmask_amd.mask_generator import rle_encode
+    from selfmask_amd.voting import rle_runs_async, vote_mask_batch_async
+    rng = np.random.Generator(np.random.PCG64(11))
+    Hp, Wp, sizes = 64, 80, [(64, 80), (49, 66), (60, 80)]
+    yy, xx = np.mgrid[:Hp, :Wp]
+    planes = []
+    for h, w in sizes:
+        ms = []
+        for _ in range(6):
+            cy, cx, ry, rx = rng.uniform(0.2, 0.8) * h, rng.uniform(0.2, 0.8) * w, rng.uniform(0.15, 0.45) * h, rng.uniform(0.15, 0.45) * w
+            m = ((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1).astype(np.uint8)
+            m[h:] = rng.integers(0, 2, size=m[h:].shape)      # what the padding's tokens were clustered into: must not count
+            m[:, w:] = rng.integers(0, 2, size=m[:, w:].shape)
+            ms.append(m)
+        ms.append(np.pad(np.ones((h, 3), np.uint8), ((0, Hp - h), (2, Wp - 5))))  # a full-height stripe of the IMAGE: "long" only by its own H
+        planes.append(np.stack(ms))
+    masks = torch.from_numpy(np.stack(planes))
+    for flags in ((True, False), (True, True), (False, False)):
+        pend = vote_mask_batch_async(masks.to(DEV), *flags, winners=True, sizes=sizes)
+        got, codes = pend.result(), rle_runs_async(pend.winners, sizes=sizes).result()
+        for b, (h, w) in enumerate(sizes):
+            crop = masks[b, :, :h, :w].contiguous()
+            ref_mask, ref_best, ref_map, table, _ = V.vote_mask(crop, *flags)
+            assert got[b][1] == ref_best and got[b][2] == ref_map, (b, flags)
+            assert torch.equal(got[b][0].cpu()[:h, :w], ref_mask)
+            kept = [ref_map[k] for k in range(len(ref_map))]
+            assert torch.equal(pend.iou.cpu()[b][kept][:, kept], table)
+            assert codes[b] == rle_encode(ref_mask.numpy())
