@@ -601,6 +601,34 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=T
                              "clusterer_phases_ms_per_batch": time_taps(lambda: VT.spectral_cluster(featn, (2, 3, 4))),
                              "eigensolver": {"block_matvecs_mean": round(float(infon[:, 1].mean()), 1), "converged": int(infon[:, 2].sum()), "of": Bn}}
     del xn, tokn, featn, detn
+    # and from FILES, as MaskGenerator(...)(p_images) is called: JPEGs of 300-400 px in both directions (every size different: 49 patch
+    # grids share the batches), decoded by the worker processes, run-length codes out
+    import shutil
+    import tempfile
+    from selfmask_amd import datasets as DS
+    from selfmask_amd.decode_pool import default_workers
+    from selfmask_amd.mask_generator import MaskGenerator
+    root = tempfile.mkdtemp(prefix="sm_bench_pm_")
+    try:
+        distinct, repeat = 256, 8
+        DS.write_synthetic_dataset(root, "duts", distinct, seed=11)
+        sub, di = DS.LAYOUTS["duts"][:2]
+        for i in range(distinct, distinct * repeat):
+            os.symlink(os.path.join(root, sub, di, f"{i % distinct:05d}.jpg"), os.path.join(root, sub, di, f"{i:05d}.jpg"))
+        files = [os.path.join(root, sub, di, f"{i:05d}.jpg") for i in range(distinct * repeat)]
+        gen = MaskGenerator(network=model, device=dev, streams=len(w.ring.streams))
+        gen(files[:distinct])  # warm: page cache, workspaces
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        codes = gen(files)
+        dtf = time.perf_counter() - t0
+        res["from_files"] = {"workload": f"MaskGenerator(...)(p_images): {len(files)} JPEG files of 300-400 px ({distinct} distinct, every size "
+                                         f"different) -> decode (worker processes) -> normalise + pad to the patch grid (device) -> chain -> "
+                                         f"run-length codes (device run boundaries); batches of <= {gen.batch_size} per patch grid, "
+                                         f"{gen.streams} in flight",
+                             "value": round(len(files) / dtf, 1), "unit": "images/sec", "files": len(codes), "decode_workers": default_workers()}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
     if cpu:
         from oracle import cluster_oracle as CO
         f0 = feats[0].cpu().numpy()

@@ -319,19 +319,18 @@ __device__ __forceinline__ void sp_filter_step(const SpGraph& g, const double* _
 // launch's 150 KB leave, and a graph that does not fit (decided on the device, where the list lengths are) falls back to MODE 0's steps.
 struct SpResGraph {
     const unsigned short* ent;   // the lists: byte offsets (row * bytes per row), each list a multiple of 4 entries
-    const unsigned short* ptr4;  // (n) list start / 4, by sorted position
-    const unsigned short* len;   // (n) list length, by sorted position (descending)
+    const unsigned short* ptr4;  // (n + 1) list start / 4, by sorted position (lengths descending): list p has ptr4[p + 1] - ptr4[p] chunks
     const unsigned short* row;   // (n) the row at a sorted position
     const double* isd;           // (n + 1) 1 / sqrt(d) by row; isd[n] = 0
     unsigned zoff;               // byte offset of the zero row: n * 64
 };
 
-// layout: [block A (n + 1) x W | block B (n + 1) x W | isd n + 1 (MODE 2 only) | ptr4 n | len n | row n | lists (16-B aligned, to the end)],
+// layout: [block A (n + 1) x W | block B (n + 1) x W | isd n + 1 (MODE 2 only) | ptr4 n + 1 | row n | lists (16-B aligned, to the end)],
 // W doubles per row.  (The lists hold m + in-degree entries per row - a mutual pair twice, every entry weighing 1/2 - 2 n m in all.)
 __host__ __device__ constexpr size_t sp_resident_entries(int n, int m) { return (((size_t)(2 * m + 3) * n) + 7) & ~(size_t)7; }  // sum of cnt <= 2 n m
 __host__ __device__ constexpr size_t sp_resident_isd_offset(int n, int w) { return (size_t)2 * (n + 1) * w * 8; }
 __host__ __device__ constexpr size_t sp_resident_ent_offset(int n, int w) {  // MODE 3 (w < 8) reads 1 / sqrt(d) from memory, once per item
-    return (sp_resident_isd_offset(n, w) + (w == SP_B ? (size_t)(n + 1) * 8 : 0) + (size_t)3 * n * 2 + 15) & ~(size_t)15;
+    return (sp_resident_isd_offset(n, w) + (w == SP_B ? (size_t)(n + 1) * 8 : 0) + (size_t)(2 * n + 1) * 2 + 15) & ~(size_t)15;
 }
 __host__ __device__ constexpr size_t sp_resident_bytes(int n, int m) {  // MODE 2: room for the longest lists there can be
     return (sp_resident_ent_offset(n, SP_B) + sp_resident_entries(n, m) * 2 + 15) & ~(size_t)15;
@@ -339,12 +338,26 @@ __host__ __device__ constexpr size_t sp_resident_bytes(int n, int m) {  // MODE 
 
 // the gathers of one chunk: four neighbours' (two-column) values
 struct SpChunk { double2 v[4]; };
+template <int TC>
+__device__ __forceinline__ double2 sp_load_cols(const char* p) {  // TC = 2: two columns (16 B); TC = 1: one, the other reads as 0
+    if (TC == 2) return *reinterpret_cast<const double2*>(p);
+    double2 v;
+    v.x = *reinterpret_cast<const double*>(p);
+    v.y = 0.0;
+    return v;
+}
+template <int TC>
+__device__ __forceinline__ void sp_store_cols(char* p, double2 v) {
+    if (TC == 2) *reinterpret_cast<double2*>(p) = v;
+    else *reinterpret_cast<double*>(p) = v.x;
+}
+template <int TC>
 __device__ __forceinline__ SpChunk sp_gather_chunk(const char* col, uint2 q) {
     SpChunk c;
-    c.v[0] = *reinterpret_cast<const double2*>(col + (q.x & 0xffffu));
-    c.v[1] = *reinterpret_cast<const double2*>(col + (q.x >> 16));
-    c.v[2] = *reinterpret_cast<const double2*>(col + (q.y & 0xffffu));
-    c.v[3] = *reinterpret_cast<const double2*>(col + (q.y >> 16));
+    c.v[0] = sp_load_cols<TC>(col + (q.x & 0xffffu));
+    c.v[1] = sp_load_cols<TC>(col + (q.x >> 16));
+    c.v[2] = sp_load_cols<TC>(col + (q.y & 0xffffu));
+    c.v[3] = sp_load_cols<TC>(col + (q.y >> 16));
     return c;
 }
 
@@ -353,26 +366,26 @@ __device__ __forceinline__ SpChunk sp_gather_chunk(const char* col, uint2 q) {
 template <int W, bool LAST>
 __device__ __forceinline__ void sp_filter_step_resident(const SpResGraph& rg, int n, const double* yl, double* xl, double c0, double f1,
                                                         double f2) {
-    constexpr int TC = 2, PER_ROW = W / TC;
+    constexpr int TC = W >= 2 ? 2 : 1, PER_ROW = W / TC;
     const int total = n * PER_ROW;
     const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
 #pragma unroll 1
     for (int t = threadIdx.x; t < total; t += SP_THREADS) {
         const int pos = t / PER_ROW, jj = (t % PER_ROW) * TC;
-        const int i = rg.row[pos], my = (rg.len[pos] + 3) >> 2;
+        const int i = rg.row[pos], my = (int)rg.ptr4[pos + 1] - (int)rg.ptr4[pos];
         const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
         const int nch = __builtin_amdgcn_readfirstlane(my);  // the wave's first row is its longest
         const char* ycol = reinterpret_cast<const char*>(yl + jj);
-        const double2 yo = *reinterpret_cast<const double2*>(yl + i * W + jj);
-        const double2 xo = *reinterpret_cast<const double2*>(xl + i * W + jj);
+        const double2 yo = sp_load_cols<TC>(reinterpret_cast<const char*>(yl + i * W + jj));
+        const double2 xo = sp_load_cols<TC>(reinterpret_cast<const char*>(xl + i * W + jj));
         const double w = rg.isd[i];
         double a0 = 0.0, a1 = 0.0;
-        SpChunk cur = sp_gather_chunk(ycol, 0 < my ? e[0] : zz);
+        SpChunk cur = sp_gather_chunk<TC>(ycol, 0 < my ? e[0] : zz);
         uint2 qn = 1 < my ? e[1] : zz;
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             SpChunk nxt = cur;
-            if (c + 1 < nch) nxt = sp_gather_chunk(ycol, qn);       // the next chunk's gathers and the index pair after it are in flight
+            if (c + 1 < nch) nxt = sp_gather_chunk<TC>(ycol, qn);       // the next chunk's gathers and the index pair after it are in flight
             const uint2 qnn = c + 2 < my ? e[c + 2] : zz;           // while this chunk is summed
 #pragma unroll
             for (int u = 0; u < 4; ++u) { a0 += cur.v[u].x; a1 += cur.v[u].y; }
@@ -385,7 +398,7 @@ __device__ __forceinline__ void sp_filter_step_resident(const SpResGraph& rg, in
         xn.x = (l0 - c0 * yo.x) * f1 - f2 * xo.x;
         xn.y = (l1 - c0 * yo.y) * f1 - f2 * xo.y;
         if (LAST) { xn.x = xn.x / w; xn.y = xn.y / w; }  // back to the symmetric variables on the way out (last step only)
-        *reinterpret_cast<double2*>(xl + i * W + jj) = xn;
+        sp_store_cols<TC>(reinterpret_cast<char*>(xl + i * W + jj), xn);
     }
     __syncthreads();
 }
@@ -422,14 +435,14 @@ __device__ __forceinline__ void sp_apply_sym(const SpGraph& g, const double* __r
 // adds isd[n] * In[n] = 0 * 0)
 template <int W>
 __device__ __forceinline__ void sp_apply_sym_resident(const SpResGraph& rg, int n, const double* in, double* out) {
-    constexpr int TC = 2, PER_ROW = W / TC, ISD_SHIFT = W == 8 ? 3 : W == 4 ? 2 : 1;  // row byte offset -> isd byte offset
+    constexpr int TC = W >= 2 ? 2 : 1, PER_ROW = W / TC, ISD_SHIFT = W == 8 ? 3 : W == 4 ? 2 : 1;  // row byte offset -> isd byte offset
     const int total = n * PER_ROW;
     const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
     const char* isdb = reinterpret_cast<const char*>(rg.isd);
 #pragma unroll 1
     for (int t = threadIdx.x; t < total; t += SP_THREADS) {
         const int pos = t / PER_ROW, jj = (t % PER_ROW) * TC;
-        const int i = rg.row[pos], my = (rg.len[pos] + 3) >> 2;
+        const int i = rg.row[pos], my = (int)rg.ptr4[pos + 1] - (int)rg.ptr4[pos];
         const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
         const int nch = __builtin_amdgcn_readfirstlane(my);
         const char* col = reinterpret_cast<const char*>(in + jj);
@@ -462,25 +475,25 @@ __device__ __forceinline__ void sp_apply_sym_resident(const SpResGraph& rg, int 
 template <int W>
 __device__ __forceinline__ void sp_apply_sym_cols(const SpResGraph& rg, int n, const double* xs, const double* __restrict__ In,
                                                   double* __restrict__ Out, int c) {
-    constexpr int TC = 2, PER_ROW = W / TC;
+    constexpr int TC = W >= 2 ? 2 : 1, PER_ROW = W / TC;
     const int total = n * PER_ROW;
     const uint2 zz = make_uint2(rg.zoff | (rg.zoff << 16), rg.zoff | (rg.zoff << 16));
 #pragma unroll 1
     for (int t = threadIdx.x; t < total; t += SP_THREADS) {
         const int pos = t / PER_ROW, jj = (t % PER_ROW) * TC;
-        const int i = rg.row[pos], my = (rg.len[pos] + 3) >> 2;
+        const int i = rg.row[pos], my = (int)rg.ptr4[pos + 1] - (int)rg.ptr4[pos];
         const uint2* e = reinterpret_cast<const uint2*>(rg.ent + (int)rg.ptr4[pos] * 4);
         const int nch = __builtin_amdgcn_readfirstlane(my);
         const char* col = reinterpret_cast<const char*>(xs + jj);
-        const double2 self = *reinterpret_cast<const double2*>(In + (int64_t)i * SP_B + c + jj);
+        const double2 self = sp_load_cols<TC>(reinterpret_cast<const char*>(In + (int64_t)i * SP_B + c + jj));
         const double wi = rg.isd[i];
         double a0 = 0.0, a1 = 0.0;
-        SpChunk cur = sp_gather_chunk(col, 0 < my ? e[0] : zz);
+        SpChunk cur = sp_gather_chunk<TC>(col, 0 < my ? e[0] : zz);
         uint2 qn = 1 < my ? e[1] : zz;
 #pragma unroll 1
         for (int k = 0; k < nch; ++k) {
             SpChunk nxt = cur;
-            if (k + 1 < nch) nxt = sp_gather_chunk(col, qn);
+            if (k + 1 < nch) nxt = sp_gather_chunk<TC>(col, qn);
             const uint2 qnn = k + 2 < my ? e[k + 2] : zz;
 #pragma unroll
             for (int u = 0; u < 4; ++u) { a0 += cur.v[u].x; a1 += cur.v[u].y; }
@@ -490,7 +503,7 @@ __device__ __forceinline__ void sp_apply_sym_cols(const SpResGraph& rg, int n, c
         double2 o;
         o.x = self.x - 0.5 * wi * a0;
         o.y = self.y - 0.5 * wi * a1;
-        *reinterpret_cast<double2*>(Out + (int64_t)i * SP_B + c + jj) = o;
+        sp_store_cols<TC>(reinterpret_cast<char*>(Out + (int64_t)i * SP_B + c + jj), o);
     }
 }
 
@@ -785,7 +798,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
 #ifdef SM_SPECTRAL_STAMPS
     if (tid == 0) { for (int k = 0; k < 16; ++k) sh.dbg[k] = 0; sh.dbg_t = __builtin_readcyclecounter(); }
 #endif
-    SpResGraph rg = {nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    SpResGraph rg = {nullptr, nullptr, nullptr, nullptr, 0u};
     constexpr int RW = MODE == 2 ? SP_B : CG;  // doubles per row of the LDS blocks
     bool lds_graph = false;
     double* xa = ylds;                            // MODE 3: the two column-group blocks
@@ -794,8 +807,7 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
         char* base = reinterpret_cast<char*>(ylds);
         double* isdl = reinterpret_cast<double*>(base + sp_resident_isd_offset(n, RW));  // MODE 2 only
         unsigned short* ptr4 = reinterpret_cast<unsigned short*>(isdl + (MODE == 2 ? n + 1 : 0));
-        unsigned short* lenl = ptr4 + n;
-        unsigned short* rowl = lenl + n;
+        unsigned short* rowl = ptr4 + (n + 1);
         unsigned short* ent = reinterpret_cast<unsigned short*>(base + sp_resident_ent_offset(n, RW));
         const int cap4 = (int)((lds_bytes - sp_resident_ent_offset(n, RW)) / 8);  // room for the lists, in groups of four entries
         if (MODE == 2)
@@ -846,19 +858,20 @@ __global__ __launch_bounds__(SP_THREADS) void spectral_embed_kernel(const int* _
                     if (p0 + u < n) {
                         const unsigned key = keys[p0 + u];
                         const int len = (int)(0xffffu - (key >> 16));
-                        rowl[p0 + u] = (unsigned short)(key & 0xffffu); lenl[p0 + u] = (unsigned short)len; ptr4[p0 + u] = (unsigned short)run;
+                        rowl[p0 + u] = (unsigned short)(key & 0xffffu); ptr4[p0 + u] = (unsigned short)run;
                         run += (len + 3) >> 2;
+                        if (p0 + u == n - 1) ptr4[n] = (unsigned short)run;
                     }
         }
         __syncthreads();
         if (lds_graph) {
             for (int t = tid; t < n * 4; t += SP_THREADS) {  // four lanes per list
-                const int pos = t >> 2, i = rowl[pos], cnt = lenl[pos], c4 = (cnt + 3) & ~3, s0 = g.ptr[i];
+                const int pos = t >> 2, i = rowl[pos], cnt = g.len[i], c4 = (cnt + 3) & ~3, s0 = g.ptr[i];
                 unsigned short* e = ent + (int)ptr4[pos] * 4;
                 for (int u = t & 3; u < c4; u += 4) e[u] = (unsigned short)((u < cnt ? g.col[s0 + u] : n) * (RW * 8));
             }
             if (MODE == 2 && tid == 0) isdl[n] = 0.0;  // what a list's padding points at (with the blocks' zero rows)
-            rg.ent = ent; rg.ptr4 = ptr4; rg.len = lenl; rg.row = rowl; rg.isd = MODE == 2 ? isdl : g.isd; rg.zoff = (unsigned)n * (RW * 8);
+            rg.ent = ent; rg.ptr4 = ptr4; rg.row = rowl; rg.isd = MODE == 2 ? isdl : g.isd; rg.zoff = (unsigned)n * (RW * 8);
         }
         __syncthreads();
         if (tid < RW) { xa[n * RW + tid] = 0.0; xb[n * RW + tid] = 0.0; }
@@ -1259,15 +1272,15 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
     const double tol = a->tol > 0.0 ? a->tol : 1e-9;
     {
         // 150 KB of LDS beside the kernel's static 3.2 KB (160 KB per workgroup on gfx950).  MODE 2 when graph (longest possible lists)
-        // and both whole blocks fit; else MODE 3 with the most columns (4 or 2) that leave room for the 2 n m list entries plus one
+        // and both whole blocks fit; else MODE 3 with the most columns (4, 2 or 1) that leave room for the 2 n m list entries plus one
         // entry of padding per row (lists are padded to fours: the kernel sees the real lengths and falls back to MODE 0's steps when
         // they do not fit); else MODE 0 with as many staged columns as fit.
-        constexpr size_t LDS_MAX = 153600;
+        constexpr size_t LDS_MAX = 159744;  // 156 KB dynamic + the static 3.2 KB (3.4 in the stamps build) of 160
         int cg = 0, mode = 0;
         if (sm::sp_resident_bytes(n, m) <= LDS_MAX && (size_t)n * 64 <= 65535) { cg = 8; mode = 2; }  // (16-bit byte offsets of the rows)
-        for (int c : {4, 2})
+        for (int c : {4, 2, 1})
             if (!cg && sm::sp_resident_ent_offset(n, c) + (size_t)(2 * m + 1) * n * 2 <= LDS_MAX && (size_t)n * c * 8 <= 65535) { cg = c; mode = 3; }
-        if (!cg) cg = (size_t)(n + 1) * 8 * 8 <= LDS_MAX ? 8 : (size_t)(n + 1) * 4 * 8 <= LDS_MAX ? 4 : 2;
+        if (!cg) cg = (size_t)(n + 1) * 8 * 8 <= 153600 ? 8 : (size_t)(n + 1) * 4 * 8 <= 153600 ? 4 : 2;
         const size_t lds = mode == 2 ? sm::sp_resident_bytes(n, m) : mode == 3 ? LDS_MAX : (size_t)(n + 1) * cg * 8;
         auto launch = [&](auto kern) {
             static bool once = false;  // per instantiation (the lambda is instantiated per kernel type)
@@ -1284,12 +1297,13 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
         static const char* const names[4][3] = {{"spectral_embed_kernel<8, 0>", "spectral_embed_kernel<4, 0>", "spectral_embed_kernel<2, 0>"},
                                                 {"", "", ""},
                                                 {"spectral_embed_kernel<8, 2>", "", ""},
-                                                {"", "spectral_embed_kernel<4, 3>", "spectral_embed_kernel<2, 3>"}};
-        sm::TapGuard tap2(stream, names[mode][cg == 8 ? 0 : cg == 4 ? 1 : 2], 0.0, Bd * (2.0 * nd * 8 * 8 + 2.0 * nd * m * 4));
+                                                {"spectral_embed_kernel<1, 3>", "spectral_embed_kernel<4, 3>", "spectral_embed_kernel<2, 3>"}};
+        sm::TapGuard tap2(stream, names[mode][cg == 8 || cg == 1 ? 0 : cg == 4 ? 1 : 2], 0.0, Bd * (2.0 * nd * 8 * 8 + 2.0 * nd * m * 4));
         if (mode == 2) launch(&sm::spectral_embed_kernel<8, 2>);
         else if (mode == 3) {
             if (cg == 4) launch(&sm::spectral_embed_kernel<4, 3>);
-            else launch(&sm::spectral_embed_kernel<2, 3>);
+            else if (cg == 2) launch(&sm::spectral_embed_kernel<2, 3>);
+            else launch(&sm::spectral_embed_kernel<1, 3>);
         } else {
             if (cg == 8) launch(&sm::spectral_embed_kernel<8, 0>);
             else if (cg == 4) launch(&sm::spectral_embed_kernel<4, 0>);

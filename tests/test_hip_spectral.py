@@ -24,7 +24,7 @@ def run(x, sizes=(2, 3, 4), n_neighbors=10, **kw):
     return labels[0].cpu().numpy(), {k: v[0].cpu().numpy() for k, v in det.items()}
 
 
-@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (1024, 2), (1444, 3), (1936, 4), (2000, 3), (3136, 2), (3136, 3), (3136, 4), (6400, 3)])
+@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (1024, 2), (1444, 3), (1936, 4), (2000, 3), (2500, 2), (2700, 3), (3136, 2), (3136, 3), (3136, 4), (6400, 3)])
 def test_separable_features_come_back_as_the_true_partition(n, k):
     x, truth = blobs(n, k, seed=n + k)
     labels, det = run(x, (k,))
@@ -34,9 +34,9 @@ def test_separable_features_come_back_as_the_true_partition(n, k):
 
 
 @pytest.mark.parametrize("g,k,seed,nn", [(28, 2, 1, 10), (28, 3, 2, 10), (28, 4, 3, 10), (56, 4, 4, 10), (56, 3, 7, 10), (28, 4, 3, 20), (28, 3, 5, 6),
-                                          (32, 3, 11, 10), (38, 3, 8, 10), (44, 4, 13, 10), (38, 2, 10, 24)])
+                                          (32, 3, 11, 10), (38, 3, 8, 10), (44, 4, 13, 10), (38, 2, 10, 24), (50, 3, 22, 10)])
 # (28^2: graph and both blocks of the recurrence in the LDS for the whole solve; 32^2, 38^2: the graph and 4 columns of the blocks per filter,
-# 44^2: 2 columns; 38^2 with 24 neighbours and 56^2: graph in memory.  2 000 points above: admitted to the 2-column plan by the launch, sent back to
+# 44^2: 2 columns, 50^2: 1 column; 38^2 with 24 neighbours and 56^2: graph in memory.  2 000 points above: admitted to the 2-column plan by the launch, sent back to
 # the graph-in-memory steps by the kernel once it has seen the real list lengths)
 def test_every_stage_against_its_restatement(g, k, seed, nn):
     x, truth = scene(g, k, seed)
