@@ -14,6 +14,10 @@
 // Every sum runs in a fixed order (no floating-point atomics): labels are a function of the input alone.
 #include "common.h"
 
+// no fused multiply-adds the source does not spell out: the eigen-solver's memory plans are different instantiations of the same
+// expressions and must round them alike (tests: the plans give the same bits), and the oracle is numpy
+#pragma clang fp contract(off)
+
 namespace sm {
 
 constexpr int SP_B = 8;          // block of vectors iterated (wanted kw <= 6 + guards)
@@ -312,7 +316,7 @@ __device__ __forceinline__ void sp_filter_step(const SpGraph& g, const double* _
 // neighbour), a wave walks its 16 rows in chunks of four neighbours up to the length of its first (longest) row - k-NN graphs have a
 // long tail (mean 13, maximum 60-70 entries at n = 784), and both the padding of every list to 24 and the serial walk of the hubs'
 // tails through memory (33 k cycles for one 71-entry row: the step's critical path) are gone.  Every row's sum still runs in list
-// order (the padding adds + 0.0): the results are bit-identical to the other modes'.
+// order (the padding adds + 0.0): the results are bit-identical to the other modes' (tests/test_hip_spectral.py, through the tuning build).
 // MODE 3 (826 <= n <= ~2100: the 38 x 50 = 1900 points of a 300 x 400 image) keeps the same graph in the LDS beside CG = 4 or 2 COLUMNS
 // of the two blocks: the recurrence never mixes columns, so a filter runs all its steps on one column group after the other, each
 // resident like MODE 2 (the block itself stays in memory and is read and written once per group and filter); the lists take what the
@@ -1280,6 +1284,10 @@ extern "C" int sm_spectral_cluster_f32(const sm_spectral_args* a, void* stream) 
         if (sm::sp_resident_bytes(n, m) <= LDS_MAX && (size_t)n * 64 <= 65535) { cg = 8; mode = 2; }  // (16-bit byte offsets of the rows)
         for (int c : {4, 2, 1})
             if (!cg && sm::sp_resident_ent_offset(n, c) + (size_t)(2 * m + 1) * n * 2 <= LDS_MAX && (size_t)n * c * 8 <= 65535) { cg = c; mode = 3; }
+#ifdef SM_TUNING  // the tuning build can force the graph-in-memory plan (tests: the plans give the same bits)
+        if (const char* e = getenv("SM_SPECTRAL_PLAN"))
+            if (atoi(e) == 0) { cg = 0; mode = 0; }
+#endif
         if (!cg) cg = (size_t)(n + 1) * 8 * 8 <= 153600 ? 8 : (size_t)(n + 1) * 4 * 8 <= 153600 ? 4 : 2;
         const size_t lds = mode == 2 ? sm::sp_resident_bytes(n, m) : mode == 3 ? LDS_MAX : (size_t)(n + 1) * cg * 8;
         auto launch = [&](auto kern) {

@@ -5,6 +5,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"; mkdir -p gpurun_out/final4; O=gpurun_out/final4
 PART=${1:-ab}
+if [[ $PART == *b* ]]; then  # first: bench.py quotes profiles/r04_pmc_traffic.json only when it was taken on exactly these kernel sources
+TAG=r04 bash scripts/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; cp gpurun_out/r04_pmc_traffic.json $O/; cp gpurun_out/r04_pmc_traffic.json profiles/
+fi
 if [[ $PART == *a* ]]; then
 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > $O/gpu_tests.log; cat $O/gpu_tests.log
 cp gpurun_out/parity_ledger.json $O/r04_parity.json 2>/dev/null
@@ -26,7 +29,6 @@ done
 rm -rf gpurun_out/r04_streams1 gpurun_out/r04_p8 gpurun_out/r04_384 gpurun_out/r04_b1 gpurun_out/r04_refine_384 gpurun_out/r04_pseudo_masks
 fi
 if [[ $PART == *b* ]]; then
-TAG=r04 bash scripts/pmc_traffic.sh > $O/pmc_traffic.log 2>&1; cp gpurun_out/r04_pmc_traffic.json $O/
 TAG=r04 bash scripts/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/r04_pmc_sq_counters.txt $O/ 2>/dev/null
 rm -rf gpurun_out/sq_* gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 for s in 1 2 3 4; do python bench.py --quick --steps 60 --warmup 12 --streams $s 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('streams=$s', d['value'], 'images/s', d['ms_per_step'], 'ms/step')"; done > $O/r04_streams.txt

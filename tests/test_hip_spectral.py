@@ -193,3 +193,39 @@ def test_mask_generator_files_to_encoded_masks(tmp_path):
     for bs, st in ((1, 1), (4, 2)):
         again = MaskGenerator(network=m, device=DEV, batch_size=bs, streams=st)(paths)
         assert again == out
+
+
+def test_the_memory_plans_give_the_same_bits():
+    """The eigen-solver's plans (graph + blocks in the LDS for the whole solve at 28^2; 4 / 2 / 1 columns per filter at 32^2, 44^2, 50^2)
+    against the graph-in-memory plan the tuning build can force (SM_SPECTRAL_PLAN=0): the same sums in the same order - eigenvalues,
+    embedding, residuals and labels bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tuning = os.path.join(root, "salient-object-detection_amd", "lib", "libselfmask_hip_tuning.so")
+    if not os.path.exists(tuning):
+        pytest.skip("tuning library not built (salient-object-detection_amd/build.py --tuning)")
+    code = r"""
+import hashlib, json, os, sys
+import numpy as np, torch
+sys.path[:0] = [os.path.join(sys.argv[1], "salient-object-detection_amd"), sys.argv[1], os.path.join(sys.argv[1], "tests")]
+from selfmask_amd import voting as VT
+from test_oracle_spectral import scene
+out = {}
+for g in (28, 32, 44, 50):
+    x = torch.from_numpy(np.stack([scene(g, 3, 40 + s)[0] for s in range(2)])).cuda()
+    labels, det = VT.spectral_cluster(x, (2, 3, 4), return_details=True)
+    h = hashlib.sha1()
+    for t in (labels, det["eigenvalues"], det["embedding"], det["residuals"], det["info"][:, :3]):
+        h.update(t.cpu().numpy().tobytes())
+    out[str(g)] = h.hexdigest()
+print("RESULT " + json.dumps(out))
+"""
+    got = {}
+    for tag, env in (("resident", {"SM_HIP_LIB": tuning}), ("memory", {"SM_HIP_LIB": tuning, "SM_SPECTRAL_PLAN": "0"})):
+        r = subprocess.run([sys.executable, "-c", code, root], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert got["resident"] == got["memory"], got
