@@ -86,10 +86,11 @@ class MaskGenerator:
         x = (rgb - np.asarray(MEAN, np.float32)) / np.asarray(STD, np.float32)               # normalize
         return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))
 
-    def _batches(self, p_images: Sequence[str]):
+    def _batches(self, p_images: Sequence[str], pack: bool = False):
         """-> (file names, decoded uint8 RGB arrays) per batch of at most ``batch_size`` images that pad to ONE patch grid
         (``pipeline.native_buckets``: the evaluator's native-resolution buckets): the headers give the sizes, the decode processes of the
-        input pipeline (decode_pool.py) the pixels, a few batches ahead of the device.  Largest buckets first."""
+        input pipeline (decode_pool.py) the pixels, a few batches ahead of the device.  Largest buckets first.  ``pack``: the second item
+        is (page-locked staging buffers of the batch, [(H, W)]) assembled on the loader's packing thread - what ``__call__`` consumes."""
         from PIL import Image
         from .pipeline import PrefetchingLoader, native_buckets
         p_images = list(p_images)
@@ -98,19 +99,22 @@ class MaskGenerator:
             with Image.open(p) as im:  # header only
                 sizes.append((im.size[1], im.size[0]))
         batches = sorted(native_buckets(sizes, self.network.encoder.patch_size, self.batch_size), key=len, reverse=True)
-        loader = PrefetchingLoader(_Files(p_images), range(len(p_images)), self.batch_size, workers=self.workers, batches=batches)
+        loader = PrefetchingLoader(_Files(p_images), range(len(p_images)), self.batch_size, workers=self.workers, batches=batches, pack=pack)
         for rgbs, _gts, idx in loader:
             yield [p_images[i].split("/")[-1] for i in idx], rgbs
 
     def _candidates(self, rgbs):
-        """decoded images of one patch grid -> ((B, sum(cluster_sizes), Hp, Wp) uint8 candidates, [(H_b, W_b)]), queued on the current
-        stream: every image zero-padded to the grid's Hp x Wp after normalisation - what ``pad_input_image`` (@L124-134) builds for it
-        alone - and its candidates are the top-left H_b x W_b of its planes"""
+        """decoded images of one patch grid (arrays, or the loader's (staging buffers, shapes)) -> ((B, sum(cluster_sizes), Hp, Wp) uint8
+        candidates, [(H_b, W_b)]), queued on the current stream: every image zero-padded to the grid's Hp x Wp after normalisation - what
+        ``pad_input_image`` (@L124-134) builds for it alone - and its candidates are the top-left H_b x W_b of its planes"""
         from .pipeline import preprocess_on_device
         P = self.network.encoder.patch_size
-        sizes = [(int(r.shape[0]), int(r.shape[1])) for r in rgbs]
+        packed = None
+        if isinstance(rgbs, tuple):
+            packed, rgbs = rgbs
+        sizes = [(int(r[0]), int(r[1])) if packed is not None else (int(r.shape[0]), int(r.shape[1])) for r in rgbs]
         Hp, Wp = -(-max(h for h, _ in sizes) // P) * P, -(-max(w for _, w in sizes) // P) * P
-        x = preprocess_on_device(rgbs, None, self.device, pinned=True, pad_to=(Hp, Wp))  # to_tensor + normalize + pad, on the device
+        x = preprocess_on_device(rgbs, None, self.device, pinned=True, packed=packed, pad_to=(Hp, Wp))  # to_tensor + normalize + pad (device)
         cands = VT.extract_candidate_masks(self.network, x, self.cluster_sizes, cluster_type=self.cluster_type, n_neighbors=self.n_neighbors)
         return (cands[None] if cands.dim() == 3 else cands), sizes
 
@@ -163,7 +167,7 @@ class MaskGenerator:
                 for n, m, (h, w) in zip(names, votes.winners_host().numpy(), sizes):
                     result[n] = m[:h, :w].copy()
 
-        for names, rgbs in self._batches(p_images):
+        for names, rgbs in self._batches(p_images, pack=True):
             with ring.next():
                 cands, sizes = self._candidates(rgbs)
                 votes = VT.vote_mask_batch_async(cands, remove_long_masks, remove_small_large_masks, winners="device" if encode else True,

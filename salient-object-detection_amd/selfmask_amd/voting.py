@@ -60,6 +60,24 @@ def vote_mask(batch_pred_masks: torch.Tensor, remove_long_masks: bool = True, re
     return batch_pred_masks[best_h], prev_to_new[best_h], new_to_prev
 
 
+_ARENAS = {}
+
+
+def _arena(tag: str, nbytes: int, dev) -> torch.Tensor:
+    """``nbytes`` of scratch on ``dev`` for the launches a call queues on the CURRENT stream: one grow-only buffer per (tag, device,
+    stream).  Launches on one stream run in order, so the next call's scratch may be the same memory; nothing handed back to a caller
+    lives here.  (Fresh torch.empty buffers per call - a Gram matrix is hundreds of MB and its size changes with every patch grid -
+    had the caching allocator free and re-allocate device memory batch after batch: a third of the host time of a mixed-size run.)"""
+    dev = torch.device(dev)
+    key = (tag, dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _ARENAS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ARENAS.pop(key, None)
+        buf = _ARENAS[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+    return buf[:nbytes]
+
+
 class PendingVotes:
     """The votes of one batch, queued on a stream: ``result()`` waits for THAT batch's device-to-host copy only, so the caller can
     queue the next batch (on another stream) before asking.  ``winners`` (B, H, W) uint8 is the voted mask of every image on the
@@ -179,7 +197,7 @@ def vote_mask_batch_async(batch_pred_masks: torch.Tensor, remove_long_masks: boo
     nbytes = lib.sm_vote_workspace_bytes(M, H, W)
     if nbytes == 0:
         raise ValueError(f"vote_mask_batch: {M} candidates of {H}x{W} (1..64 candidates)")
-    ws = torch.empty(nbytes * B, dtype=torch.uint8, device=dev)
+    ws = _arena("vote", nbytes * B, dev)
     keep = torch.empty((B, M), dtype=torch.int32, device=dev)
     iou = torch.empty((B, M, M), dtype=torch.float32, device=dev)
     sums = torch.empty((B, M), dtype=torch.float32, device=dev)
@@ -236,7 +254,7 @@ def spectral_cluster(features: torch.Tensor, cluster_sizes: Sequence[int] = (2, 
     if nbytes == 0:
         raise ValueError(f"spectral_cluster: {n} points, n_neighbors {n_neighbors}, {kw} vectors (16 <= n <= 8192, n_neighbors 2..33, k <= 6)")
     dev = f.device
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _arena("spectral", nbytes, dev)
     labels = torch.empty((B, len(sizes), n), dtype=torch.int32, device=dev)
     a = N.SpectralArgs()
     a.features, a.labels = f.data_ptr(), labels.data_ptr()
@@ -259,11 +277,14 @@ def spectral_cluster(features: torch.Tensor, cluster_sizes: Sequence[int] = (2, 
     return (labels, det) if return_details else labels
 
 
-def upsample_tokens_aligned(tokens: torch.Tensor, gh: int, gw: int, scale: int = 2) -> torch.Tensor:
+def upsample_tokens_aligned(tokens: torch.Tensor, gh: int, gw: int, scale: int = 2, scratch: bool = False) -> torch.Tensor:
     """tokens (B, gh*gw, 384) -> (B, scale*gh, scale*gw, 384): F.interpolate(scale_factor=scale, mode="bilinear", align_corners=True)."""
     t = tokens.contiguous().float()
     B = t.shape[0]
-    up = torch.empty((B, scale * gh, scale * gw, N.EMBED), dtype=torch.float32, device=t.device)
+    shape = (B, scale * gh, scale * gw, N.EMBED)
+    # ``scratch``: the result lives in the stream's arena (valid until the next such call on this stream) - extract_candidate_masks
+    up = (_arena("features", 4 * B * scale * gh * scale * gw * N.EMBED, t.device).view(torch.float32).view(shape) if scratch
+          else torch.empty(shape, dtype=torch.float32, device=t.device))
     N.check(N.load().sm_upsample_tokens_aligned_f32(t.data_ptr(), t.stride(0), up.data_ptr(), B, gh, gw, scale,
                                                     torch.cuda.current_stream(t.device).cuda_stream), "sm_upsample_tokens_aligned_f32")
     return up
@@ -311,7 +332,7 @@ def extract_candidate_masks(model, x: torch.Tensor, cluster_sizes=(2, 3, 4), clu
     p = model.encoder.patch_size
     tok = model(x, encoder_only=True)["patch_tokens"]  # (B, gh, gw, 384), final-normed, cls dropped
     gh, gw = tok.shape[1:3]
-    feats = upsample_tokens_aligned(tok.reshape(B, gh * gw, N.EMBED), gh, gw, 2)  # (B, 2gh, 2gw, 384)
+    feats = upsample_tokens_aligned(tok.reshape(B, gh * gw, N.EMBED), gh, gw, 2, scratch=True)  # (B, 2gh, 2gw, 384)
     flat = feats.reshape(B, 4 * gh * gw, N.EMBED)
     if clusterer is not None:
         lab = torch.stack([clusterer(flat, k).reshape(B, 4 * gh * gw).to(torch.int32) for k in cluster_sizes], dim=1)
