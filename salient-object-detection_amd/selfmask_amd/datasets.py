@@ -26,6 +26,50 @@ LAYOUTS = {
 }
 
 
+def probe_size(path: str) -> Tuple[int, int]:
+    """(H, W) of an image file from its header: the JPEG frame header (SOFn) or the PNG IHDR read directly - a few reads per file against
+    PIL's plugin machinery (45 us per file: 0.09 s of a 0.6-s run over 2 048 files) - and PIL itself for anything else or anything odd.
+    Like ``Image.open(path).size``, EXIF orientation is not applied."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(26)
+            if head[:8] == b"\x89PNG\r\n\x1a\n" and head[12:16] == b"IHDR":
+                return int.from_bytes(head[20:24], "big"), int.from_bytes(head[16:20], "big")
+            if head[:2] == b"\xff\xd8":
+                f.seek(2)
+                while True:
+                    b = f.read(1)
+                    if not b:
+                        break
+                    if b != b"\xff":
+                        continue
+                    m = f.read(1)
+                    while m == b"\xff":  # fill bytes
+                        m = f.read(1)
+                    if not m:
+                        break
+                    code = m[0]
+                    if code in (0x01, 0xD8) or 0xD0 <= code <= 0xD7:  # stand-alone markers
+                        continue
+                    if code in (0xD9, 0xDA):  # end of image / start of scan before any frame header
+                        break
+                    seg = f.read(2)
+                    if len(seg) < 2:
+                        break
+                    length = int.from_bytes(seg, "big")
+                    if 0xC0 <= code <= 0xCF and code not in (0xC4, 0xC8, 0xCC):  # SOF0..SOF15 without DHT, JPG, DAC
+                        fr = f.read(5)
+                        if len(fr) == 5:
+                            return int.from_bytes(fr[1:3], "big"), int.from_bytes(fr[3:5], "big")
+                        break
+                    f.seek(length - 2, 1)
+    except OSError:
+        pass
+    with Image.open(path) as im:
+        w, h = im.size
+    return h, w
+
+
 class SaliencyTestDataset:
     def __init__(self, dir_dataset: str, dataset_name: str, eval_img_size: Optional[int] = None):
         if dataset_name not in LAYOUTS:
@@ -43,9 +87,7 @@ class SaliencyTestDataset:
     def image_size(self, ind: int) -> Tuple[int, int]:
         """(H, W) from the file header only (PIL opens lazily): the native-resolution evaluator plans its token-grid buckets
         from these before anything is decoded."""
-        with Image.open(self.p_imgs[ind]) as im:
-            w, h = im.size
-        return h, w
+        return probe_size(self.p_imgs[ind])
 
     def __getitem__(self, ind: int) -> dict:
         image = Image.open(self.p_imgs[ind]).convert("RGB")

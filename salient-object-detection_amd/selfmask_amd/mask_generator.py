@@ -91,13 +91,10 @@ class MaskGenerator:
         (``pipeline.native_buckets``: the evaluator's native-resolution buckets): the headers give the sizes, the decode processes of the
         input pipeline (decode_pool.py) the pixels, a few batches ahead of the device.  Largest buckets first.  ``pack``: the second item
         is (page-locked staging buffers of the batch, [(H, W)]) assembled on the loader's packing thread - what ``__call__`` consumes."""
-        from PIL import Image
+        from .datasets import probe_size
         from .pipeline import PrefetchingLoader, native_buckets
         p_images = list(p_images)
-        sizes = []
-        for p in p_images:
-            with Image.open(p) as im:  # header only
-                sizes.append((im.size[1], im.size[0]))
+        sizes = [probe_size(p) for p in p_images]  # headers only
         batches = sorted(native_buckets(sizes, self.network.encoder.patch_size, self.batch_size), key=len, reverse=True)
         loader = PrefetchingLoader(_Files(p_images), range(len(p_images)), self.batch_size, workers=self.workers, batches=batches, pack=pack)
         for rgbs, _gts, idx in loader:

@@ -175,3 +175,33 @@ def test_loader_falls_back_to_threads_without_shared_memory(tmp_path, monkeypatc
         out = list(PrefetchingLoader(ds, range(len(ds)), 2, workers=2, depth=1))
     assert any("decoding on threads" in str(x.message) for x in w)
     assert sum(len(b[0]) for b in out) == 5 and np.array_equal(out[0][0][0], decode_item(ds.p_imgs[0], ds.p_gts[0])[0])
+
+
+def test_probe_size_reads_what_pil_reads(tmp_path):
+    """datasets.probe_size (JPEG frame header / PNG IHDR read directly) against Image.open(...).size: baseline, progressive and
+    optimised JPEGs, with an EXIF-sized APP1 segment in front, grayscale, PNG (RGB, palette, 16-bit), and a format it hands to PIL."""
+    from PIL import Image
+    from selfmask_amd.datasets import probe_size
+    rng = np.random.Generator(np.random.PCG64(5))
+    files = []
+    for i, (h, w) in enumerate([(300, 400), (37, 53), (1, 1), (641, 17)]):
+        img = Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        for tag, kw in (("base", {}), ("prog", {"progressive": True}), ("opt", {"optimize": True, "quality": 60})):
+            p = str(tmp_path / f"{i}_{tag}.jpg")
+            img.save(p, **kw)
+            files.append(p)
+        p = str(tmp_path / f"{i}_exif.jpg")
+        img.save(p, exif=b"Exif\x00\x00" + bytes(40000))  # a long APP1 segment before the frame header
+        files.append(p)
+        img.convert("L").save(str(tmp_path / f"{i}_gray.jpg"))
+        files.append(str(tmp_path / f"{i}_gray.jpg"))
+        for tag, im2 in (("rgb", img), ("pal", img.convert("P")), ("i16", Image.fromarray(rng.integers(0, 65535, size=(h, w), dtype=np.uint16)))):
+            p = str(tmp_path / f"{i}_{tag}.png")
+            im2.save(p)
+            files.append(p)
+        p = str(tmp_path / f"{i}.bmp")
+        img.save(p)
+        files.append(p)
+    for p in files:
+        with Image.open(p) as im:
+            assert probe_size(p) == (im.size[1], im.size[0]), p
