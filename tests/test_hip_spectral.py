@@ -229,3 +229,52 @@ print("RESULT " + json.dumps(out))
         assert r.returncode == 0, r.stderr[-2000:]
         got[tag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert got["resident"] == got["memory"], got
+
+
+def test_mask_generator_sharded_over_two_ranks(tmp_path):
+    """configs[4] across ranks, rehearsed as two processes on this one GPU with a gloo group: MaskGenerator(...)(files, comm=...) gives every
+    rank the codes of ALL files, equal to the single-process result."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from PIL import Image
+    from selfmask_amd.datasets import synthetic_scene
+    from selfmask_amd.mask_generator import MaskGenerator
+    rng = np.random.Generator(np.random.PCG64(9))
+    paths = []
+    for i, (h, w) in enumerate([(96, 128), (90, 125), (100, 120), (96, 128), (64, 64)]):
+        p = str(tmp_path / f"f{i}.png")
+        Image.fromarray(synthetic_scene(rng, h, w)[0]).save(p)
+        paths.append(p)
+    m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(31, "soft", patch_size=16), strict=True)
+    single = MaskGenerator(network=m.to(DEV), device=DEV, batch_size=2)(paths)
+    code = r"""
+import json, os, sys
+import torch, torch.distributed as dist
+sys.path[:0] = [os.path.join(sys.argv[1], "salient-object-detection_amd"), sys.argv[1]]
+from selfmask_amd import MaskFormer, synthetic_state_dict
+from selfmask_amd.distributed import TorchDistComm
+from selfmask_amd.mask_generator import MaskGenerator
+dist.init_process_group("gloo")
+m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+m.load_state_dict(synthetic_state_dict(31, "soft", patch_size=16), strict=True)
+out = MaskGenerator(network=m.to("cuda:0"), device="cuda:0", batch_size=2)(json.loads(sys.argv[2]), comm=TorchDistComm())
+print("RESULT " + json.dumps(out, sort_keys=True))
+dist.destroy_process_group()
+"""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", code, root, json.dumps(paths)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env={**os.environ, "RANK": str(r), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                                   "HSA_ENABLE_IPC_MODE_LEGACY": "0"}) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so_, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    got = [json.loads([ln for ln in so_.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so_, _ in outs]
+    assert got[0] == got[1] == json.loads(json.dumps(single, sort_keys=True))
+    assert list(got[0]) == sorted(got[0]) and len(got[0]) == 5
