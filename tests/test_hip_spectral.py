@@ -24,7 +24,7 @@ def run(x, sizes=(2, 3, 4), n_neighbors=10, **kw):
     return labels[0].cpu().numpy(), {k: v[0].cpu().numpy() for k, v in det.items()}
 
 
-@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (1024, 2), (1444, 3), (1936, 4), (2000, 3), (2500, 2), (2700, 3), (3136, 2), (3136, 3), (3136, 4), (6400, 3)])
+@pytest.mark.parametrize("n,k", [(784, 2), (784, 3), (784, 4), (840, 3), (900, 2), (1024, 2), (1444, 3), (1936, 4), (2000, 3), (2500, 2), (2700, 3), (3136, 2), (3136, 3), (3136, 4), (6400, 3)])
 def test_separable_features_come_back_as_the_true_partition(n, k):
     x, truth = blobs(n, k, seed=n + k)
     labels, det = run(x, (k,))
