@@ -584,7 +584,7 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=T
            "parity": "UNPINNED: the reference's `clusterings` module is absent in every form; scikit-learn is the witness (tests)"}
     # the generator's own operating point: images at their NATIVE size (mask_generator.pyc@L136-200) - DUTS-TR is mostly 400 x 300:
     # 19 x 25 patches -> 38 x 50 = 1900 points per image (the eigen-solver keeps 2 columns of its blocks in the LDS there)
-    Hn, Wn, Bn = 300, 400, 64
+    Hn, Wn, Bn = 300, 400, 128
     from selfmask_amd import synthetic_images
     xn = torch.from_numpy(synthetic_images(4321, (Bn, 3, Hn, Wn))).to(dev)
     sn = max(4, steps // 3)
