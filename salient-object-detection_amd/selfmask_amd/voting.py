@@ -148,16 +148,15 @@ class PendingRuns:
         import numpy as np
         self._done.synchronize()
         info = self._info_h.numpy()
-        longest = int(min(info[:, 0].max(initial=0), self.cap))
+        longest = int(info[:, 0].max(initial=0))
+        if longest > self.cap:  # more runs than the buffer holds (noise-like masks): once more on the device with room for the longest
+            again = PendingRuns(self.masks, longest, None if self._sizes_dev is None else self.sizes)
+            return again.result()
         starts = self._starts[:, :max(longest, 1)].cpu().numpy()  # only as many columns as the longest code needs
         out = []
         for b in range(info.shape[0]):
             n, first = int(info[b, 0]), int(info[b, 1])
             H, W = self.sizes[b]
-            if n > self.cap:  # more runs than the buffer holds (noise-like masks): this one on the host
-                from .mask_generator import rle_encode
-                out.append(rle_encode(self.masks[b, :H, :W].cpu().numpy()))
-                continue
             bounds = np.concatenate([[0], starts[b, :n], [H * W]])
             counts = np.diff(bounds).tolist()
             out.append({"size": [H, W], "counts": ([0] + counts) if first else counts})

@@ -108,7 +108,7 @@ def test_pack_shapes_bytes_and_batches(h, w):
 @pytest.mark.parametrize("h,w", [(224, 224), (300, 400), (37, 53), (1, 9), (5, 1)])
 def test_run_length_codes_from_the_device(h, w):
     """sm_rle_runs_u8 + the host's differences against mask_generator.rle_encode (COCO's uncompressed form: column-major, zeros first):
-    blobs, a mask starting with a set pixel, all zeros, all ones, any non-zero byte, and more runs than the buffer (host fallback)."""
+    blobs, a mask starting with a set pixel, all zeros, all ones, any non-zero byte, and more runs than the buffer holds (a second pass on the device with a longer one)."""
     from selfmask_amd.mask_generator import rle_decode, rle_encode
     from selfmask_amd.voting import rle_runs_async
     rng = np.random.Generator(np.random.PCG64(h * 7 + w))
