@@ -557,6 +557,7 @@ __device__ __forceinline__ void jacobi_eig_wave(const double (&sym)[36], SpShare
         a[j] = v;
         z[j] = k == j ? 1.0 : 0.0;
     }
+    double prev_off = 0.0;
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0, dia = 0.0;
 #pragma unroll
@@ -569,6 +570,10 @@ __device__ __forceinline__ void jacobi_eig_wave(const double (&sym)[36], SpShare
         off = readlane_d(off, 0);
         dia = readlane_d(dia, 0);
         if (off <= 1e-32 * dia) break;
+        // at the rounding floor (off-diagonal norm below 1e-14 of the diagonal's) a sweep that no longer quarters it is the last one
+        // that helps: some matrices sit just above 1e-32 and would sweep on to the limit of 30
+        if (sweep > 0 && off <= 1e-28 * dia && off >= 0.25 * prev_off) break;
+        prev_off = off;
 #pragma unroll
         for (int r = 0; r < SP_B - 1; ++r) {
             const int pk = k == 7 ? r : (k == r ? 7 : (2 * r - k + 7) % 7);  // this row's partner in round r
@@ -624,25 +629,51 @@ __device__ __forceinline__ void jacobi_eig_wave(const double (&sym)[36], SpShare
     }
 }
 
+// The 8 x 8 Gram matrices of the block on the fp64 matrix cores: acc[tri(a, b)] = sum over rows of P[r][a] Q[r][b] (SYM: the symmetric
+// part, (P[r][a] Q[r][b] + P[r][b] Q[r][a]) / 2), every thread returning with the 36 totals.  v_mfma_f64_16x16x4 takes four rows per
+// issue: lane l feeds A[l % 16][l / 16] and B[l / 16][l % 16] - for the Gram of a block both are the block's entry (row l / 16, column
+// l % 16; columns 8..15 read as 0) - and returns D[l / 16 + 4 r][l % 16] in its four accumulators r.  A wave walks every eighth group
+// of four rows, the eight waves' upper triangles meet in the LDS and are added in wave order.  (Per-lane 36-value accumulators over the
+// rows and a 36-value workgroup butterfly had cost 17 k cycles of a 29 k-cycle Cholesky-QR pass.)
+typedef double sp_d4 __attribute__((ext_vector_type(4)));
+template <bool SYM>
+__device__ __forceinline__ void gram_upper_mfma(const double* P, const double* Q, int n, SpShared& sh, double (&acc)[36]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kk = lane >> 4;
+    sp_d4 c1 = {0.0, 0.0, 0.0, 0.0}, c2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int g = wave; g < n / 4; g += SP_WAVES) {  // n % 4 == 0
+        const int at = (4 * g + kk) * SP_B + col;
+        const double p = col < SP_B ? P[at] : 0.0;
+        const double q = SYM ? (col < SP_B ? Q[at] : 0.0) : p;
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, q, c1, 0, 0, 0);          // D[i][j] += P[r][i] Q[r][j]
+        if (SYM) c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(q, p, c2, 0, 0, 0);  // D[i][j] += Q[r][i] P[r][j]
+    }
+    __syncthreads();  // sh.red may still be read from a previous call
+    if (col < SP_B) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {  // accumulator r of lane l is D[l / 16 + 4 r][l % 16] (the f64 form's own map): rows 0..7 are r = 0, 1
+            const int i = kk + 4 * r;
+            if (i <= col) sh.red[wave * 36 + sp_tri(i, col)] = SYM ? 0.5 * (c1[r] + c2[r]) : c1[r];
+        }
+    }
+    __syncthreads();
+    if (tid < 36) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < SP_WAVES; ++w) s += sh.red[w * 36 + tid];
+        sh.red[SP_WAVES * 36 + tid] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 36; ++i) acc[i] = sh.red[SP_WAVES * 36 + i];
+}
+
 // X <- X R^-1 with R^T R = X^T X + shift * trace * I (Cholesky QR); row-local after one workgroup reduction
 __device__ __forceinline__ void chol_qr_pass(double* __restrict__ X, int n, double shift, SpShared& sh, int* guard) {
     const int tid = threadIdx.x;
     double acc[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll 1
-    for (int r = tid; r < n; r += SP_THREADS) {
-        double x[SP_B];
-#pragma unroll
-        for (int j = 0; j < SP_B; ++j) x[j] = X[(int64_t)r * SP_B + j];
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < SP_B; ++a)
-#pragma unroll
-            for (int b = a; b < SP_B; ++b) acc[t++] += x[a] * x[b];
-    }
-    SP_MARK(0);
-    block_sum<36>(acc, sh.red);
+    gram_upper_mfma<false>(X, X, n, sh, acc);
     SP_MARK(1);
     if (tid < 64) {
         // The factor and its inverse, one COLUMN per lane (lane b = column b; lanes 8.. repeat them): step a of the factorisation needs
@@ -718,21 +749,7 @@ __device__ __forceinline__ void chol_qr_pass(double* __restrict__ X, int n, doub
 __device__ __forceinline__ void rayleigh_ritz(double* __restrict__ Q, double* __restrict__ LQ, int n, SpShared& sh) {
     const int tid = threadIdx.x;
     double acc[36];
-#pragma unroll
-    for (int i = 0; i < 36; ++i) acc[i] = 0.0;
-#pragma unroll 1
-    for (int r = tid; r < n; r += SP_THREADS) {
-        double q[SP_B], l[SP_B];
-#pragma unroll
-        for (int j = 0; j < SP_B; ++j) { q[j] = Q[(int64_t)r * SP_B + j]; l[j] = LQ[(int64_t)r * SP_B + j]; }
-        int t = 0;
-#pragma unroll
-        for (int a = 0; a < SP_B; ++a)
-#pragma unroll
-            for (int b = a; b < SP_B; ++b) acc[t++] += 0.5 * (q[a] * l[b] + q[b] * l[a]);  // the symmetric part
-    }
-    SP_MARK(4);
-    block_sum<36>(acc, sh.red);
+    gram_upper_mfma<true>(Q, LQ, n, sh, acc);  // the symmetric part of Q^T (L Q)
     SP_MARK(5);
     if (tid < 64) jacobi_eig_wave(acc, sh);
     SP_MARK(6);
