@@ -610,7 +610,7 @@ def pseudo_masks_leg(dev, streams, P=16, S=224, B=128, steps=12, warmup=3, cpu=T
     from selfmask_amd.mask_generator import MaskGenerator
     root = tempfile.mkdtemp(prefix="sm_bench_pm_")
     try:
-        distinct, repeat = 256, 8
+        distinct, repeat = 256, 24
         DS.write_synthetic_dataset(root, "duts", distinct, seed=11)
         sub, di = DS.LAYOUTS["duts"][:2]
         for i in range(distinct, distinct * repeat):
