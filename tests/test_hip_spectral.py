@@ -278,3 +278,34 @@ dist.destroy_process_group()
     got = [json.loads([ln for ln in so_.splitlines() if ln.startswith("RESULT ")][-1][7:]) for so_, _ in outs]
     assert got[0] == got[1] == json.loads(json.dumps(single, sort_keys=True))
     assert list(got[0]) == sorted(got[0]) and len(got[0]) == 5
+
+
+def test_mask_generator_odd_inputs(tmp_path):
+    """Grayscale JPEG, RGBA / palette / 16-bit-free PNG, one file, no file: every input reaches the encoder as ``.convert("RGB")`` + to_tensor +
+    normalize (the batches hold what ``_load`` gives), every file comes back with a code of its own size, an empty list gives an empty dict."""
+    from PIL import Image
+    from selfmask_amd.datasets import synthetic_scene
+    from selfmask_amd.mask_generator import MaskGenerator, rle_decode
+    from selfmask_amd.pipeline import preprocess_on_device
+    m = MaskFormer(n_queries=20, patch_size=16, n_decoder_layers=6, return_intermediate=True, use_binary_classifier=True)
+    m.load_state_dict(synthetic_state_dict(31, "soft", patch_size=16), strict=True)
+    gen = MaskGenerator(network=m.to(DEV), device=DEV)
+    assert gen([]) == {}
+    rng = np.random.Generator(np.random.PCG64(3))
+    img = Image.fromarray(synthetic_scene(rng, 80, 112)[0])
+    paths = {}
+    for name, im, kw in (("gray.jpg", img.convert("L"), {}), ("rgba.png", img.convert("RGBA"), {}), ("pal.png", img.convert("P"), {}),
+                         ("cmyk.jpg", img.convert("CMYK"), {})):
+        p = str(tmp_path / name)
+        im.save(p, **kw)
+        paths[name] = p
+    out = gen(list(paths.values()))
+    assert sorted(out) == sorted(paths)
+    for name in paths:
+        assert rle_decode(out[name]).shape == (80, 112)
+    one = gen([paths["gray.jpg"]])
+    assert one == {"gray.jpg": out["gray.jpg"]}  # alone or in a batch: the same code
+    for names, rgbs in gen._batches(list(paths.values())):
+        xb = preprocess_on_device(rgbs, None, DEV, pinned=True, pad_to=(80, 112)).cpu()
+        for n, x in zip(names, xb):
+            assert torch.equal(x, gen._load(paths[n])), n
