@@ -76,6 +76,7 @@ class MaskGenerator:
         self.cluster_sizes, self.cluster_type, self.feature_types = tuple(int(k) for k in cluster_sizes), cluster_type, list(feature_types)
         self.device, self.network, self.batch_size, self.n_neighbors = torch.device(device), network, int(batch_size), int(n_neighbors)
         self.streams, self.workers = max(1, int(streams)), workers
+        self._ring = None  # the streams of __call__, made once: the per-stream scratch of the clusterer (voting._arena) stays bounded
 
     # ---- mask_generator.pyc@L136-200 --------------------------------------------------------------------------------------------
     def _load(self, p_image: str) -> torch.Tensor:
@@ -150,7 +151,11 @@ class MaskGenerator:
             return {n: merged[n] for n in names}  # the list's order, whatever the sharding
         from collections import deque
         from .streams import StreamRing
-        ring = StreamRing(self.device, self.streams)
+        if self._ring is None:
+            self._ring = StreamRing(self.device, self.streams)
+        ring = self._ring
+        ring.home = torch.cuda.current_stream(self.device)  # whatever the caller queued so far is visible to the ring's streams
+        ring.fork()
         pending = deque()
         result: Dict[str, object] = {}
 

@@ -78,6 +78,11 @@ def _arena(tag: str, nbytes: int, dev) -> torch.Tensor:
     return buf[:nbytes]
 
 
+def release_scratch() -> None:
+    """Drop every per-stream scratch buffer of this module (they are grow-only: a run over very large batches keeps its high-water mark)."""
+    _ARENAS.clear()
+
+
 class PendingVotes:
     """The votes of one batch, queued on a stream: ``result()`` waits for THAT batch's device-to-host copy only, so the caller can
     queue the next batch (on another stream) before asking.  ``winners`` (B, H, W) uint8 is the voted mask of every image on the
